@@ -1,0 +1,136 @@
+/*
+ * linne_amd.h -- C-ABI of the MI355X (gfx950) per-frame prediction path, batch form.
+ *
+ * The reference has no FFI for this path: its caller reaches it through LINNEEncoder_EncodeBlock /
+ * LINNEDecoder_DecodeBlock (include/linne_encoder.h:49-54, include/linne_decoder.h:38-43), one block per
+ * call.  liblinne_amd.so keeps those 13 public symbols (include/linne_encoder.h, include/linne_decoder.h
+ * in this directory) and adds the entry points below, which are what those functions call internally and
+ * what a maintainer would bind to feed many frames at once.  Plain pointers and sizes
+ * only; no torch types.  Every function returns a LINNEApiResult value (0 = OK) unless noted.
+ *
+ * Units: a "frame" is one LINNE block (num_samples_per_block samples per channel); a "channel-frame" is
+ * one channel of one frame -- the independent unit of work.
+ *
+ * Data layout (all device buffers are SoA, frame-major, planar):
+ *   pcm / residual : int32_t [num_frames][num_channels][stride]        stride = num_samples_per_block
+ *   params         : int32_t [num_frames][num_channels][LINNE_AMD_PARAM_WORDS]
+ *   stats          : double  [num_frames][num_channels][LINNE_AMD_STAT_WORDS]
+ */
+#ifndef LINNE_AMD_H_INCLUDED
+#define LINNE_AMD_H_INCLUDED
+
+#include <stdint.h>
+
+#define LINNE_AMD_MAX_LAYERS      3
+#define LINNE_AMD_MAX_PARAMS      128
+#define LINNE_AMD_PARAM_WORDS     160     /* per channel-frame, see offsets below */
+#define LINNE_AMD_STAT_WORDS      8
+
+/* params record (int32 words) of one channel-frame:
+ *   [0..1]  pre-emphasis prev (first sample of each stage's input; linne_encoder.c:637,707-709)
+ *   [2..3]  pre-emphasis coefficient, 0..15            (linne_utility.c:158-193)
+ *   [4..6]  number of units per layer (power of two)   (linne_network.c:268-347)
+ *   [7..9]  coefficient right shift per layer          (lpc.c:981-1040)
+ *   [10..]  quantised coefficients, layers back to back (sum of the preset's layer sizes <= 148),
+ *           in filter order (index 0 multiplies the oldest sample; linne_network.c:310-316) */
+#define LINNE_AMD_PRM_PREV    0
+#define LINNE_AMD_PRM_PCOEF   2
+#define LINNE_AMD_PRM_UNITS   4
+#define LINNE_AMD_PRM_RSHIFT  7
+#define LINNE_AMD_PRM_COEF    10
+
+/* stats record (doubles) of one channel-frame, inputs of the host-side block-type decision
+ * (linne_encoder.c:480-529, lpc.c:810-865):
+ *   [0] r0        SIN-window autocorrelation lag 0 of the raw channel
+ *   [1..3] k1..k3 PARCOR coefficients 1..order-1 of that analysis (order = layer-0 size)
+ *   [4] zero_path 1.0 if that Levinson call took the all-zero branch (lpc.c:271-276), else 0.0
+ *   [5] tail      value the channel's analysis leaves in parcor[order] (oracle quirk Q2)
+ *   [6] best_pass index of the winning regulariser
+ *   [7] loss      its L1 loss */
+#define LINNE_AMD_ST_R0     0
+#define LINNE_AMD_ST_K1     1
+#define LINNE_AMD_ST_ZERO   4
+#define LINNE_AMD_ST_TAIL   5
+#define LINNE_AMD_ST_BEST   6
+#define LINNE_AMD_ST_LOSS   7
+
+struct LINNEAmdShape {                  /* batch-wide stream parameters (struct LINNEEncodeParameter) */
+    uint32_t num_channels;
+    uint32_t bits_per_sample;
+    uint32_t num_samples_per_block;     /* = row stride of pcm / residual */
+    uint32_t preset;
+    uint32_t ch_process_method;         /* 0 none, 1 mid/side */
+};
+
+struct LINNEAmdContext;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* number of visible HIP devices (0 when there is none); never fails */
+int LINNEAmd_GetDeviceCount(void);
+
+/* Creates a context on `device`: a scratch arena of about scratch_bytes (0 = default 6 GiB, grown on
+ * demand) and the stream work is issued on.  Returns NULL when the HIP runtime or the device is
+ * unavailable -- there is no CPU fallback. */
+struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t scratch_bytes);
+void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx);
+/* message of the last failure on this context ("" if none) */
+const char *LINNEAmd_GetLastError(const struct LINNEAmdContext *ctx);
+/* grows the scratch arena to at least `bytes` (bigger arena = more frames per launch) */
+int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t bytes);
+/* use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL = own stream */
+int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream);
+
+/* ENCODE hot path, device resident.  Replaces, for every frame of the batch, the numeric core of
+ * LINNEEncoder_EncodeCompressData (linne_encoder.c:613-696) and the analysis half of
+ * LINNEEncoder_DecideBlockDataType (linne_encoder.c:494-503):
+ *   MS (linne_utility.c:120-132) -> 2x pre-emphasis (:158-212) -> per regulariser { per layer { Welch window,
+ *   autocorrelation, Levinson-Durbin (lpc.c:176-366) for every unit count; residual L1 search
+ *   (linne_network.c:268-347); forward (linne_network.c:165-210) } } -> best regulariser (linne_network.c:605-630)
+ *   -> quantisation (lpc.c:981-1040) -> int32 FIR cascade (linne_lpc_predict.c:7-38).
+ * d_pcm: right-justified signed PCM; h_num_samples[f] <= stride is frame f's valid length (host array,
+ * NULL = all frames full).  Work is enqueued on the context's stream; the call returns without
+ * synchronising unless it has to grow the arena. */
+int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *d_pcm, const uint32_t *h_num_samples, uint32_t num_frames,
+        int32_t *d_residual, int32_t *d_params, double *d_stats);
+
+/* DECODE hot path, device resident, in place: d_data holds the entropy-decoded residual on entry and PCM on
+ * return.  Replaces linne_decoder.c:503-522: per channel the int32 synthesis cascade in reverse layer order
+ * (linne_lpc_synthesize.c:8-83), two-stage de-emphasis (linne_utility.c:215-241), then MS->LR
+ * (linne_utility.c:135-147). */
+int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        int32_t *d_data, const uint32_t *h_num_samples, uint32_t num_frames, const int32_t *d_params);
+
+/* Same two paths on host buffers (H2D, kernels, D2H, synchronous); what EncodeBlock / DecodeBlock use. */
+int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *pcm, const uint32_t *num_samples, uint32_t num_frames,
+        int32_t *residual, int32_t *params, double *stats);
+int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        int32_t *data, const uint32_t *num_samples, uint32_t num_frames, const int32_t *params);
+
+/* blocks until everything enqueued on the context's stream has finished */
+int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
+
+/* Timing of the dominant kernel of the last Encode/DecodeFramesDevice call, measured with HIP events on the
+ * context's stream: returns milliseconds (negative if nothing was recorded).  which: 0 = whole call,
+ * 1 = encode autocorrelation kernels, 2 = encode trial-residual kernels, 3 = decode synthesis kernel. */
+double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
+int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);
+
+/* Host entropy stage, batch form (thread pool over frames): serialises analysed frames to .lnn blocks exactly
+ * as linne_encoder.c:698-749,806-855 does.  blocks_out receives the blocks back to back; block_sizes[f] their
+ * byte counts.  pcm is needed for RAW blocks.  parcor_state (in/out, may be NULL = 0.0) carries oracle quirk Q2
+ * across calls.  Returns LINNEApiResult. */
+int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
+        uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
+        uint32_t num_threads);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* LINNE_AMD_H_INCLUDED */

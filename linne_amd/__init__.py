@@ -1,0 +1,213 @@
+"""linne_amd -- Python bindings (ctypes) of liblinne_amd.so, the MI355X-native implementation of the LINNE
+per-frame prediction path behind LINNE's own C API.
+
+The product is the shared library (linne_amd/csrc, built in-tree as linne_amd/liblinne_amd.so); this module
+only loads it and wraps its two interfaces:
+
+* ``api``      -- the 13 LINNE public functions (include/linne_encoder.h, include/linne_decoder.h), host buffers;
+* ``Context``  -- the batch C-ABI of include/linne_amd.h on device-resident buffers (torch tensors are used
+  only to own HBM and to name the HIP stream).
+
+There is no CPU fallback: importing works without a GPU (so the symbol table can be checked), but any
+compute call needs a HIP device, and a missing library raises ImportError.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblinne_amd.so")
+
+PARAM_WORDS = 160
+STAT_WORDS = 8
+PRM_PREV, PRM_PCOEF, PRM_UNITS, PRM_RSHIFT, PRM_COEF = 0, 2, 4, 7, 10
+ST_R0, ST_K1, ST_ZERO, ST_TAIL, ST_BEST, ST_LOSS = 0, 1, 4, 5, 6, 7
+PRESET_LAYERS = {0: (2, 32), 1: (2, 32), 2: (4, 64, 8), 3: (4, 64, 8), 4: (4, 64, 8),
+                 5: (4, 128, 16), 6: (4, 128, 16), 7: (4, 128, 16)}
+PRESET_NUM_REGULARS = {0: 1, 1: 2, 2: 1, 3: 2, 4: 4, 5: 1, 6: 2, 7: 4}
+
+# symbols include/*.h declare (checked by tests/test_abi.py)
+API_SYMBOLS = [
+    "LINNEEncoder_EncodeHeader", "LINNEEncoder_CalculateWorkSize", "LINNEEncoder_Create", "LINNEEncoder_Destroy",
+    "LINNEEncoder_SetEncodeParameter", "LINNEEncoder_EncodeBlock", "LINNEEncoder_EncodeWhole",
+    "LINNEDecoder_DecodeHeader", "LINNEDecoder_CalculateWorkSize", "LINNEDecoder_Create", "LINNEDecoder_Destroy",
+    "LINNEDecoder_SetHeader", "LINNEDecoder_DecodeBlock", "LINNEDecoder_DecodeWhole",
+]
+AMD_SYMBOLS = [
+    "LINNEAmd_GetDeviceCount", "LINNEAmd_ContextCreate", "LINNEAmd_ContextDestroy", "LINNEAmd_GetLastError",
+    "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
+    "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastTimingMs",
+    "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
+]
+
+
+class Shape(C.Structure):
+    _fields_ = [("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32), ("num_samples_per_block", C.c_uint32),
+                ("preset", C.c_uint32), ("ch_process_method", C.c_uint32)]
+
+
+def _load():
+    # torch bundles its own HIP runtime (same soname as /opt/rocm's).  Importing torch FIRST makes
+    # liblinne_amd.so bind to that already-loaded runtime, so both share one HIP context: torch tensors can
+    # be handed to the C-ABI and torch.cuda streams/events see our work.  The other order loads two runtimes.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C linne_amd/csrc`). linne_amd has no pure-Python or CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.LINNEAmd_GetDeviceCount.restype = C.c_int
+    L.LINNEAmd_ContextCreate.restype = C.c_void_p
+    L.LINNEAmd_ContextCreate.argtypes = [C.c_int, C.c_uint64]
+    L.LINNEAmd_ContextDestroy.argtypes = [C.c_void_p]
+    L.LINNEAmd_GetLastError.restype = C.c_char_p
+    L.LINNEAmd_GetLastError.argtypes = [C.c_void_p]
+    L.LINNEAmd_ReserveScratch.argtypes = [C.c_void_p, C.c_uint64]
+    L.LINNEAmd_SetStream.argtypes = [C.c_void_p, C.c_void_p]
+    L.LINNEAmd_EncodeFramesDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32,
+                                              C.c_void_p, C.c_void_p, C.c_void_p]
+    L.LINNEAmd_DecodeFramesDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.LINNEAmd_EncodeFramesHost.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]
+    L.LINNEAmd_DecodeFramesHost.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.LINNEAmd_Synchronize.argtypes = [C.c_void_p]
+    L.LINNEAmd_GetLastTimingMs.restype = C.c_double
+    L.LINNEAmd_GetLastTimingMs.argtypes = [C.c_void_p, C.c_int]
+    L.LINNEAmd_EnableTiming.argtypes = [C.c_void_p, C.c_int]
+    L.LINNEAmd_PackFrames.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
+    return L
+
+
+lib = _load()
+
+
+def device_count():
+    return int(lib.LINNEAmd_GetDeviceCount())
+
+
+class LinneAmdError(RuntimeError):
+    pass
+
+
+class Context:
+    """Batch hot path on one GPU (include/linne_amd.h).  Tensors are torch int32/float64 CUDA(HIP) tensors."""
+
+    def __init__(self, device=0, scratch_bytes=0, use_torch_stream=True):
+        self.h = lib.LINNEAmd_ContextCreate(int(device), int(scratch_bytes))
+        if not self.h:
+            raise LinneAmdError(f"LINNEAmd_ContextCreate(device={device}) failed: no usable HIP device "
+                                "(the prediction path has no CPU fallback)")
+        self.device = int(device)
+        if use_torch_stream:
+            import torch
+            s = torch.cuda.current_stream(self.device).cuda_stream
+            self._check(lib.LINNEAmd_SetStream(self.h, C.c_void_p(s)), "SetStream")
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.LINNEAmd_ContextDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, ret, what):
+        if ret != 0:
+            raise LinneAmdError(f"{what} -> {ret}: {lib.LINNEAmd_GetLastError(self.h).decode()}")
+
+    @staticmethod
+    def shape(nch, bits, block, preset, ms):
+        return Shape(nch, bits, block, preset, int(ms))
+
+    def reserve(self, nbytes):
+        self._check(lib.LINNEAmd_ReserveScratch(self.h, int(nbytes)), "ReserveScratch")
+
+    def enable_timing(self, on=True):
+        lib.LINNEAmd_EnableTiming(self.h, int(on))
+
+    def last_ms(self, which=0):
+        return float(lib.LINNEAmd_GetLastTimingMs(self.h, which))
+
+    def synchronize(self):
+        self._check(lib.LINNEAmd_Synchronize(self.h), "Synchronize")
+
+    def encode_frames(self, shape, pcm, num_samples=None, out=None):
+        """pcm: int32 cuda tensor [F][C][S] -> (residual [F][C][S] int32, params [F][C][160] int32, stats [F][C][8] f64)"""
+        import torch
+        F, Cn, S = pcm.shape
+        assert pcm.dtype == torch.int32 and pcm.is_cuda and pcm.is_contiguous()
+        assert Cn == shape.num_channels and S == shape.num_samples_per_block
+        if out is None:
+            res = torch.empty_like(pcm)
+            prm = torch.zeros((F, Cn, PARAM_WORDS), dtype=torch.int32, device=pcm.device)
+            st = torch.zeros((F, Cn, STAT_WORDS), dtype=torch.float64, device=pcm.device)
+        else:
+            res, prm, st = out
+        ns = None
+        if num_samples is not None:
+            ns = np.ascontiguousarray(num_samples, dtype=np.uint32)
+            assert ns.shape == (F,)
+        self._check(lib.LINNEAmd_EncodeFramesDevice(self.h, C.byref(shape), pcm.data_ptr(), ns.ctypes.data if ns is not None else None,
+                                                    F, res.data_ptr(), prm.data_ptr(), st.data_ptr()), "EncodeFramesDevice")
+        return res, prm, st
+
+    def decode_frames(self, shape, data, params, num_samples=None):
+        """in place: data int32 cuda [F][C][S] residual -> PCM"""
+        import torch
+        F, Cn, S = data.shape
+        assert data.dtype == torch.int32 and data.is_cuda and data.is_contiguous() and params.is_contiguous()
+        ns = None
+        if num_samples is not None:
+            ns = np.ascontiguousarray(num_samples, dtype=np.uint32)
+        self._check(lib.LINNEAmd_DecodeFramesDevice(self.h, C.byref(shape), data.data_ptr(), ns.ctypes.data if ns is not None else None,
+                                                    F, params.data_ptr()), "DecodeFramesDevice")
+        return data
+
+    def encode_frames_host(self, shape, pcm, num_samples=None):
+        """numpy int32 [F][C][S] -> numpy (residual, params, stats)"""
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+        F, Cn, S = pcm.shape
+        res = np.zeros_like(pcm)
+        prm = np.zeros((F, Cn, PARAM_WORDS), dtype=np.int32)
+        st = np.zeros((F, Cn, STAT_WORDS), dtype=np.float64)
+        ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+        self._check(lib.LINNEAmd_EncodeFramesHost(self.h, C.byref(shape), pcm.ctypes.data, ns.ctypes.data if ns is not None else None,
+                                                  F, res.ctypes.data, prm.ctypes.data, st.ctypes.data), "EncodeFramesHost")
+        return res, prm, st
+
+    def decode_frames_host(self, shape, residual, params, num_samples=None):
+        d = np.ascontiguousarray(residual, dtype=np.int32).copy()
+        prm = np.ascontiguousarray(params, dtype=np.int32)
+        ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+        self._check(lib.LINNEAmd_DecodeFramesHost(self.h, C.byref(shape), d.ctypes.data, ns.ctypes.data if ns is not None else None,
+                                                  d.shape[0], prm.ctypes.data), "DecodeFramesHost")
+        return d
+
+
+def pack_frames(shape, pcm, residual, params, stats, num_samples=None, parcor_state=0.0, threads=0):
+    """host entropy stage: numpy arrays of one batch -> (list of block bytes, new parcor_state)"""
+    pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+    residual = np.ascontiguousarray(residual, dtype=np.int32)
+    params = np.ascontiguousarray(params, dtype=np.int32)
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    F = pcm.shape[0]
+    cap = pcm.size * 8 + 64 * F + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    sizes = np.zeros(F, dtype=np.uint32)
+    ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+    st = C.c_double(parcor_state)
+    ret = lib.LINNEAmd_PackFrames(C.byref(shape), pcm.ctypes.data, ns.ctypes.data if ns is not None else None, F,
+                                  residual.ctypes.data, params.ctypes.data, stats.ctypes.data, out.ctypes.data, cap,
+                                  sizes.ctypes.data, C.byref(st), threads or (os.cpu_count() or 1))
+    if ret != 0:
+        raise LinneAmdError(f"PackFrames -> {ret}")
+    blocks, off = [], 0
+    for s in sizes:
+        blocks.append(out[off:off + int(s)].tobytes())
+        off += int(s)
+    return blocks, st.value

@@ -1,0 +1,1065 @@
+/*
+ * lnn_device.hip -- gfx950 (MI355X) kernels of the LINNE per-frame prediction path and their C-ABI
+ * launchers (declared in include/linne_amd.h).
+ *
+ * Bit-exactness rules (DESIGN.md "Arithmetic contract"):
+ *   - this TU is compiled with -ffp-contract=off: every double multiply and add is a separate, correctly
+ *     rounded IEEE-754 operation, issued in the reference's order.  A sum that the reference evaluates as
+ *     one chain is owned by ONE thread here; parallelism comes only from independent chains (lags, units,
+ *     unit-count trials, regulariser passes, samples, channels, frames).
+ *   - libm values the reference takes from glibc (Welch divisor pow(n-1,-2), the SIN window) are computed
+ *     on the host and passed in as tables.
+ *   - int32 filters use 32-bit wrap-around arithmetic (uint32 multiply/add, arithmetic shift).
+ *
+ * Citations are file:line under /root/reference.
+ */
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "linne_amd.h"
+#include "lnn_common.h"
+
+#define LNN_MAXT        8       /* unit-count trials per layer: u = 1,2,...,128 */
+#define LNN_MAXU        128
+#define LNN_MAXP        128
+#define LNN_MAXL        3
+#define LNN_MAXR        4
+#define LNN_MAXCLS      16
+#define LNN_MAXCH       8
+#define LNN_ACW         256     /* autocorrelation words per (job, trial): P + u <= 256 */
+
+/* one distinct frame length of a batch (full frames, the ragged tail, ...) */
+struct DevClass {
+    uint32_t n;                         /* valid samples                                             */
+    uint32_t na;                        /* analysis length (linne_encoder.c:644-655)                 */
+    uint32_t sin_off;                   /* offset of this class's SIN window table                   */
+    uint32_t pad;
+    uint32_t ntrials[LNN_MAXL];
+    uint32_t trial_u[LNN_MAXL][LNN_MAXT];
+    double   trial_div[LNN_MAXL][LNN_MAXT];   /* 4*pow(na/u - 1, -2) from the host libm (lpc.c:199)  */
+};
+
+struct Plan {
+    uint32_t C, S, bits, L, R, ms, F, J;
+    uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
+    double regs[LNN_MAXR];
+    double scale;                       /* 2^-(bits-1), exact */
+    const int32_t *pcm; int32_t *resid; int32_t *prm; double *stats;
+    const uint32_t *cls_of_frame; const DevClass *cls; const double *sintab;
+    int32_t *xint, *xtmp;               /* [F*C][S]                    */
+    double *sig;                        /* [J][2][S]                   */
+    double *wx;                         /* [J][MAXT][S] windowed signal, later |trial residual| */
+    double *acorr;                      /* [J][MAXT][ACW]              */
+    double *tcoef;                      /* [J][MAXT][MAXP]  filter order (reversed LPC order) */
+    double *ptail; uint8_t *ptail_set;  /* [J][MAXT][MAXU]             */
+    double *tloss;                      /* [J][MAXT]                   */
+    double *lparams;                    /* [J][MAXL][MAXP]             */
+    uint32_t *lunits;                   /* [J][MAXL]                   */
+    double *jloss, *jtail;              /* [J]                         */
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * small device helpers
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ double round_away(double d) { return (d >= 0.0) ? floor(d + 0.5) : -floor(-d + 0.5); }   /* lpc.c:49-52 */
+__device__ __forceinline__ int32_t mulshr5(int32_t x, int32_t c) { return (int32_t)((uint32_t)x * (uint32_t)c) >> 5; }
+
+/* Levinson-Durbin, lpc.c:252-324, on a private array a[0..order+1]; r[1..order] are the lags, r0 the
+ * ridge-scaled lag 0 (lpc.c:358).  The reference's u/v vectors are the old a and its mirror:
+ * a_new[i] = u[i] + gamma*v[i] with u = (1,a1..ak,0), v = (0,ak..a1,1), so the update is done in place on
+ * pairs (i, k+1-i).  On return a[1..order] are the LPC coefficients.  parcor_out (optional) gets
+ * parcor[0..order-1] exactly as the reference writes them. */
+__device__ void levinson(const double *r, double r0, uint32_t order, double *a, double *parcor_out)
+{
+    for (uint32_t i = 0; i < order + 2; i++) a[i] = 0.0;
+    a[0] = 1.0;
+    double ek = r0;
+    a[1] = -r[1] / r0;
+    if (parcor_out) parcor_out[0] = r[1] / ek;
+    ek += r[1] * a[1];
+    for (uint32_t k = 1; k < order; k++) {
+        double gamma = 0.0;
+        for (uint32_t i = 0; i < k + 1; i++) gamma += a[i] * r[k + 1 - i];
+        gamma /= -ek;
+        ek *= (1.0 - gamma * gamma);
+        const double a0 = 1.0 + gamma * 0.0;              /* u[0]   + gamma*v[0]   */
+        const double ak1 = 0.0 + gamma * 1.0;             /* u[k+1] + gamma*v[k+1] */
+        uint32_t i = 1, j = k;
+        while (i < j) {
+            const double ai = a[i], aj = a[j];
+            a[i] = ai + gamma * aj;
+            a[j] = aj + gamma * ai;
+            i++; j--;
+        }
+        if (i == j) { const double ai = a[i]; a[i] = ai + gamma * ai; }
+        a[0] = a0; a[k + 1] = ak1;
+        if (parcor_out) parcor_out[k] = -gamma;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K1: per frame -- copy, MS, two pre-emphasis stages, block-type statistics
+ * ---------------------------------------------------------------------------------------------- */
+#define PREP_THREADS 256
+__device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sh)
+{
+    const uint32_t t = threadIdx.x;
+    sh[t] = v; __syncthreads();
+    for (uint32_t s = PREP_THREADS / 2; s > 0; s >>= 1) { if (t < s) sh[t] += sh[t + s]; __syncthreads(); }
+    const int64_t r = sh[0]; __syncthreads();
+    return r;
+}
+__device__ __forceinline__ int64_t block_max_i64(int64_t v, int64_t *sh)
+{
+    const uint32_t t = threadIdx.x;
+    sh[t] = v; __syncthreads();
+    for (uint32_t s = PREP_THREADS / 2; s > 0; s >>= 1) { if (t < s) sh[t] = (sh[t] > sh[t + s]) ? sh[t] : sh[t + s]; __syncthreads(); }
+    const int64_t r = sh[0]; __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
+{
+    __shared__ int64_t sh[PREP_THREADS];
+    __shared__ int32_t sh_coef;
+    __shared__ double sh_r[LNN_MAXCH][8];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const DevClass &c = p.cls[p.cls_of_frame[f]];
+    const uint32_t n = c.n, S = p.S, C = p.C;
+    const int32_t *in = p.pcm + (size_t)f * C * S;
+    int32_t *xa = p.xint + (size_t)f * C * S;
+    int32_t *xb = p.xtmp + (size_t)f * C * S;
+
+    /* copy with zero padding (linne_encoder.c:613-621) and LR -> MS on channels 0/1 (linne_utility.c:120-132) */
+    for (uint32_t s = tid; s < S; s += PREP_THREADS) {
+        for (uint32_t ch = 0; ch < C; ch++) xa[(size_t)ch * S + s] = (s < n) ? in[(size_t)ch * S + s] : 0;
+        if (p.ms && s < n) {
+            const uint32_t l = (uint32_t)in[s], r = (uint32_t)in[(size_t)S + s];
+            const int32_t side = (int32_t)(r - l);
+            xa[(size_t)S + s] = side;
+            xa[s] = (int32_t)(l + (uint32_t)(side >> 1));
+        }
+    }
+    __syncthreads();
+
+    /* two pre-emphasis stages per channel (linne_encoder.c:634-641) */
+    for (uint32_t ch = 0; ch < C; ch++) {
+        int32_t *src = xa + (size_t)ch * S, *dst = xb + (size_t)ch * S;
+        int32_t *rec = p.prm + ((size_t)f * C + ch) * LINNE_AMD_PARAM_WORDS;
+        for (uint32_t stage = 0; stage < 2; stage++) {
+            /* coefficient: linne_utility.c:158-193.  corr0 = sum x[s]^2, corr1 = sum x[s]x[s+1], s < n-1, are
+             * double chains in the reference; when max|x|^2 * n < 2^53 every partial sum is an exactly
+             * representable integer, so any summation order gives the reference's bits (integer path);
+             * otherwise one thread runs the chains in order. */
+            int64_t mx = 0;
+            for (uint32_t s = tid; s < n; s += PREP_THREADS) { const int64_t v = src[s]; const int64_t av = v < 0 ? -v : v; mx = av > mx ? av : mx; }
+            mx = block_max_i64(mx, sh);
+            const bool exact = ((double)mx * (double)mx * (double)n) < 9.0e15;
+            double c0, c1;
+            if (exact) {
+                int64_t s0 = 0, s1 = 0;
+                for (uint32_t s = tid; s + 1 < n; s += PREP_THREADS) { const int64_t a = src[s], b = src[s + 1]; s0 += a * a; s1 += a * b; }
+                s0 = block_sum_i64(s0, sh);
+                s1 = block_sum_i64(s1, sh);
+                c0 = (double)s0; c1 = (double)s1;
+            } else {
+                c0 = 0.0; c1 = 0.0;
+                if (tid == 0) {
+                    double curr = (double)src[0];
+                    for (uint32_t s = 0; s + 1 < n; s++) {
+                        const double succ = (double)src[s + 1];
+                        c0 += curr * curr;
+                        c1 += curr * succ;
+                        curr = succ;
+                    }
+                }
+            }
+            if (tid == 0) {
+                int32_t coef;
+                c1 /= c0;
+                if ((c0 < 1e-6) || (c1 < 0.0)) coef = 0;
+                else { coef = (int32_t)round_away(c1 * 32.0); if (coef >= 16) coef = 15; }
+                sh_coef = coef;
+                rec[LINNE_AMD_PRM_PREV + stage] = src[0];
+                rec[LINNE_AMD_PRM_PCOEF + stage] = coef;
+            }
+            __syncthreads();
+            const int32_t coef = sh_coef;
+            /* linne_utility.c:196-212 with prev := first sample */
+            for (uint32_t s = tid; s < S; s += PREP_THREADS) {
+                int32_t v = src[s];
+                if (s < n) { const int32_t prev = src[s ? s - 1 : 0]; v = (int32_t)((uint32_t)v - (uint32_t)mulshr5(prev, coef)); }
+                dst[s] = v;
+            }
+            __syncthreads();
+            int32_t *t = src; src = dst; dst = t;
+        }
+        /* two stages: xa -> xb -> xa, the pre-emphasised channel is back in xa */
+    }
+
+    /* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW
+     * channel at order P0 = layer-0 size, one chain per (channel, lag) */
+    const uint32_t P0 = p.P[0];
+    const double *sinw = p.sintab + c.sin_off;
+    if (tid < C * (P0 + 1)) {
+        const uint32_t ch = tid / (P0 + 1), lag = tid % (P0 + 1);
+        const int32_t *x = in + (size_t)ch * S;
+        double r = 0.0;
+        if (lag < n) {
+            for (uint32_t i = 0; i + lag < n; i++) {
+                const double a = ((double)x[i] * p.scale) * sinw[i];
+                const double b = ((double)x[i + lag] * p.scale) * sinw[i + lag];
+                r += a * b;
+            }
+        }
+        sh_r[ch][lag] = r;
+    }
+    __syncthreads();
+    if (tid < C) {
+        double a[8], pc[8], rl[8];
+        double *st = p.stats + ((size_t)f * C + tid) * LINNE_AMD_STAT_WORDS;
+        for (uint32_t i = 0; i <= P0; i++) rl[i] = sh_r[tid][i];
+        const double r0 = rl[0] * (1.0 + 0.0);
+        const int zero = (n < P0) || (fabs(r0) < (double)FLT_EPSILON);
+        for (uint32_t i = 0; i < 8; i++) pc[i] = 0.0;
+        if (!zero) levinson(rl, r0, P0, a, pc);
+        st[LINNE_AMD_ST_R0] = rl[0];
+        st[LINNE_AMD_ST_K1 + 0] = pc[1]; st[LINNE_AMD_ST_K1 + 1] = pc[2]; st[LINNE_AMD_ST_K1 + 2] = pc[3];
+        st[LINNE_AMD_ST_ZERO] = zero ? 1.0 : 0.0;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * analysis, one layer at a time over every job = (channel-frame, regulariser pass)
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ const DevClass &job_class(const Plan &p, uint32_t job) { return p.cls[p.cls_of_frame[(job / p.R) / p.C]]; }
+
+/* layer-0 input: the pre-emphasised int32 channel scaled to [-1,1) (linne_encoder.c:661-663) */
+__global__ void k_load_layer0(Plan p)
+{
+    const uint32_t job = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    const DevClass &c = job_class(p, job);
+    if (s >= c.na) return;
+    p.sig[((size_t)job * 2 + 0) * p.S + s] = (double)p.xint[(size_t)(job / p.R) * p.S + s] * p.scale;
+}
+
+/* Welch window for every trial (lpc.c:196-205).  Q1: the middle sample of an odd-length unit is never
+ * written by the reference; it still holds what the previous trial (u/2, even length 2n) left at that
+ * index: its LAST unit's windowed sample at local index m. */
+__global__ void k_window(Plan p, uint32_t layer, uint32_t cur)
+{
+    const uint32_t job = blockIdx.z, t = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    const DevClass &c = job_class(p, job);
+    if (t >= c.ntrials[layer] || s >= c.na) return;
+    const uint32_t u = c.trial_u[layer][t], n = c.na / u;
+    const double div = c.trial_div[layer][t];
+    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    const uint32_t unit = s / n, loc = s - unit * n;
+    double v;
+    if ((n & 1u) && loc == (n >> 1)) {
+        const uint32_t n2 = 2 * n;
+        const double divp = c.trial_div[layer][t - 1];
+        const double w = divp * (double)loc * (double)(n2 - 1 - loc);
+        v = x[(size_t)(u / 2 - 1) * n2 + loc] * w;
+    } else {
+        const uint32_t h = (loc < (n >> 1)) ? loc : (n - 1 - loc);
+        const double w = div * (double)h * (double)(n - 1 - h);
+        v = x[s] * w;
+    }
+    p.wx[((size_t)job * LNN_MAXT + t) * p.S + s] = v;
+}
+
+/* autocorrelation (lpc.c:215-249): one thread per chain (trial, unit, lag), summed in increasing i */
+__global__ void k_autocorr(Plan p, uint32_t layer)
+{
+    const uint32_t job = blockIdx.y;
+    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    const DevClass &c = job_class(p, job);
+    const uint32_t P = p.P[layer];
+    uint32_t t = 0;
+    for (; t < c.ntrials[layer]; t++) {
+        const uint32_t cnt = P + c.trial_u[layer][t];
+        if (q < cnt) break;
+        q -= cnt;
+    }
+    if (t >= c.ntrials[layer]) return;
+    const uint32_t u = c.trial_u[layer][t], n = c.na / u, np = P / u;
+    const uint32_t unit = q / (np + 1), lag = q - unit * (np + 1);
+    const double *w = p.wx + ((size_t)job * LNN_MAXT + t) * p.S + (size_t)unit * n;
+    double r = 0.0;
+    if (lag < n) {
+        const uint32_t cnt = n - lag;
+        for (uint32_t i = 0; i < cnt; i++) r += w[i] * w[i + lag];
+    }
+    p.acorr[((size_t)job * LNN_MAXT + t) * LNN_ACW + q] = r;
+}
+
+/* ridge + Levinson-Durbin per (trial, unit) (lpc.c:327-366, 578-633 with zero AF iterations), lanes = jobs.
+ * Writes the coefficients in filter order (reversed, linne_network.c:310-316). */
+__global__ void k_levinson(Plan p, uint32_t layer)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= p.J) return;
+    const DevClass &c = job_class(p, job);
+    uint32_t pr = blockIdx.y, t = 0;
+    for (; t < c.ntrials[layer]; t++) {
+        if (pr < c.trial_u[layer][t]) break;
+        pr -= c.trial_u[layer][t];
+    }
+    if (t >= c.ntrials[layer]) return;
+    const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u, unit = pr;
+    const uint32_t P0 = p.P[0];
+    const double reg = p.regs[job % p.R];
+    const double *r = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    double a[LNN_MAXP + 2];
+    double tail = 0.0; int tail_set = 0;
+    int zero = 0;
+    if (n < np) {                                           /* lpc.c:349-355 */
+        zero = 1;
+    } else {
+        const double r0 = r[0] * (1.0 + reg);               /* lpc.c:358 */
+        if (fabs(r0) < (double)FLT_EPSILON) zero = 1;       /* lpc.c:271-276, 597-602 */
+        else {
+            double pc[LNN_MAXP + 1];
+            levinson(r, r0, np, a, (layer + 1 == p.L) ? pc : nullptr);
+            if (layer + 1 == p.L && np > P0) { tail = pc[P0]; tail_set = 1; }
+        }
+    }
+    if (zero) {
+        for (uint32_t k = 0; k < np; k++) h[k] = 0.0;
+        if (np >= P0) { tail = 0.0; tail_set = 1; }         /* zero branches write parcor[0..order] */
+    } else {
+        for (uint32_t k = 0; k < np; k++) h[k] = a[np - k];
+    }
+    if (layer + 1 == p.L) {
+        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
+        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
+    }
+}
+
+/* trial residual magnitude (linne_network.c:318-335): residual = x[s]; residual += h[k]*x[s-p+k] in k order;
+ * taps that would read before the start of the frame are skipped (unit 0 ramp, :320-327).  |residual| is
+ * stored over the (dead) windowed signal; sample 0 contributes nothing to the loss. */
+#define RES_THREADS 256
+__global__ __launch_bounds__(RES_THREADS) void k_trial_residual(Plan p, uint32_t layer, uint32_t cur)
+{
+    __shared__ double xs[RES_THREADS + LNN_MAXP];
+    const uint32_t job = blockIdx.z, t = blockIdx.y, s0 = blockIdx.x * RES_THREADS, tid = threadIdx.x;
+    const DevClass &c = job_class(p, job);
+    if (t >= c.ntrials[layer] || s0 >= c.na) return;
+    const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u;
+    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    /* tile [s0 - MAXP, s0 + RES_THREADS) */
+    for (uint32_t i = tid; i < RES_THREADS + LNN_MAXP; i += RES_THREADS) {
+        const int64_t g = (int64_t)s0 - LNN_MAXP + i;
+        xs[i] = (g >= 0 && g < (int64_t)c.na) ? x[g] : 0.0;
+    }
+    __syncthreads();
+    const uint32_t s = s0 + tid;
+    if (s >= c.na) return;
+    const uint32_t unit = s / n;
+    const double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    double res = xs[tid + LNN_MAXP];
+    const uint32_t kstart = (s < np) ? (np - s) : 0;       /* skip taps before sample 0 */
+    for (uint32_t k = kstart; k < np; k++) res += h[k] * xs[tid + LNN_MAXP - np + k];
+    double av = (res > 0) ? res : -res;                     /* LINNEUTILITY_ABS */
+    if (s == 0) av = 0.0;
+    p.wx[((size_t)job * LNN_MAXT + t) * p.S + s] = av;
+}
+
+/* mean |residual| per trial: ONE chain over all samples of all units (linne_network.c:326,334,337) */
+__global__ void k_loss_sum(Plan p, uint32_t layer)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    if (job >= p.J) return;
+    const DevClass &c = job_class(p, job);
+    if (t >= c.ntrials[layer]) return;
+    const double *a = p.wx + ((size_t)job * LNN_MAXT + t) * p.S;
+    double loss = 0.0;
+    uint32_t s = 0;
+    for (; s + 8 <= c.na; s += 8) {
+        const double v0 = a[s], v1 = a[s + 1], v2 = a[s + 2], v3 = a[s + 3], v4 = a[s + 4], v5 = a[s + 5], v6 = a[s + 6], v7 = a[s + 7];
+        loss += v0; loss += v1; loss += v2; loss += v3; loss += v4; loss += v5; loss += v6; loss += v7;
+    }
+    for (; s < c.na; s++) loss += a[s];
+    p.tloss[(size_t)job * LNN_MAXT + t] = loss / (double)c.na;
+}
+
+/* strict-< argmin over the trials (linne_network.c:338-341), keep its coefficients (== SetParameter,
+ * :350-376, which recomputes the same values) and, for the last layer, the value the layer leaves in
+ * parcor[P0] (Q2): the last call in reference order -- trials in order, then SetParameter's units -- that
+ * wrote it. */
+__global__ void k_select(Plan p, uint32_t layer)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= p.J) return;
+    const DevClass &c = job_class(p, job);
+    double min_loss = (double)FLT_MAX;
+    uint32_t best = 0; int found = 0;
+    for (uint32_t t = 0; t < c.ntrials[layer]; t++) {
+        const double l = p.tloss[(size_t)job * LNN_MAXT + t];
+        if (l < min_loss) { min_loss = l; best = t; found = 1; }
+    }
+    (void)found;
+    const uint32_t P = p.P[layer];
+    p.lunits[(size_t)job * LNN_MAXL + layer] = c.trial_u[layer][best];
+    const double *h = p.tcoef + ((size_t)job * LNN_MAXT + best) * LNN_MAXP;
+    double *dst = p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP;
+    for (uint32_t k = 0; k < P; k++) dst[k] = h[k];
+    if (layer + 1 == p.L) {
+        double tail = 0.0; int set = 0;
+        const uint32_t bu = c.trial_u[layer][best];
+        for (int32_t unit = (int32_t)bu - 1; unit >= 0 && !set; unit--) {
+            const size_t o = ((size_t)job * LNN_MAXT + best) * LNN_MAXU + unit;
+            if (p.ptail_set[o]) { tail = p.ptail[o]; set = 1; }
+        }
+        for (int32_t t = (int32_t)c.ntrials[layer] - 1; t >= 0 && !set; t--)
+            for (int32_t unit = (int32_t)c.trial_u[layer][t] - 1; unit >= 0 && !set; unit--) {
+                const size_t o = ((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit;
+                if (p.ptail_set[o]) { tail = p.ptail[o]; set = 1; }
+            }
+        p.jtail[job] = tail;
+    }
+}
+
+/* forward with the chosen units (linne_network.c:165-210): predict = 0; predict += h[j]*din[i-p+j]; data[i] += predict */
+__global__ __launch_bounds__(RES_THREADS) void k_forward(Plan p, uint32_t layer, uint32_t cur)
+{
+    __shared__ double xs[RES_THREADS + LNN_MAXP];
+    const uint32_t job = blockIdx.y, s0 = blockIdx.x * RES_THREADS, tid = threadIdx.x;
+    const DevClass &c = job_class(p, job);
+    if (s0 >= c.na) return;
+    const uint32_t P = p.P[layer], u = p.lunits[(size_t)job * LNN_MAXL + layer], n = c.na / u, np = P / u;
+    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    double *y = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
+    for (uint32_t i = tid; i < RES_THREADS + LNN_MAXP; i += RES_THREADS) {
+        const int64_t g = (int64_t)s0 - LNN_MAXP + i;
+        xs[i] = (g >= 0 && g < (int64_t)c.na) ? x[g] : 0.0;
+    }
+    __syncthreads();
+    const uint32_t s = s0 + tid;
+    if (s >= c.na) return;
+    const uint32_t unit = s / n;
+    const double *h = p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP + (size_t)unit * np;
+    double out = xs[tid + LNN_MAXP];
+    if (s != 0) {
+        double pred = 0.0;
+        const uint32_t kstart = (s < np) ? (np - s) : 0;
+        for (uint32_t k = kstart; k < np; k++) pred += h[k] * xs[tid + LNN_MAXP - np + k];
+        out += pred;
+    }
+    y[s] = out;
+}
+
+/* L1 loss of the last layer's output (linne_network.c:50-63): one chain */
+__global__ void k_final_loss(Plan p, uint32_t cur)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= p.J) return;
+    const DevClass &c = job_class(p, job);
+    const double *a = p.sig + ((size_t)job * 2 + cur) * p.S;
+    double norm = 0.0;
+    uint32_t s = 0;
+    for (; s + 8 <= c.na; s += 8) {
+        const double v0 = fabs(a[s]), v1 = fabs(a[s + 1]), v2 = fabs(a[s + 2]), v3 = fabs(a[s + 3]);
+        const double v4 = fabs(a[s + 4]), v5 = fabs(a[s + 5]), v6 = fabs(a[s + 6]), v7 = fabs(a[s + 7]);
+        norm += v0; norm += v1; norm += v2; norm += v3; norm += v4; norm += v5; norm += v6; norm += v7;
+    }
+    for (; s < c.na; s++) norm += fabs(a[s]);
+    p.jloss[job] = norm / (double)c.na;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * finalize per channel-frame: best regulariser, quantisation, int32 FIR cascade
+ * ---------------------------------------------------------------------------------------------- */
+#define FIN_THREADS 256
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
+{
+    __shared__ int32_t s_coef[LNN_MAXL][LNN_MAXP];
+    __shared__ uint32_t s_rshift[LNN_MAXL], s_units[LNN_MAXL], s_best;
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x;
+    const DevClass &c = p.cls[p.cls_of_frame[cf / p.C]];
+    const uint32_t n = c.n, S = p.S;
+    int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    double *st = p.stats + (size_t)cf * LINNE_AMD_STAT_WORDS;
+
+    if (tid == 0) {     /* linne_network.c:618-626 */
+        double min_loss = (double)FLT_MAX; uint32_t best = 0;
+        for (uint32_t r = 0; r < p.R; r++) { const double l = p.jloss[(size_t)cf * p.R + r]; if (l < min_loss) { min_loss = l; best = r; } }
+        s_best = best;
+        st[LINNE_AMD_ST_TAIL] = p.jtail[(size_t)cf * p.R + best];
+        st[LINNE_AMD_ST_BEST] = (double)best;
+        st[LINNE_AMD_ST_LOSS] = p.jloss[(size_t)cf * p.R + best];
+    }
+    __syncthreads();
+    const uint32_t job = cf * p.R + s_best;
+    if (tid < p.L) {    /* lpc.c:981-1040 over all units of the layer together */
+        const uint32_t l = tid, P = p.P[l];
+        const double *d = p.lparams + ((size_t)job * LNN_MAXL + l) * LNN_MAXP;
+        double mx = 0.0;
+        for (uint32_t k = 0; k < P; k++) if (mx < fabs(d[k])) mx = fabs(d[k]);
+        uint32_t rshift;
+        if (mx <= 0.0078125) {                              /* 2^-(8-1) */
+            rshift = 8;
+            for (uint32_t k = 0; k < P; k++) s_coef[l][k] = 0;
+        } else {
+            int ndigit; (void)frexp(mx, &ndigit);
+            rshift = (uint32_t)(7 - ndigit);
+            const double sc = ldexp(1.0, (int)rshift);       /* pow(2.0, rshift), exact */
+            double qerr = 0.0;
+            for (int32_t k = (int32_t)P - 1; k >= 0; k--) {
+                qerr += d[k] * sc;
+                int32_t q = (int32_t)round_away(qerr);
+                if (q >= 128) q = 127; else if (q < -128) q = -128;
+                qerr -= (double)q;
+                s_coef[l][k] = q;
+            }
+        }
+        s_rshift[l] = rshift;
+        s_units[l] = p.lunits[(size_t)job * LNN_MAXL + l];
+        rec[LINNE_AMD_PRM_UNITS + l] = (int32_t)s_units[l];
+        rec[LINNE_AMD_PRM_RSHIFT + l] = (int32_t)rshift;
+        for (uint32_t k = 0; k < P; k++) rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + k] = s_coef[l][k];
+    }
+    __syncthreads();
+    /* FIR cascade (linne_encoder.c:687-696, linne_lpc_predict.c:7-38) on the n valid samples */
+    int32_t *src = p.xint + (size_t)cf * S, *dst = p.xtmp + (size_t)cf * S;
+    for (uint32_t l = 0; l < p.L; l++) {
+        const uint32_t units = s_units[l], np = p.P[l] / units, ns = n / units, rs = s_rshift[l];
+        const uint32_t half = 1u << ((rs - 1u) & 31u);
+        int32_t *out = (l + 1 == p.L) ? (p.resid + (size_t)cf * S) : dst;
+        for (uint32_t s = tid; s < n; s += FIN_THREADS) {
+            int32_t v = src[s];
+            const uint32_t unit = s / (ns ? ns : 1u);
+            if (ns >= np && unit < units) {
+                const uint32_t loc = s - unit * ns;
+                if (loc >= np) {
+                    uint32_t pred = half;
+                    const int32_t *cc = s_coef[l] + unit * np;
+                    const int32_t *xx = src + (size_t)unit * ns + loc - np;
+                    for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
+                    v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
+                }
+            }
+            out[s] = v;
+        }
+        if (l + 1 == p.L) for (uint32_t s = n + tid; s < S; s += FIN_THREADS) out[s] = 0;
+        __syncthreads();
+        if (l + 1 < p.L) { int32_t *t = src; src = dst; dst = t; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * decode: synthesis cascade + de-emphasis per channel-frame (one wavefront), MS->LR per frame
+ * ---------------------------------------------------------------------------------------------- */
+struct DecPlan {
+    uint32_t C, S, L, ms, F;
+    uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
+    int32_t *data; const int32_t *prm; const uint32_t *nsmp;
+};
+
+/* wrap-around sum of one int per lane over the 64-lane wavefront (associative, so a DPP tree is exact) */
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   /* row_bcast:15 -> rows 1,3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   /* row_bcast:31 -> rows 2,3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+#define SYN_LDS_MAX_SAMPLES 36864      /* 144 KiB of the CU's 160 KiB LDS */
+__global__ __launch_bounds__(64) void k_synthesize(DecPlan p, uint32_t lds_samples)
+{
+    extern __shared__ __attribute__((aligned(16))) int32_t lds[];   /* lds_samples words + 128 coefficient words */
+    int32_t *cpad = lds + lds_samples;
+    const uint32_t cf = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = p.nsmp[cf / p.C], S = p.S;
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    int32_t *g = p.data + (size_t)cf * S;
+    const bool use_lds = (n <= lds_samples);
+    int32_t *d = use_lds ? lds : g;
+    if (use_lds) { for (uint32_t s = lane; s < n; s += 64) lds[s] = g[s]; }
+    __syncthreads();
+    /* linne_decoder.c:503-509: layers in reverse order; linne_lpc_synthesize.c:8-83: units independent */
+    for (int32_t l = (int32_t)p.L - 1; l >= 0; l--) {
+        const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
+        const uint32_t np = p.P[l] / units, ns = n / units;
+        const uint32_t half = 1u << ((rs - 1u) & 31u);
+        if (ns < np) continue;
+        for (uint32_t unit = 0; unit < units; unit++) {
+            int32_t *x = d + (size_t)unit * ns;
+            /* zero-extended coefficient ring: tap j of the 128-window [t-128, t) */
+            __syncthreads();
+            for (uint32_t j = lane; j < 128; j += 64) cpad[j] = (j >= 128 - np) ? rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + unit * np + (j - (128 - np))] : 0;
+            __syncthreads();
+            /* history ring: slot m holds x[t'] with t' = m (mod 128); preload the first np samples */
+            int32_t h0 = 0, h1 = 0;
+            if (lane < np) h0 = x[lane];
+            if (lane + 64 < np) h1 = x[lane + 64];
+            for (uint32_t t = np; t < ns; t++) {
+                const int32_t ca = cpad[(lane - t) & 127u], cb = cpad[(lane + 64u - t) & 127u];
+                const int32_t acc = (int32_t)((uint32_t)h0 * (uint32_t)ca + (uint32_t)h1 * (uint32_t)cb);
+                const uint32_t pred = half + (uint32_t)wave_sum_i32(acc);
+                const int32_t y = (int32_t)((uint32_t)x[t] - (uint32_t)((int32_t)pred >> (rs & 31u)));
+                if (lane == 0) x[t] = y;
+                const uint32_t slot = t & 127u;
+                if (lane == (slot & 63u)) { if (slot & 64u) h1 = y; else h0 = y; }
+            }
+        }
+    }
+    __syncthreads();
+    /* two-stage de-emphasis (linne_utility.c:215-241): stage-2 inverse then stage-1 inverse, fused */
+    if (lane == 0 && n > 0) {
+        const int32_t c0 = rec[LINNE_AMD_PRM_PCOEF + 0], c1 = rec[LINNE_AMD_PRM_PCOEF + 1];
+        int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
+        for (uint32_t s = 0; s < n; s++) {
+            const int32_t z = (int32_t)((uint32_t)d[s] + (uint32_t)mulshr5(zp, c1));
+            const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0));
+            d[s] = y; zp = z; yp = y;
+        }
+    }
+    __syncthreads();
+    if (use_lds) { for (uint32_t s = lane; s < n; s += 64) g[s] = lds[s]; }
+}
+
+/* MS -> LR (linne_utility.c:135-147) */
+__global__ void k_ms_to_lr(DecPlan p)
+{
+    const uint32_t f = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.nsmp[f]) return;
+    int32_t *m = p.data + (size_t)f * p.C * p.S, *sd = m + p.S;
+    const uint32_t l = (uint32_t)m[s] - (uint32_t)(sd[s] >> 1);
+    m[s] = (int32_t)l;
+    sd[s] = (int32_t)((uint32_t)sd[s] + l);
+}
+
+/* ================================================================================================
+ * host side of this TU: context, scratch arena, launch sequences, C-ABI
+ * ============================================================================================== */
+struct LINNEAmdContext {
+    int device;
+    hipStream_t stream; int own_stream;
+    void *arena; uint64_t arena_bytes;
+    char err[256];
+    int timing;
+    hipEvent_t ev[2]; int ev_valid;
+    float last_ms[4];
+    /* cached class tables */
+    DevClass *d_cls; double *d_sin; uint64_t sin_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
+};
+
+#define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
+
+static const uint32_t k_layers_a[] = { 2, 32 }, k_layers_b[] = { 4, 64, 8 }, k_layers_c[] = { 4, 128, 16 };
+static const double k_regs_1[] = { 0.0 }, k_regs_2[] = { 0.0, 1.0 / 512.0 }, k_regs_4[] = { 0.0, 1.0 / 2048.0, 1.0 / 512.0, 1.0 / 128.0 };
+
+extern "C" int lnn_preset_info(uint32_t preset, uint32_t *num_layers, uint32_t *layers, uint32_t *num_regs, double *regs)
+{   /* libs/linne_internal/src/linne_internal.c:16-41 */
+    const uint32_t *L; const double *R; uint32_t nl, nr;
+    if (preset >= 8) return -1;
+    if (preset < 2) { L = k_layers_a; nl = 2; } else if (preset < 5) { L = k_layers_b; nl = 3; } else { L = k_layers_c; nl = 3; }
+    switch (preset) { case 0: case 2: case 5: R = k_regs_1; nr = 1; break; case 1: case 3: case 6: R = k_regs_2; nr = 2; break; default: R = k_regs_4; nr = 4; }
+    if (num_layers) *num_layers = nl;
+    if (layers) for (uint32_t i = 0; i < nl; i++) layers[i] = L[i];
+    if (num_regs) *num_regs = nr;
+    if (regs) for (uint32_t i = 0; i < nr; i++) regs[i] = R[i];
+    return 0;
+}
+
+extern "C" int LINNEAmd_GetDeviceCount(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t scratch_bytes)
+{
+    int n = 0;
+    hipError_t e;
+#define CC_FAIL(what) do { fprintf(stderr, "liblinne_amd: ContextCreate(device=%d): %s: %s\n", device, what, hipGetErrorString(e)); } while (0)
+    if ((e = hipGetDeviceCount(&n)) != hipSuccess) { CC_FAIL("hipGetDeviceCount"); return NULL; }
+    if (n <= 0 || device < 0 || device >= n) { fprintf(stderr, "liblinne_amd: ContextCreate(device=%d): %d HIP device(s) visible\n", device, n); return NULL; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { CC_FAIL("hipSetDevice"); return NULL; }
+    LINNEAmdContext *ctx = (LINNEAmdContext *)calloc(1, sizeof(*ctx));
+    if (!ctx) return NULL;
+    ctx->device = device;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { CC_FAIL("hipStreamCreate"); free(ctx); return NULL; }
+    ctx->own_stream = 1;
+    if (scratch_bytes == 0) scratch_bytes = 6ull << 30;
+    if ((e = hipMalloc(&ctx->arena, scratch_bytes)) != hipSuccess) { CC_FAIL("hipMalloc(arena)"); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
+    ctx->arena_bytes = scratch_bytes;
+    if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
+    if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
+    for (int i = 0; i < 4; i++) ctx->last_ms[i] = -1.0f;
+#undef CC_FAIL
+    return ctx;
+}
+
+extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
+{
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->arena) hipFree(ctx->arena);
+    if (ctx->d_cls) hipFree(ctx->d_cls);
+    if (ctx->d_sin) hipFree(ctx->d_sin);
+    if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
+    if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
+    hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    free(ctx);
+}
+
+extern "C" const char *LINNEAmd_GetLastError(const struct LINNEAmdContext *ctx) { return ctx ? ctx->err : "no context"; }
+
+extern "C" int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (hip_stream) {
+        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+        ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = 0;
+    } else if (!ctx->own_stream) {
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = 1;
+    }
+    return LNN_OK;
+}
+
+extern "C" int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t bytes)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    if (ctx->arena_bytes >= bytes) return LNN_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    void *fresh = NULL;
+    if (hipMalloc(&fresh, bytes) != hipSuccess) { (void)hipGetLastError(); snprintf(ctx->err, sizeof(ctx->err), "cannot reserve %llu bytes of scratch", (unsigned long long)bytes); return LNN_NG; }
+    if (ctx->arena) HIPCHK(ctx, hipFree(ctx->arena));
+    ctx->arena = fresh; ctx->arena_bytes = bytes;
+    return LNN_OK;
+}
+
+extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return LNN_OK;
+}
+
+extern "C" int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable) { if (!ctx) return LNN_INVALID_ARGUMENT; ctx->timing = enable; return LNN_OK; }
+extern "C" double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which)
+{
+    if (!ctx || which < 0 || which > 3) return -1.0;
+    if (which == 0 && ctx->ev_valid) {
+        float ms = -1.0f;
+        if (hipEventSynchronize(ctx->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_ms[0] = ms;
+    }
+    return ctx->last_ms[which];
+}
+
+static int ensure_buf(LINNEAmdContext *ctx, void **ptr, uint64_t *cap, uint64_t need)
+{
+    if (*cap >= need) return LNN_OK;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*ptr) HIPCHK(ctx, hipFree(*ptr));
+    *ptr = NULL; *cap = 0;
+    HIPCHK(ctx, hipMalloc(ptr, need));
+    *cap = need;
+    return LNN_OK;
+}
+
+struct HostShape { uint32_t L, R, P[LNN_MAXL], coef_off[LNN_MAXL], maxP; double regs[LNN_MAXR]; };
+static int shape_info(const struct LINNEAmdShape *s, HostShape *h)
+{
+    if (!s || s->preset >= 8 || s->num_channels == 0 || s->num_channels > LNN_MAXCH || s->bits_per_sample == 0 || s->bits_per_sample > 32
+            || s->num_samples_per_block == 0 || s->ch_process_method > 1 || (s->ch_process_method == 1 && s->num_channels < 2)) return LNN_INVALID_FORMAT;
+    lnn_preset_info(s->preset, &h->L, h->P, &h->R, h->regs);
+    uint32_t off = 0; h->maxP = 0;
+    for (uint32_t l = 0; l < h->L; l++) { h->coef_off[l] = off; off += h->P[l]; if (h->P[l] > h->maxP) h->maxP = h->P[l]; }
+    for (uint32_t l = 0; l < h->L; l++) if (s->num_samples_per_block <= h->P[l]) return LNN_INVALID_FORMAT;   /* linne_encoder.c:176-181 */
+    return LNN_OK;
+}
+
+/* Builds the per-length classes of a batch and uploads them (tables are host libm values). */
+static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const HostShape *hs,
+        const uint32_t *h_num_samples, uint32_t F, int for_encode, uint32_t **h_clsidx_out)
+{
+    DevClass cls[LNN_MAXCLS];
+    uint32_t ncls = 0;
+    const uint32_t S = shape->num_samples_per_block;
+    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (F ? F : 1));
+    uint32_t *nsm = (uint32_t *)malloc(sizeof(uint32_t) * (F ? F : 1));
+    if (!idx || !nsm) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
+    memset(cls, 0, sizeof(cls));
+    uint64_t sin_total = 0;
+    for (uint32_t f = 0; f < F; f++) {
+        const uint32_t n = h_num_samples ? h_num_samples[f] : S;
+        if (n == 0 || n > S) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
+        nsm[f] = n;
+        uint32_t k = 0;
+        for (; k < ncls; k++) if (cls[k].n == n) break;
+        if (k == ncls) {
+            if (ncls == LNN_MAXCLS) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "more than %d distinct frame lengths in one batch", LNN_MAXCLS); return LNN_INVALID_ARGUMENT; }
+            DevClass &c = cls[ncls++];
+            c.n = n;
+            uint32_t na = ((n + 7u) / 8u) * 8u;             /* linne_encoder.c:652-654 */
+            if (na < hs->maxP) na = hs->maxP;
+            if (na > S) na = S;
+            c.na = na;
+            c.sin_off = (uint32_t)sin_total; sin_total += n;
+            if (for_encode) {
+                if (na & 1u) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
+                for (uint32_t l = 0; l < hs->L; l++) {
+                    const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
+                    uint32_t nt = 0;
+                    for (uint32_t u = 1; u <= maxu; u <<= 1) {
+                        if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
+                        c.trial_u[l][nt] = u;
+                        c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
+                        nt++;
+                    }
+                    c.ntrials[l] = nt;
+                }
+            }
+        }
+        idx[f] = k;
+    }
+    int ret;
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) { free(idx); free(nsm); return ret; }
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_nsmp, &ctx->nsmp_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) { free(idx); free(nsm); return ret; }
+    hipError_t e;
+    e = hipMemcpyAsync(ctx->d_clsidx, idx, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_nsmp, nsm, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && for_encode) {
+        double *tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
+        if (!tab) e = hipErrorOutOfMemory;
+        else {
+            for (uint32_t k = 0; k < ncls; k++) {
+                const uint32_t n = cls[k].n;
+                for (uint32_t s = 0; s < n; s++) tab[cls[k].sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
+            }
+            ret = ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1));
+            if (ret == LNN_OK) e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
+            if (ret == LNN_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            free(tab);
+            if (ret != LNN_OK) { free(idx); free(nsm); return ret; }
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     /* idx/nsm/cls are stack or freed below */
+    free(nsm);
+    if (h_clsidx_out) *h_clsidx_out = idx; else free(idx);
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "class table upload: %s", hipGetErrorString(e)); if (h_clsidx_out) { free(idx); *h_clsidx_out = NULL; } return LNN_NG; }
+    return LNN_OK;
+}
+
+static uint64_t align_up(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
+
+/* bytes of scratch one frame needs (C channel-frames, R passes each) */
+static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const HostShape *hs)
+{
+    const uint64_t C = shape->num_channels, S = shape->num_samples_per_block, J = C * hs->R;
+    uint64_t b = 0;
+    b += 2 * C * S * sizeof(int32_t);
+    b += J * 2 * S * sizeof(double);
+    b += J * LNN_MAXT * S * sizeof(double);
+    b += J * LNN_MAXT * LNN_ACW * sizeof(double);
+    b += J * LNN_MAXT * LNN_MAXP * sizeof(double);
+    b += J * LNN_MAXT * LNN_MAXU * (sizeof(double) + 1);
+    b += J * LNN_MAXT * sizeof(double);
+    b += J * LNN_MAXL * LNN_MAXP * sizeof(double);
+    b += J * LNN_MAXL * sizeof(uint32_t);
+    b += J * 2 * sizeof(double);
+    return b + 4096;
+}
+
+extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *d_pcm, const uint32_t *h_num_samples, uint32_t num_frames,
+        int32_t *d_residual, int32_t *d_params, double *d_stats)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->err[0] = 0;
+    if (!shape || !d_pcm || !d_residual || !d_params || !d_stats) { snprintf(ctx->err, sizeof(ctx->err), "null argument"); return LNN_INVALID_ARGUMENT; }
+    if (num_frames == 0) return LNN_OK;
+    HostShape hs;
+    int ret = shape_info(shape, &hs);
+    if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 1, NULL)) != LNN_OK) return ret;
+
+    const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
+    const uint64_t per_frame = frame_scratch_bytes(shape, &hs);
+    uint64_t chunk = (ctx->arena_bytes - 65536) / per_frame;
+    if (chunk == 0) {       /* grow the arena to hold at least one frame */
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(ctx->arena)); ctx->arena = NULL; ctx->arena_bytes = 0;
+        HIPCHK(ctx, hipMalloc(&ctx->arena, per_frame * 4 + 65536));
+        ctx->arena_bytes = per_frame * 4 + 65536;
+        chunk = 4;
+    }
+    if (chunk > num_frames) chunk = num_frames;
+    {   /* grid.y / grid.z carry the job index: J = chunk * C * R must stay below 65536 */
+        const uint64_t lim = 65535u / ((uint64_t)C * hs.R);
+        if (chunk > lim) chunk = lim;
+    }
+
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
+    for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk) {
+        const uint32_t Fc = (num_frames - f0 < chunk) ? (num_frames - f0) : (uint32_t)chunk;
+        const uint64_t CF = (uint64_t)Fc * C, J = CF * hs.R;
+        Plan p; memset(&p, 0, sizeof(p));
+        p.C = C; p.S = S; p.bits = shape->bits_per_sample; p.L = hs.L; p.R = hs.R; p.ms = shape->ch_process_method; p.F = Fc; p.J = (uint32_t)J;
+        for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
+        for (uint32_t r = 0; r < hs.R; r++) p.regs[r] = hs.regs[r];
+        p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
+        p.pcm = d_pcm + (size_t)f0 * C * S; p.resid = d_residual + (size_t)f0 * C * S;
+        p.prm = d_params + (size_t)f0 * C * LINNE_AMD_PARAM_WORDS; p.stats = d_stats + (size_t)f0 * C * LINNE_AMD_STAT_WORDS;
+        p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin;
+        uint8_t *a = (uint8_t *)ctx->arena;
+#define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
+        TAKE(p.xint, int32_t, CF * S); TAKE(p.xtmp, int32_t, CF * S);
+        TAKE(p.sig, double, J * 2 * S); TAKE(p.wx, double, J * LNN_MAXT * S);
+        TAKE(p.acorr, double, J * LNN_MAXT * LNN_ACW); TAKE(p.tcoef, double, J * LNN_MAXT * LNN_MAXP);
+        TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
+        TAKE(p.tloss, double, J * LNN_MAXT); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
+        TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
+#undef TAKE
+        if ((uint64_t)(a - (uint8_t *)ctx->arena) > ctx->arena_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
+        const uint32_t sblocks = (S + 255) / 256;
+        hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k_load_layer0, dim3(sblocks, (uint32_t)J), dim3(256), 0, ctx->stream, p);
+        uint32_t cur = 0;
+        for (uint32_t l = 0; l < hs.L; l++) {
+            const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
+            uint32_t nt = 0, nprob = 0, nchain = 0;
+            for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
+            hipLaunchKernelGGL(k_window, dim3(sblocks, nt, (uint32_t)J), dim3(256), 0, ctx->stream, p, l, cur);
+            hipLaunchKernelGGL(k_autocorr, dim3((nchain + 63) / 64, (uint32_t)J), dim3(64), 0, ctx->stream, p, l);
+            hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, ctx->stream, p, l);
+            hipLaunchKernelGGL(k_trial_residual, dim3(sblocks, nt, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur);
+            hipLaunchKernelGGL(k_loss_sum, dim3(((uint32_t)J + 63) / 64, nt), dim3(64), 0, ctx->stream, p, l);
+            hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l);
+            hipLaunchKernelGGL(k_forward, dim3(sblocks, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur);
+            cur ^= 1u;
+        }
+        hipLaunchKernelGGL(k_final_loss, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, cur);
+        hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, ctx->stream, p);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
+    return LNN_OK;
+}
+
+extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        int32_t *d_data, const uint32_t *h_num_samples, uint32_t num_frames, const int32_t *d_params)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->err[0] = 0;
+    if (!shape || !d_data || !d_params) { snprintf(ctx->err, sizeof(ctx->err), "null argument"); return LNN_INVALID_ARGUMENT; }
+    if (num_frames == 0) return LNN_OK;
+    HostShape hs;
+    int ret = shape_info(shape, &hs);
+    if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 0, NULL)) != LNN_OK) return ret;
+    DecPlan p; memset(&p, 0, sizeof(p));
+    p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
+    for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
+    p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
+    {
+        uint32_t lds_samples = (p.S < SYN_LDS_MAX_SAMPLES) ? p.S : SYN_LDS_MAX_SAMPLES;
+        lds_samples = (lds_samples + 3u) & ~3u;
+        const size_t lds_bytes = sizeof(int32_t) * ((size_t)lds_samples + 128);
+        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_synthesize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), lds_bytes, ctx->stream, p, lds_samples);
+    }
+    if (p.ms) hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p);
+    HIPCHK(ctx, hipGetLastError());
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
+    return LNN_OK;
+}
+
+/* host-buffer forms: staging buffers are allocated per call (the block-at-a-time API is latency-, not
+ * throughput-oriented; batch callers use the device entry points) */
+extern "C" int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *pcm, const uint32_t *num_samples, uint32_t num_frames,
+        int32_t *residual, int32_t *params, double *stats)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    if (!shape || !pcm || !residual || !params || !stats) return LNN_INVALID_ARGUMENT;
+    if (num_frames == 0) return LNN_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
+    const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * num_frames,
+                   sb = sizeof(double) * LINNE_AMD_STAT_WORDS * (uint64_t)shape->num_channels * num_frames;
+    int32_t *d_pcm = NULL, *d_res = NULL, *d_prm = NULL; double *d_st = NULL;
+    int ret = LNN_NG;
+    if (hipMalloc((void **)&d_pcm, nb) != hipSuccess || hipMalloc((void **)&d_res, nb) != hipSuccess
+            || hipMalloc((void **)&d_prm, pb) != hipSuccess || hipMalloc((void **)&d_st, sb) != hipSuccess) {
+        snprintf(ctx->err, sizeof(ctx->err), "hipMalloc of staging buffers failed");
+        goto done;
+    }
+    if (hipMemcpyAsync(d_pcm, pcm, nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "H2D failed"); goto done; }
+    if (hipMemsetAsync(d_prm, 0, pb, ctx->stream) != hipSuccess || hipMemsetAsync(d_st, 0, sb, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "memset failed"); goto done; }
+    ret = LINNEAmd_EncodeFramesDevice(ctx, shape, d_pcm, num_samples, num_frames, d_res, d_prm, d_st);
+    if (ret != LNN_OK) goto done;
+    ret = LNN_NG;
+    if (hipMemcpyAsync(residual, d_res, nb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+            || hipMemcpyAsync(params, d_prm, pb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+            || hipMemcpyAsync(stats, d_st, sb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "D2H failed"); goto done; }
+    {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "stream sync: %s", hipGetErrorString(e)); goto done; }
+    }
+    ret = LNN_OK;
+done:
+    hipStreamSynchronize(ctx->stream);
+    if (d_pcm) hipFree(d_pcm);
+    if (d_res) hipFree(d_res);
+    if (d_prm) hipFree(d_prm);
+    if (d_st) hipFree(d_st);
+    return ret;
+}
+
+extern "C" int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        int32_t *data, const uint32_t *num_samples, uint32_t num_frames, const int32_t *params)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    if (!shape || !data || !params) return LNN_INVALID_ARGUMENT;
+    if (num_frames == 0) return LNN_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
+    const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * num_frames;
+    int32_t *d_data = NULL, *d_prm = NULL;
+    int ret = LNN_NG;
+    if (hipMalloc((void **)&d_data, nb) != hipSuccess || hipMalloc((void **)&d_prm, pb) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipMalloc of staging buffers failed"); goto done; }
+    if (hipMemcpyAsync(d_data, data, nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess
+            || hipMemcpyAsync(d_prm, params, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "H2D failed"); goto done; }
+    ret = LINNEAmd_DecodeFramesDevice(ctx, shape, d_data, num_samples, num_frames, d_prm);
+    if (ret != LNN_OK) goto done;
+    ret = LNN_NG;
+    if (hipMemcpyAsync(data, d_data, nb, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "D2H failed"); goto done; }
+    {
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "stream sync: %s", hipGetErrorString(e)); goto done; }
+    }
+    ret = LNN_OK;
+done:
+    hipStreamSynchronize(ctx->stream);
+    if (d_data) hipFree(d_data);
+    if (d_prm) hipFree(d_prm);
+    return ret;
+}

@@ -1,0 +1,494 @@
+/*
+ * lnn_entropy.c -- host entropy / bit-stream stage of liblinne_amd.so (north_star leaves it on the host):
+ * CRC16, MSB-first bit I/O, the static Huffman code of the coefficients, the partitioned recursive Rice
+ * coder, block (de)serialisation and the block-type decision.  Batch entry points run a thread pool over
+ * frames (frames are independent once the sequential block-type pass is done).
+ *
+ * Behavioural references (file:line under /root/reference):
+ *   libs/bit_stream/include/bit_stream.h:240-433      bit order, flush-to-byte semantics
+ *   libs/static_huffman/src/static_huffman.c:28-165   tree construction and code assignment
+ *   libs/linne_coder/src/linne_coder.c:86-327         gamma / recursive Rice / partition search
+ *   libs/linne_internal/src/linne_utility.c:72-89     CRC16-IBM
+ *   libs/linne_encoder/src/linne_encoder.c:480-862    block type, block layout
+ *   libs/linne_decoder/src/linne_decoder.c:357-668    block parsing
+ */
+#include "lnn_host.h"
+#include "lnn_coef_freq.h"
+
+#include <float.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------------ CRC16 */
+static uint16_t g_crc_table[256];
+static void crc_init(void)
+{
+    uint32_t i, b;
+    for (i = 0; i < 256; i++) {
+        uint16_t c = (uint16_t)i;
+        for (b = 0; b < 8; b++) c = (uint16_t)((c & 1u) ? ((c >> 1) ^ 0xA001u) : (c >> 1));
+        g_crc_table[i] = c;
+    }
+}
+uint16_t lnn_crc16(const uint8_t *data, uint64_t size)
+{
+    uint16_t crc = 0;
+    while (size--) crc = (uint16_t)((crc >> 8) ^ g_crc_table[(crc ^ *data++) & 0xFFu]);
+    return crc;
+}
+
+/* ------------------------------------------------------------------------------------------------ bits */
+struct bitw { uint8_t *p, *base, *end; uint64_t acc; uint32_t n; int overflow; };
+static void bw_open(struct bitw *w, uint8_t *mem, uint64_t size) { w->p = w->base = mem; w->end = mem + size; w->acc = 0; w->n = 0; w->overflow = 0; }
+static inline void bw_put(struct bitw *w, uint32_t val, uint32_t nbits)
+{   /* nbits <= 32; at most 7 bits pending */
+    if (nbits == 0) return;
+    w->acc = (w->acc << nbits) | (uint64_t)(val & (uint32_t)(0xFFFFFFFFu >> (32u - nbits)));
+    w->n += nbits;
+    while (w->n >= 8) {
+        w->n -= 8;
+        if (w->p < w->end) *w->p++ = (uint8_t)(w->acc >> w->n); else w->overflow = 1;
+    }
+}
+static inline void bw_zero_run_then_one(struct bitw *w, uint32_t run)   /* `run` zeros, then a 1 */
+{
+    while (run >= 32) { bw_put(w, 0, 32); run -= 32; }
+    bw_put(w, 1, run + 1 > 32 ? 32 : run + 1);
+}
+static void bw_flush(struct bitw *w) { if (w->n) bw_put(w, 0, 8 - w->n); }
+static uint64_t bw_bytes(const struct bitw *w) { return (uint64_t)(w->p - w->base); }
+
+struct bitr { const uint8_t *base; uint64_t nbits, pos; };
+static void br_open(struct bitr *r, const uint8_t *mem, uint64_t size) { r->base = mem; r->nbits = size * 8u; r->pos = 0; }
+static inline uint32_t br_peek32(const struct bitr *r)
+{   /* next 32 bits, zero beyond the end */
+    const uint64_t byte = r->pos >> 3;
+    const uint32_t sh = (uint32_t)(r->pos & 7u);
+    uint64_t v = 0;
+    uint32_t i;
+    const uint64_t nbytes = (r->nbits >> 3);
+    for (i = 0; i < 5; i++) v = (v << 8) | ((byte + i < nbytes) ? r->base[byte + i] : 0u);
+    return (uint32_t)((v << sh) >> 8);
+}
+static inline uint32_t br_get(struct bitr *r, uint32_t nbits)
+{
+    uint32_t v;
+    if (nbits == 0) return 0;
+    v = br_peek32(r) >> (32u - nbits);
+    r->pos += nbits;
+    return v;
+}
+static inline uint32_t br_zero_run(struct bitr *r)
+{
+    uint32_t run = 0;
+    for (;;) {
+        const uint32_t w = br_peek32(r);
+        if (w) { const uint32_t z = (uint32_t)__builtin_clz(w); r->pos += z + 1; return run + z; }
+        if (r->pos >= r->nbits) return run;              /* ran off the data: corrupt stream */
+        run += 32; r->pos += 32;
+    }
+}
+static uint64_t br_bytes(const struct bitr *r) { return (r->pos + 7u) >> 3; }
+
+/* ------------------------------------------------------------------------------------------------ Huffman */
+static struct { uint32_t root; uint16_t child[512][2]; uint32_t code[256]; uint8_t len[256]; } g_huff;
+static void huff_walk(uint32_t node, uint32_t code, uint32_t len)
+{
+    if (node < 256) { g_huff.code[node] = code; g_huff.len[node] = (uint8_t)len; return; }
+    huff_walk(g_huff.child[node][0], code << 1, len + 1);
+    huff_walk(g_huff.child[node][1], (code << 1) | 1u, len + 1);
+}
+static void huff_init(void)
+{   /* repeatedly merge the two least frequent live nodes; the scan order and strict '<' fix the ties */
+    uint32_t weight[513], next, i;
+    for (i = 0; i < 513; i++) weight[i] = 0;
+    for (i = 0; i < 256; i++) weight[i] = lnn_coef_freq[i] ? lnn_coef_freq[i] : 1u;
+    weight[512] = 0xFFFFFFFFu;
+    for (next = 256; ; next++) {
+        uint32_t lo = 512, lo2 = 512;
+        for (i = 0; i < next; i++) {
+            if (weight[i] == 0) continue;
+            if (weight[i] < weight[lo]) { lo2 = lo; lo = i; }
+            else if (weight[i] < weight[lo2]) lo2 = i;
+        }
+        if (lo2 == 512) break;
+        weight[next] = weight[lo] + weight[lo2];
+        weight[lo] = weight[lo2] = 0;
+        g_huff.child[next][0] = (uint16_t)lo; g_huff.child[next][1] = (uint16_t)lo2;
+    }
+    g_huff.root = next - 1;
+    huff_walk(g_huff.root, 0, 0);
+}
+static inline uint32_t huff_get(struct bitr *r)
+{
+    uint32_t node = g_huff.root;
+    do { node = g_huff.child[node][br_get(r, 1)]; } while (node >= 256);
+    return node;
+}
+
+static pthread_once_t g_once = PTHREAD_ONCE_INIT;
+static void tables_init(void) { crc_init(); huff_init(); }
+void lnn_tables_init(void) { pthread_once(&g_once, tables_init); }
+
+/* ------------------------------------------------------------------------------------------------ Rice */
+#define RICE_LOG2_PARTS 10u
+#define RICE_PARTS      (1u << RICE_LOG2_PARTS)
+
+static inline uint32_t zz(int32_t v) { const uint32_t d = (uint32_t)v << 1; return (v < 0) ? ((0u - d) - 1u) : d; }
+static inline int32_t unzz(uint32_t u) { return (int32_t)(u >> 1) ^ -(int32_t)(u & 1u); }
+static inline uint32_t ceil_log2(uint32_t x) { const uint32_t y = x - 1u; return y ? 32u - (uint32_t)__builtin_clz(y) : 0u; }
+
+/* geometric-distribution ML estimate -> second-stage parameter (linne_coder.c:172-200); host libm */
+static inline uint32_t rice_k2(double mean)
+{
+    const double optx = 0.5127629514437670454896078808815218508243560791015625;
+    const double rho = 1.0 / (1.0 + mean);
+    const double t = floor((log(log(optx) / log(1.0 - rho))) * 1.4426950408889634);
+    return (uint32_t)((0 > t) ? 0 : t);
+}
+static inline uint32_t gamma_len(uint32_t u) { return u ? (2u * ceil_log2(u + 2u) - 1u) : 1u; }
+
+struct rice_scratch { double mean[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint32_t *u; uint32_t ucap; };
+
+static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct rice_scratch *sc)
+{
+    uint32_t max_order = 1, parts, order, part, s, best = 0, min_bits = 0xFFFFFFFFu;
+    int32_t i;
+    uint32_t *u;
+    if (sc->ucap < n) { free(sc->u); sc->u = malloc(sizeof(uint32_t) * n); sc->ucap = sc->u ? n : 0; if (!sc->u) return -1; }
+    u = sc->u;
+    for (s = 0; s < n; s++) u[s] = zz(data[s]);
+    while ((n % (1u << max_order)) == 0) max_order++;
+    max_order = (max_order - 1 < RICE_LOG2_PARTS) ? max_order - 1 : RICE_LOG2_PARTS;
+    parts = 1u << max_order;
+    {
+        const uint32_t ns = n / parts;
+        for (part = 0; part < parts; part++) {
+            double sum = 0.0;
+            const uint32_t *q = u + (size_t)part * ns;
+            for (s = 0; s < ns; s++) sum += q[s];
+            sc->mean[max_order][part] = sum / ns;
+        }
+    }
+    for (i = (int32_t)max_order - 1; i >= 0; i--)
+        for (part = 0; part < (1u << i); part++)
+            sc->mean[i][part] = (sc->mean[i + 1][2 * part] + sc->mean[i + 1][2 * part + 1]) / 2.0;
+    for (order = 0; order <= max_order; order++) {
+        const uint32_t ns = n >> order;
+        uint32_t prevk2 = 0, bits = 0;
+        for (part = 0; part < (1u << order); part++) {
+            const uint32_t k2 = rice_k2(sc->mean[order][part]), k1 = k2 + 1, k1pow = 1u << k1;
+            const uint32_t *q = u + (size_t)part * ns;
+            uint32_t b = 0;
+            for (s = 0; s < ns; s++) { const uint32_t v = q[s]; b += (v < k1pow) ? (k1 + 1) : (k2 + 2 + ((v - k1pow) >> k2)); }
+            bits += b;
+            bits += part ? gamma_len(zz((int32_t)k2 - (int32_t)prevk2)) : 5u;
+            prevk2 = k2;
+        }
+        if (min_bits > bits) { min_bits = bits; best = order; }
+    }
+    {
+        const uint32_t ns = n >> best;
+        uint32_t prevk2 = 0;
+        bw_put(w, best, RICE_LOG2_PARTS);
+        for (part = 0; part < (1u << best); part++) {
+            const uint32_t k2 = rice_k2(sc->mean[best][part]), k1 = k2 + 1, k1pow = 1u << k1, k2mask = (1u << k2) - 1u;
+            const uint32_t *q = u + (size_t)part * ns;
+            if (part == 0) bw_put(w, k2, 5);
+            else {
+                const uint32_t g = zz((int32_t)k2 - (int32_t)prevk2);
+                if (g == 0) bw_put(w, 1, 1);
+                else { const uint32_t nd = ceil_log2(g + 2u); bw_put(w, 0, nd - 1); bw_put(w, g + 1, nd); }
+            }
+            prevk2 = k2;
+            for (s = 0; s < ns; s++) {
+                uint32_t v = q[s];
+                if (v < k1pow) { bw_put(w, k1pow | v, k1 + 1); }         /* '1' then k1 bits */
+                else { v -= k1pow; bw_zero_run_then_one(w, 1 + (v >> k2)); bw_put(w, v & k2mask, k2); }
+            }
+        }
+    }
+    return 0;
+}
+
+static void rice_decode(struct bitr *r, int32_t *data, uint32_t n)
+{
+    const uint32_t order = br_get(r, RICE_LOG2_PARTS), ns = n >> order;
+    uint32_t part, s, k2 = 0;
+    for (part = 0; part < (1u << order); part++) {
+        if (r->pos > r->nbits) return;
+        if (part == 0) k2 = br_get(r, 5);
+        else {
+            const uint32_t nd = br_zero_run(r) + 1;
+            const uint32_t g = (nd == 1) ? 0u : (uint32_t)((1ul << (nd - 1)) + br_get(r, nd - 1) - 1);
+            k2 = (uint32_t)((int32_t)k2 + unzz(g));
+        }
+        k2 &= 31u;
+        {
+            const uint32_t k1 = (k2 + 1) & 31u, k1pow = 1u << k1;
+            int32_t *q = data + (size_t)part * ns;
+            for (s = 0; s < ns; s++) {
+                const uint32_t quot = br_zero_run(r);
+                const uint32_t v = (quot == 0) ? br_get(r, k1) : (br_get(r, k2) + k1pow + ((quot - 1) << k2));
+                q[s] = unzz(v);
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ blocks */
+static void put_be16(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; }
+static void put_be32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v; }
+static uint32_t get_be16(const uint8_t *p) { return ((uint32_t)p[0] << 8) | p[1]; }
+static uint32_t get_be32(const uint8_t *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+int lnn_shape_layers(const struct LINNEAmdShape *shape, struct lnn_layers *out)
+{
+    uint32_t l, off = 0;
+    if (!shape || lnn_preset_info(shape->preset, &out->num_layers, out->size, &out->num_regs, out->regs) != 0) return -1;
+    out->max_size = 0;
+    for (l = 0; l < out->num_layers; l++) { out->offset[l] = off; off += out->size[l]; if (out->size[l] > out->max_size) out->max_size = out->size[l]; }
+    out->total = off;
+    return 0;
+}
+
+/* Block-type decision (linne_encoder.c:480-529) from the device statistics; the transcendental part of
+ * LPCCalculator_EstimateCodeLength (lpc.c:832-859) runs here with the host libm.  *state carries what the
+ * reference's calculator holds in parcor[order] (oracle quirk Q2). */
+uint32_t lnn_decide_block_type(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t n,
+        const int32_t *pcm_frame, const double *stats_frame, double *state)
+{
+    const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, order = ly->size[0];
+    uint32_t ch, s, ord;
+    double mean = 0.0;
+    for (ch = 0; ch < C; ch++) {
+        const double *st = stats_frame + (size_t)ch * LINNE_AMD_STAT_WORDS;
+        const int zero = st[LINNE_AMD_ST_ZERO] != 0.0;
+        double p, ratio, len;
+        if (zero) *state = 0.0;                                    /* the zero branches write parcor[0..order] */
+        p = st[LINNE_AMD_ST_R0];
+        p *= ldexp(1.0, (int)(2u * (bits - 1u)));                  /* pow(2, 2(bits-1)), exact */
+        if (fabs(p) <= FLT_MIN) len = 0.0;
+        else {
+            p = log(p) * 1.4426950408889634 - log((double)n) * 1.4426950408889634;
+            ratio = 0.0;
+            for (ord = 1; ord < order; ord++) { const double k = zero ? 0.0 : st[LINNE_AMD_ST_K1 + ord - 1]; ratio += log(1.0 - k * k) * 1.4426950408889634; }
+            ratio += log(1.0 - (*state) * (*state)) * 1.4426950408889634;
+            len = 1.9426950408889634 + 0.5f * (p + ratio);
+            if (len <= 0) len = 1.0;
+        }
+        mean += len;
+    }
+    mean /= C;
+    mean /= bits;
+    if (mean >= 0.95f) return LNN_BLOCK_RAW;
+    for (ch = 0; ch < C; ch++) {
+        const int32_t *x = pcm_frame + (size_t)ch * shape->num_samples_per_block;
+        for (s = 0; s < n; s++) if (x[s] != 0) return LNN_BLOCK_COMPRESS;
+    }
+    return LNN_BLOCK_SILENT;
+}
+
+/* serialises one block (linne_encoder.c:806-855); returns LNN_* and the byte count */
+static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t type, uint32_t n,
+        const int32_t *pcm, const int32_t *residual, const int32_t *params,
+        uint8_t *out, uint64_t cap, uint32_t *size_out, struct rice_scratch *sc)
+{
+    const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, S = shape->num_samples_per_block;
+    uint32_t ch, l, i, s;
+    uint64_t body = 0;
+    if (cap < 11) return LNN_INSUFFICIENT_BUFFER;
+    put_be16(out, 0xFFFF);
+    out[8] = (uint8_t)type; put_be16(out + 9, n);
+    if (type == LNN_BLOCK_RAW) {                                   /* linne_encoder.c:532-591 */
+        uint8_t *p = out + 11;
+        if (bits != 8 && bits != 16 && bits != 24) return LNN_INVALID_FORMAT;
+        if (cap - 11 < ((uint64_t)bits * n * C) / 8) return LNN_INSUFFICIENT_BUFFER;
+        for (s = 0; s < n; s++)
+            for (ch = 0; ch < C; ch++) {
+                const uint32_t u = zz(pcm[(size_t)ch * S + s]);
+                if (bits == 24) *p++ = (uint8_t)(u >> 16);
+                if (bits >= 16) *p++ = (uint8_t)(u >> 8);
+                *p++ = (uint8_t)u;
+            }
+        body = (uint64_t)(p - (out + 11));
+    } else if (type == LNN_BLOCK_COMPRESS) {                       /* linne_encoder.c:698-749 */
+        struct bitw w;
+        bw_open(&w, out + 11, cap - 11);
+        for (ch = 0; ch < C; ch++) {
+            const int32_t *rec = params + (size_t)ch * LINNE_AMD_PARAM_WORDS;
+            for (l = 0; l < 2; l++) {
+                bw_put(&w, zz(rec[LINNE_AMD_PRM_PREV + l]), bits + 1);
+                bw_put(&w, (uint32_t)rec[LINNE_AMD_PRM_PCOEF + l], 4);
+            }
+        }
+        for (ch = 0; ch < C; ch++) {
+            const int32_t *rec = params + (size_t)ch * LINNE_AMD_PARAM_WORDS;
+            for (l = 0; l < ly->num_layers; l++) {
+                bw_put(&w, ceil_log2((uint32_t)rec[LINNE_AMD_PRM_UNITS + l]), 3);
+                bw_put(&w, (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l], 4);
+                for (i = 0; i < ly->size[l]; i++) {
+                    const uint32_t sym = zz(rec[LINNE_AMD_PRM_COEF + ly->offset[l] + i]) & 255u;
+                    bw_put(&w, g_huff.code[sym], g_huff.len[sym]);
+                }
+            }
+        }
+        for (ch = 0; ch < C; ch++) if (rice_encode(&w, residual + (size_t)ch * S, n, sc) != 0) return LNN_NG;
+        bw_flush(&w);
+        if (w.overflow) return LNN_INSUFFICIENT_BUFFER;
+        body = bw_bytes(&w);
+    }
+    if (body + 5 > 0xFFFFFFFFull) return LNN_INSUFFICIENT_BUFFER;
+    put_be32(out + 2, (uint32_t)body + 5);
+    put_be16(out + 6, lnn_crc16(out + 8, body + 3));
+    *size_out = (uint32_t)(11 + body);
+    return LNN_OK;
+}
+
+/* ---- thread pool over frames ------------------------------------------------------------------------- */
+struct pack_job {
+    const struct LINNEAmdShape *shape; const struct lnn_layers *ly;
+    const int32_t *pcm, *residual, *params; const uint32_t *nsmp; const uint8_t *types;
+    uint8_t **slot; uint64_t *slot_cap; uint32_t *sizes; int *rets;
+    uint32_t first, count;
+};
+static void *pack_worker(void *arg)
+{
+    struct pack_job *j = arg;
+    struct rice_scratch *sc = calloc(1, sizeof(*sc));
+    const uint64_t CS = (uint64_t)j->shape->num_channels * j->shape->num_samples_per_block;
+    uint32_t f;
+    for (f = j->first; f < j->first + j->count; f++) {
+        if (!sc) { j->rets[f] = LNN_NG; continue; }
+        j->rets[f] = pack_block(j->shape, j->ly, j->types[f], j->nsmp ? j->nsmp[f] : j->shape->num_samples_per_block,
+                j->pcm + f * CS, j->residual + f * CS, j->params + (size_t)f * j->shape->num_channels * LINNE_AMD_PARAM_WORDS,
+                j->slot[f], j->slot_cap[f], &j->sizes[f], sc);
+    }
+    if (sc) { free(sc->u); free(sc); }
+    return NULL;
+}
+
+int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
+        uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
+        uint32_t num_threads)
+{
+    struct lnn_layers ly;
+    uint8_t *types = NULL, **slot = NULL, *pool = NULL;
+    uint64_t *slot_cap = NULL, CS, per_slot, off;
+    int *rets = NULL, ret = LNN_OK;
+    double state = parcor_state ? *parcor_state : 0.0;
+    uint32_t f, t, C;
+    pthread_t th[64];
+    struct pack_job jobs[64];
+    if (!shape || !pcm || !residual || !params || !stats || !blocks_out || !block_sizes) return LNN_INVALID_ARGUMENT;
+    if (lnn_shape_layers(shape, &ly) != 0) return LNN_INVALID_FORMAT;
+    if (num_frames == 0) return LNN_OK;
+    lnn_tables_init();
+    C = shape->num_channels;
+    CS = (uint64_t)C * shape->num_samples_per_block;
+    types = malloc(num_frames); slot = malloc(sizeof(*slot) * num_frames); slot_cap = malloc(sizeof(*slot_cap) * num_frames);
+    rets = malloc(sizeof(int) * num_frames);
+    if (!types || !slot || !slot_cap || !rets) { ret = LNN_NG; goto done; }
+    /* sequential pass: block types (the only cross-frame dependency, quirk Q2) */
+    for (f = 0; f < num_frames; f++) {
+        const uint32_t n = num_samples ? num_samples[f] : shape->num_samples_per_block;
+        const double *st = stats + (size_t)f * C * LINNE_AMD_STAT_WORDS;
+        types[f] = (uint8_t)lnn_decide_block_type(shape, &ly, n, pcm + f * CS, st, &state);
+        if (types[f] == LNN_BLOCK_COMPRESS) state = st[(size_t)(C - 1) * LINNE_AMD_STAT_WORDS + LINNE_AMD_ST_TAIL];
+    }
+    if (parcor_state) *parcor_state = state;
+    /* parallel pass: serialise into private slots, then compact in order */
+    per_slot = 64 + CS * 8;
+    pool = malloc(per_slot * (uint64_t)((num_frames < 4096) ? num_frames : 4096));
+    if (!pool) { ret = LNN_NG; goto done; }
+    off = 0;
+    {
+        uint32_t base;
+        if (num_threads == 0) num_threads = 1;
+        if (num_threads > 64) num_threads = 64;
+        for (base = 0; base < num_frames && ret == LNN_OK; base += 4096) {
+            const uint32_t cnt = (num_frames - base < 4096) ? (num_frames - base) : 4096;
+            uint32_t first = 0, nt = (num_threads < cnt) ? num_threads : cnt;
+            for (f = 0; f < cnt; f++) { slot[base + f] = pool + per_slot * f; slot_cap[base + f] = per_slot; }
+            for (t = 0; t < nt; t++) {
+                const uint32_t c = cnt / nt + ((t < cnt % nt) ? 1u : 0u);
+                struct pack_job *j = &jobs[t];
+                j->shape = shape; j->ly = &ly; j->pcm = pcm; j->residual = residual; j->params = params; j->nsmp = num_samples;
+                j->types = types; j->slot = slot; j->slot_cap = slot_cap; j->sizes = block_sizes; j->rets = rets;
+                j->first = base + first; j->count = c; first += c;
+                if (nt == 1) pack_worker(j); else pthread_create(&th[t], NULL, pack_worker, j);
+            }
+            if (nt > 1) for (t = 0; t < nt; t++) pthread_join(th[t], NULL);
+            for (f = base; f < base + cnt; f++) {
+                if (rets[f] != LNN_OK) { ret = rets[f]; break; }
+                if (off + block_sizes[f] > blocks_capacity) { ret = LNN_INSUFFICIENT_BUFFER; break; }
+                memcpy(blocks_out + off, slot[f], block_sizes[f]);
+                off += block_sizes[f];
+            }
+        }
+    }
+done:
+    free(types); free(slot); free(slot_cap); free(rets); free(pool);
+    return ret;
+}
+
+/* ---- block parsing (linne_decoder.c:564-668 without the synthesis) ------------------------------------ */
+int lnn_parse_block(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, const uint8_t *data, uint64_t avail,
+        int check_crc, uint32_t max_samples, uint32_t *type_out, uint32_t *n_out, uint32_t *consumed_out,
+        int32_t *samples /* [C][S]: residual (COMPRESS) or PCM (RAW/SILENT) */, int32_t *params)
+{
+    const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, S = shape->num_samples_per_block;
+    uint32_t bsize, type, n, ch, l, i, s;
+    if (avail < 11) return LNN_INSUFFICIENT_DATA;
+    if (get_be16(data) != 0xFFFF) return LNN_INVALID_FORMAT;
+    bsize = get_be32(data + 2);
+    if ((uint64_t)bsize + 6 > avail) return LNN_INSUFFICIENT_DATA;
+    if (bsize < 5) return LNN_INVALID_FORMAT;
+    if (check_crc && lnn_crc16(data + 8, bsize - 2) != get_be16(data + 6)) return LNN_DETECT_DATA_CORRUPTION;
+    type = data[8]; n = get_be16(data + 9);
+    if (n > max_samples || n > S) return LNN_INSUFFICIENT_BUFFER;
+    *type_out = type; *n_out = n;
+    if (type == LNN_BLOCK_RAW) {
+        const uint8_t *q = data + 11;
+        if (bits != 8 && bits != 16 && bits != 24) return LNN_INVALID_FORMAT;
+        if (avail - 11 < ((uint64_t)bits * n * C) / 8) return LNN_INSUFFICIENT_DATA;
+        for (s = 0; s < n; s++)
+            for (ch = 0; ch < C; ch++) {
+                uint32_t u = 0;
+                if (bits == 24) u = *q++;
+                if (bits >= 16) u = (u << 8) | *q++;
+                u = (u << 8) | *q++;
+                samples[(size_t)ch * S + s] = unzz(u);
+            }
+        *consumed_out = 11 + (uint32_t)(q - (data + 11));
+    } else if (type == LNN_BLOCK_SILENT) {
+        for (ch = 0; ch < C; ch++) memset(samples + (size_t)ch * S, 0, sizeof(int32_t) * n);
+        *consumed_out = 11;
+    } else if (type == LNN_BLOCK_COMPRESS) {
+        struct bitr r;
+        if (n == 0) return LNN_INVALID_FORMAT;
+        br_open(&r, data + 11, avail - 11);
+        for (ch = 0; ch < C; ch++) {
+            int32_t *rec = params + (size_t)ch * LINNE_AMD_PARAM_WORDS;
+            memset(rec, 0, sizeof(int32_t) * LINNE_AMD_PARAM_WORDS);
+            for (l = 0; l < 2; l++) {
+                rec[LINNE_AMD_PRM_PREV + l] = unzz(br_get(&r, bits + 1));
+                rec[LINNE_AMD_PRM_PCOEF + l] = (int32_t)br_get(&r, 4);
+            }
+        }
+        for (ch = 0; ch < C; ch++) {
+            int32_t *rec = params + (size_t)ch * LINNE_AMD_PARAM_WORDS;
+            for (l = 0; l < ly->num_layers; l++) {
+                rec[LINNE_AMD_PRM_UNITS + l] = (int32_t)(1u << br_get(&r, 3));
+                rec[LINNE_AMD_PRM_RSHIFT + l] = (int32_t)br_get(&r, 4);
+                for (i = 0; i < ly->size[l]; i++) rec[LINNE_AMD_PRM_COEF + ly->offset[l] + i] = unzz(huff_get(&r));
+            }
+        }
+        for (ch = 0; ch < C; ch++) rice_decode(&r, samples + (size_t)ch * S, n);
+        *consumed_out = 11 + (uint32_t)br_bytes(&r);
+    } else return LNN_INVALID_FORMAT;
+    return LNN_OK;
+}

@@ -1,0 +1,129 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same inputs.
+Bar: bit-exact (all outputs are integers; the double-precision analysis feeds an 8-bit quantiser and an argmin,
+so any deviation in operation order would show up as differing coefficients / unit counts)."""
+import numpy as np
+import pytest
+
+import linne_amd
+from refs import fnv1a64
+from signals import WAVEFORMS, music, music_frames, waveform
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_taps(tap, rec, stats, preset, nch, where):
+    for ch in range(nch):
+        t, r = tap.ch[ch], rec[ch]
+        assert list(t.preem_prev) == list(r[0:2]), f"{where} ch{ch}: pre-emphasis prev"
+        assert list(t.preem_coef) == list(r[2:4]), f"{where} ch{ch}: pre-emphasis coef"
+        nl = len(linne_amd.PRESET_LAYERS[preset])
+        assert list(t.num_units)[:nl] == list(r[4:4 + nl]), f"{where} ch{ch}: units {list(t.num_units)} vs {list(r[4:7])}"
+        assert list(t.rshift)[:nl] == list(r[7:7 + nl]), f"{where} ch{ch}: rshift"
+        off = 10
+        for l, P in enumerate(linne_amd.PRESET_LAYERS[preset]):
+            assert list(t.coef[l][:P]) == list(r[off:off + P]), f"{where} ch{ch} layer{l}: coefficients"
+            off += P
+        st = stats[ch]
+        assert st[linne_amd.ST_R0] == t.est_r0, f"{where} ch{ch}: SIN-window r0 {st[0]!r} vs {t.est_r0!r}"
+        assert int(st[linne_amd.ST_BEST]) == t.best_pass, f"{where} ch{ch}: best regulariser"
+        assert st[linne_amd.ST_LOSS] == t.pass_loss[t.best_pass], f"{where} ch{ch}: L1 loss"
+        assert st[linne_amd.ST_TAIL] == t.parcor_tail, f"{where} ch{ch}: parcor tail (Q2)"
+
+
+def test_smoke():
+    import __graft_entry__ as g
+    g.smoke()
+
+
+@pytest.mark.parametrize("nch,bits,block,preset,ms,nframes", [
+    (2, 16, 10240, 7, True, 3),
+    (1, 16, 10240, 4, False, 2),
+    (2, 16, 1024, 0, True, 4),
+    (2, 24, 4096, 5, True, 2),
+    (8, 24, 10240, 7, True, 1),
+    (3, 8, 1024, 2, False, 3),
+    (2, 16, 2048, 6, False, 2),
+])
+def test_hotpath_full_frames(ctx, oracle, nch, bits, block, preset, ms, nframes):
+    frames = music_frames(nframes, nch, block, bits, seed=block + preset)
+    shape = ctx.shape(nch, bits, block, preset, ms)
+    res, prm, st = ctx.encode_frames_host(shape, frames)
+    for f in range(nframes):
+        enc = oracle.encoder(nch, bits, 44100, block, preset, ms)
+        tap, ores = enc.hotpath(frames[f])
+        enc.close()
+        _check_taps(tap, prm[f], st[f], preset, nch, f"frame {f}")
+        assert np.array_equal(ores, res[f]), f"frame {f}: residual"
+    # decode hot path: inverse of the encode one
+    dec = ctx.decode_frames_host(shape, res, prm)
+    assert np.array_equal(dec, frames)
+
+
+@pytest.mark.parametrize("n", [129, 680, 2000, 9280, 3001, 8, 1000, 10239])
+def test_hotpath_ragged_tail_frames(ctx, oracle, n):
+    """tail frames: zero padding to the analysis length and the odd-window quirk Q1 (n = 680, 2000, 9280 give odd
+    sub-lengths 85, 125, 145)"""
+    nch, bits, block, preset = 2, 16, 10240, 7
+    x = music(nch, block + n, bits, seed=n)
+    frames = np.zeros((2, nch, block), dtype=np.int32)
+    frames[0] = x[:, :block]
+    frames[1, :, :n] = x[:, block:]
+    ns = np.array([block, n], dtype=np.uint32)
+    shape = ctx.shape(nch, bits, block, preset, True)
+    res, prm, st = ctx.encode_frames_host(shape, frames, ns)
+    enc = oracle.encoder(nch, bits, 44100, block, preset, True)
+    for f in range(2):
+        tap, ores = enc.hotpath(frames[f][:, :ns[f]])
+        _check_taps(tap, prm[f], st[f], preset, nch, f"frame {f} n={ns[f]}")
+        assert np.array_equal(ores, res[f][:, :ns[f]])
+    enc.close()
+    dec = ctx.decode_frames_host(shape, res, prm, ns)
+    assert np.array_equal(dec[0], frames[0]) and np.array_equal(dec[1][:, :n], frames[1][:, :n])
+
+
+@pytest.mark.parametrize("kind", WAVEFORMS)
+@pytest.mark.parametrize("nch,bits,preset", [(1, 16, 0), (2, 16, 7), (8, 8, 4), (2, 24, 7)])
+def test_lnn_bytes_reference_waveforms(product, oracle, kind, nch, bits, preset):
+    """the reference's round-trip matrix (test/linne_encode_decode/main.cpp:335-536), pinned at the byte level:
+    EncodeWhole through the drop-in API == the oracle's stream; DecodeWhole restores the input"""
+    x = waveform(kind, nch, 8192, bits, seed=nch * 100 + bits)
+    ms = nch >= 2
+    mine = product.encode_whole(x, bits, 8000, 1024, preset, ms)
+    want = oracle.encode_whole(x, bits, 8000, 1024, preset, ms)
+    assert len(mine) == len(want) and mine == want, f"{kind}: .lnn differs ({fnv1a64(mine)} vs {fnv1a64(want)})"
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec[:nch, :8192], x)
+
+
+def test_lnn_bytes_music_with_tail(product, oracle, reference):
+    x = music(2, 3 * 10240 + 2000, 16, seed=11)
+    mine = product.encode_whole(x, 16, 44100, 10240, 7, True)
+    assert mine == oracle.encode_whole(x, 16, 44100, 10240, 7, True)
+    assert mine == reference.encode_whole(x, 16, 44100, 10240, 7, True)
+    blocks = product.encode_blocks(x, 16, 44100, 10240, 7, True)          # the CLI's block-at-a-time loop
+    assert blocks == mine
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
+    ret, dec = reference.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
+
+
+def test_decode_errors(product, oracle):
+    """linne_decoder_test.cpp:470-579: sync corruption, payload corruption, truncation"""
+    x = music(2, 4096, 16, seed=5)
+    good = oracle.encode_whole(x, 16, 44100, 2048, 4, True)
+    bad = bytearray(good); bad[30] ^= 0xFF
+    assert product.decode_whole(bytes(bad))[0] == 2            # INVALID_FORMAT
+    bad = bytearray(good); bad[60] ^= 0xFF
+    assert product.decode_whole(bytes(bad))[0] == 6            # DETECT_DATA_CORRUPTION
+    assert product.decode_whole(good[:len(good) - 7])[0] == 4  # INSUFFICIENT_DATA
+
+
+def test_full_size_round_trip_property(ctx):
+    """size-independent property at a larger batch: decode(encode(x)) == x for 64 stereo frames"""
+    import torch
+    frames = music_frames(64, 2, 10240, 16, seed=99)
+    shape = ctx.shape(2, 16, 10240, 7, True)
+    res, prm, st = ctx.encode_frames_host(shape, frames)
+    assert np.array_equal(ctx.decode_frames_host(shape, res, prm), frames)
+    assert (prm[:, :, linne_amd.PRM_UNITS:linne_amd.PRM_UNITS + 3] >= 1).all()
