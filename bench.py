@@ -1,0 +1,289 @@
+#!/usr/bin/env python3
+"""bench.py -- LINNE per-frame prediction path on MI355X: frames/s of encode (-m 7) and decode, 44.1 kHz stereo.
+
+One "step" = one pass of the encode hot path (MS, pre-emphasis, LPC analysis + layer cascade for 4 regularisers,
+quantisation, int32 FIR cascade: LINNEAmd_EncodeFramesDevice) over one batch of synthetic PCM that is already
+resident in HBM.  At N=1 the batch is BASELINE.json configs[1]: 60 min of 44.1 kHz int16 stereo = 15 504 frames of
+10 240 samples (the last one a 9 280-sample tail).  With N > 1 every rank encodes its own 60-minute track (frames
+shard with no data-path collective): "scaling": "weak".  The decode hot path (configs[2]) is timed right after on
+the encode's own output and reported as decode_frames_per_s; it must reproduce the PCM bit for bit.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM as BASELINE.json asks (the path
+is FP64-VALU / dependent-chain bound; `valu_f64` gives that view), `cpu_baseline` times the
+reference CPU encoder (oracle/_ref, or the oracle port if absent) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+import linne_amd
+
+ALGO_BYTES_PER_CF = 82552           # 40960 in + 40960 out + 632 params per channel-frame
+MAC_PER_CF_REFERENCE = 46.2e6       # as written in the reference (-m 7, N = 10240)
+MAC_PER_CF_EXECUTED = 30.7e6        # bit-exact de-duplicated schedule this build runs
+HBM_PEAK_GBS = 8000.0
+FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it
+KERNEL_KINDS = {1: "k_prep", 2: "k_window", 3: "k_autocorr", 4: "k_levinson", 5: "k_trial_residual", 6: "k_loss_sum",
+                7: "k_select", 8: "k_forward", 9: "k_final_loss", 10: "k_finalize", 11: "k_synthesize", 12: "k_ms_to_lr"}
+
+
+def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):
+    """compressible synthetic 'music' (SURVEY 8d recipe, generated on the GPU): per channel 6 harmonics of
+    110*(ch+1) Hz with amplitudes 0.3/(k+1) and random phases, plus AR(2)-coloured noise; mix, clip, round."""
+    g = torch.Generator(device=device)
+    g.manual_seed(0x4C494E4E ^ seed)
+    out = torch.empty((nch, num_samples), dtype=torch.int32, device=device)
+    # impulse response of 1 / (1 - 1.6 z^-1 + 0.8 z^-2), 128 taps
+    h = [1.0, 1.6]
+    for _ in range(126):
+        h.append(1.6 * h[-1] - 0.8 * h[-2])
+    h = torch.tensor(h[::-1], dtype=torch.float64, device=device).view(1, 1, -1)
+    hgain = float(torch.sqrt((h * h).sum()))
+    full = float(1 << (bits - 1))
+    for ch in range(nch):
+        phases = torch.rand(6, generator=g, device=device, dtype=torch.float64) * (2 * np.pi)
+        for s0 in range(0, num_samples, chunk):
+            n = min(chunk, num_samples - s0)
+            t = (torch.arange(s0, s0 + n, device=device, dtype=torch.float64)) / rate
+            tone = torch.zeros(n, dtype=torch.float64, device=device)
+            for k in range(6):
+                tone += (0.3 / (k + 1)) * torch.sin(2 * np.pi * 110.0 * (ch + 1) * (k + 1) * t + phases[k])
+            e = torch.randn(n + 127, generator=g, device=device, dtype=torch.float64) * (0.1 / hgain)
+            noise = torch.nn.functional.conv1d(e.view(1, 1, -1), h).view(-1)
+            x = torch.clamp(0.6 * tone + noise, -0.999, 0.999) * full
+            out[ch, s0:s0 + n] = torch.round(x).to(torch.int32)
+    return out
+
+
+def frames_from_track(track, block):
+    """[C][num_samples] -> ([F][C][block] zero padded, num_samples per frame)"""
+    nch, ns = track.shape
+    F = (ns + block - 1) // block
+    pad = F * block - ns
+    if pad:
+        track = torch.cat([track, torch.zeros((nch, pad), dtype=track.dtype, device=track.device)], dim=1)
+    frames = track.view(nch, F, block).permute(1, 0, 2).contiguous()
+    nsm = np.full(F, block, dtype=np.uint32)
+    if pad:
+        nsm[-1] = block - pad
+    return frames, nsm
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota and BENCH_CPU_CORES
+    (a one-GPU box grants 16 of the host's cores)"""
+    n = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    n = min(n, int(os.environ.get("BENCH_CPU_CORES", "16")))
+    return max(1, n)
+
+
+def cpu_baseline(frames_host, bits, block, preset, ms, budget_frames_per_thread):
+    """reference CPU encoder (EncodeBlock incl. its entropy stage) on the first frames of the workload, one handle
+    per thread over disjoint frames"""
+    from refs import LinneApi, Oracle, REF_SO, EncodeParameter, reference_available
+    import ctypes as C
+    cores = host_cores()
+    F, nch, _ = frames_host.shape
+    per = min(budget_frames_per_thread, max(1, F // cores))
+    total = per * cores
+    if reference_available():
+        api = LinneApi(REF_SO)
+        kind = "reference"
+
+        def work(t):
+            enc = api.new_encoder(nch, bits, 44100, block, preset, ms)
+            out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
+            osz = C.c_uint32(0)
+            for f in range(t * per, (t + 1) * per):
+                ptrs = (C.POINTER(C.c_int32) * nch)(*[frames_host[f, ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
+                r = api.L.LINNEEncoder_EncodeBlock(enc, ptrs, block, out.ctypes.data, out.size, C.byref(osz))
+                assert r == 0
+            api.L.LINNEEncoder_Destroy(enc)
+
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
+        t0 = time.perf_counter()
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = time.perf_counter() - t0
+    else:
+        o = Oracle()
+        kind = "port"
+        p = EncodeParameter(nch, bits, 44100, block, preset, int(ms))
+        sub = np.ascontiguousarray(frames_host[:total])
+        nbytes = C.c_uint64(0)
+        dt = o.L.oracle_bench_encode(C.byref(p), sub.ctypes.data, total, cores, C.byref(nbytes))
+    return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": kind,
+            "sample": f"{total} full stereo frames of the same track ({per} per thread, {dt:.1f} s wall), EncodeBlock incl. entropy stage"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--minutes", type=float, default=60.0, help="track length per GPU (default: configs[1], 60 min)")
+    ap.add_argument("--preset", type=int, default=7)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames-per-thread", type=int, default=128)
+    ap.add_argument("--scratch-gib", type=float, default=24.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    nch, bits, block, rate, ms = 2, 16, 10240, 44100, True
+    ns_total = int(round(args.minutes * 60 * rate))
+    track = synth_track(ns_total, nch, bits, seed=rank, device=dev)
+    frames, nsm = frames_from_track(track, block)
+    del track
+    F = frames.shape[0]
+    ctx = linne_amd.Context(local, scratch_bytes=int(args.scratch_gib * (1 << 30)))
+    shape = ctx.shape(nch, bits, block, args.preset, ms)
+    res = torch.empty_like(frames)
+    prm = torch.zeros((F, nch, linne_amd.PARAM_WORDS), dtype=torch.int32, device=dev)
+    st = torch.zeros((F, nch, linne_amd.STAT_WORDS), dtype=torch.float64, device=dev)
+    work = torch.empty_like(frames)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def encode_step():
+        ctx.encode_frames(shape, frames, nsm, out=(res, prm, st))
+
+    def decode_step():
+        work.copy_(res)
+        ctx.decode_frames(shape, work, prm, nsm)
+
+    for _ in range(args.warmup):
+        encode_step()
+    barrier()
+    ctx.enable_timing(True)
+    kern_ms = {k: 0.0 for k in KERNEL_KINDS}
+    kern_launches = {k: 0 for k in KERNEL_KINDS}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        encode_step()
+        torch.cuda.synchronize()            # per-step sync so the per-kernel events of this step can be read
+        for k in range(1, 11):
+            m = ctx.last_ms(k)
+            if m > 0:
+                kern_ms[k] += m
+                kern_launches[k] += ctx.last_launches(k)
+    barrier()
+    enc_s = time.perf_counter() - t0
+    ctx.enable_timing(False)
+
+    # decode: warm-up, then K timed steps
+    decode_step()
+    barrier()
+    ok = bool(torch.equal(work, frames))
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        decode_step()
+        torch.cuda.synchronize()
+        for k in (11, 12):
+            m = ctx.last_ms(k)
+            if m > 0:
+                kern_ms[k] += m
+                kern_launches[k] += ctx.last_launches(k)
+    barrier()
+    dec_s = time.perf_counter() - t0
+    ctx.enable_timing(False)
+
+    if world > 1:
+        tt = torch.tensor([enc_s, dec_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        enc_s, dec_s = float(tt[0]), float(tt[1])
+        okt = torch.tensor([1 if ok else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        ok = bool(okt.item())
+
+    if rank == 0:
+        total_frames = F * world * args.steps
+        enc_fps = total_frames / enc_s
+        dec_fps = total_frames / dec_s
+        # dominant encode kernel: roofline against HBM with ALGORITHMIC bytes (DESIGN.md "Measurement")
+        dom = max(range(1, 11), key=lambda k: kern_ms[k])
+        launches = max(1, kern_launches[dom])
+        avg_ms = kern_ms[dom] / launches
+        # one launch of a per-layer kernel serves one chunk of frames for one layer; price it on the channel-frames
+        # of its chunk: all steps together processed F*nch*steps channel-frames in launches/(layers) chunk-launches
+        nlayers = len(linne_amd.PRESET_LAYERS[args.preset])
+        per_layer = dom in (2, 3, 4, 5, 6, 7, 8)
+        chunk_launches = launches / (nlayers if per_layer else 1)
+        cf_per_launch = F * nch * args.steps / chunk_launches
+        # a per-layer kernel of one layer carries that layer's share; report the whole-kernel view: bytes of the
+        # channel-frames one launch processes / its duration
+        achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(KERNEL_KINDS[dom], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": traffic, "kernel": KERNEL_KINDS[dom], "avg_launch_ms": avg_ms, "launches": launches,
+                    "channel_frames_per_launch": cf_per_launch,
+                    "note": "algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64"}
+        cf_per_s = enc_fps * nch / world        # per GPU
+        valu = {"executed_tflops": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12, "reference_equiv_tflops": 2 * MAC_PER_CF_REFERENCE * cf_per_s / 1e12,
+                "peak_fma_tflops": FP64_PEAK_TFLOPS, "frac_of_unfused_peak": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / (FP64_PEAK_TFLOPS / 2)}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))
+            cpu = cpu_baseline(frames[:nf].cpu().numpy(), bits, block, args.preset, ms, args.cpu_frames_per_thread)
+        breakdown = {KERNEL_KINDS[k]: round(kern_ms[k] / args.steps, 3) for k in KERNEL_KINDS if kern_ms[k] > 0}
+        line = {
+            "metric": "frames/sec encode (-m 7) + decode, 44.1 kHz stereo, bit-exact; 1/2/4/8 GPU",
+            "value": enc_fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": enc_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"encode -m {args.preset}: {args.minutes:g} min 44.1 kHz int16 stereo per GPU = {F} frames of {block} samples "
+                                   f"(tail {int(nsm[-1])}), MS on, PCM resident in HBM; decode = inverse hot path on the encode output",
+                       "frames_per_gpu": F, "channels": nch, "preset": args.preset, "sharding": f"{world} independent track(s), one per GPU"},
+            "decode_frames_per_s": dec_fps, "decode_ms_per_step": dec_s / args.steps * 1e3, "decode_bit_exact": ok,
+            "encode_channel_frames_per_s": enc_fps * nch,
+            "kernel_ms_per_step": breakdown,
+            "roofline": roofline, "valu_f64": valu, "cpu_baseline": cpu,
+        }
+        if cpu:
+            line["speedup_vs_cpu_baseline"] = enc_fps / cpu["value"]
+        print(json.dumps(line), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(2)
+
+
+if __name__ == "__main__":
+    main()

@@ -80,7 +80,8 @@ void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx);
 const char *LINNEAmd_GetLastError(const struct LINNEAmdContext *ctx);
 /* grows the scratch arena to at least `bytes` (bigger arena = more frames per launch) */
 int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t bytes);
-/* use an existing hipStream_t (e.g. torch's current stream) for all subsequent work; NULL = own stream */
+/* issue all subsequent work on an existing hipStream_t (e.g. torch's current stream); NULL names the device's
+ * default (null) stream.  Until this is called the context uses a stream of its own. */
 int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream);
 
 /* ENCODE hot path, device resident.  Replaces, for every frame of the batch, the numeric core of
@@ -114,10 +115,13 @@ int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmd
 /* blocks until everything enqueued on the context's stream has finished */
 int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
 
-/* Timing of the dominant kernel of the last Encode/DecodeFramesDevice call, measured with HIP events on the
- * context's stream: returns milliseconds (negative if nothing was recorded).  which: 0 = whole call,
- * 1 = encode autocorrelation kernels, 2 = encode trial-residual kernels, 3 = decode synthesis kernel. */
+/* Per-kernel timing of the last Encode/DecodeFramesDevice call, measured with HIP events recorded on the
+ * context's stream around each launch (only while timing is enabled).  GetLastTimingMs returns the summed
+ * milliseconds of all launches of one kernel kind (negative if none was recorded), GetLastTimingLaunches their
+ * count.  which: 0 whole call, 1 prep, 2 window, 3 autocorrelation, 4 levinson, 5 trial residual, 6 loss sum,
+ * 7 select, 8 forward, 9 final loss, 10 finalize (quantise + FIR cascade), 11 synthesis, 12 MS->LR. */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
+int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);
 
 /* Host entropy stage, batch form (thread pool over frames): serialises analysed frames to .lnn blocks exactly

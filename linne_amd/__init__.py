@@ -38,7 +38,7 @@ AMD_SYMBOLS = [
     "LINNEAmd_GetDeviceCount", "LINNEAmd_ContextCreate", "LINNEAmd_ContextDestroy", "LINNEAmd_GetLastError",
     "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastTimingMs",
-    "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
+    "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
 ]
 
 
@@ -78,6 +78,8 @@ def _load():
     L.LINNEAmd_GetLastTimingMs.restype = C.c_double
     L.LINNEAmd_GetLastTimingMs.argtypes = [C.c_void_p, C.c_int]
     L.LINNEAmd_EnableTiming.argtypes = [C.c_void_p, C.c_int]
+    L.LINNEAmd_GetLastTimingLaunches.restype = C.c_int
+    L.LINNEAmd_GetLastTimingLaunches.argtypes = [C.c_void_p, C.c_int]
     L.LINNEAmd_PackFrames.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     return L
@@ -132,6 +134,9 @@ class Context:
 
     def last_ms(self, which=0):
         return float(lib.LINNEAmd_GetLastTimingMs(self.h, which))
+
+    def last_launches(self, which):
+        return int(lib.LINNEAmd_GetLastTimingLaunches(self.h, which))
 
     def synchronize(self):
         self._check(lib.LINNEAmd_Synchronize(self.h), "Synchronize")

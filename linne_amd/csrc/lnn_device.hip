@@ -652,7 +652,8 @@ struct LINNEAmdContext {
     char err[256];
     int timing;
     hipEvent_t ev[2]; int ev_valid;
-    float last_ms[4];
+    /* per-kernel spans of the last call (timing enabled): HIP events on the launch stream */
+    hipEvent_t *span_ev; int *span_kind; int nspans, span_cap;
     /* cached class tables */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
 };
@@ -700,7 +701,6 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     ctx->arena_bytes = scratch_bytes;
     if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
-    for (int i = 0; i < 4; i++) ctx->last_ms[i] = -1.0f;
 #undef CC_FAIL
     return ctx;
 }
@@ -716,6 +716,8 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
     hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
+    for (int i = 0; i < 2 * ctx->span_cap; i++) hipEventDestroy(ctx->span_ev[i]);
+    free(ctx->span_ev); free(ctx->span_kind);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     free(ctx);
 }
@@ -725,15 +727,10 @@ extern "C" const char *LINNEAmd_GetLastError(const struct LINNEAmdContext *ctx) 
 extern "C" int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream)
 {
     if (!ctx) return LNN_INVALID_ARGUMENT;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    if (hip_stream) {
-        if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-        ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = 0;
-    } else if (!ctx->own_stream) {
-        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = 1;
-    }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) { HIPCHK(ctx, hipStreamDestroy(ctx->stream)); ctx->own_stream = 0; }
+    ctx->stream = (hipStream_t)hip_stream;              /* NULL is the device's default (null) stream */
     return LNN_OK;
 }
 
@@ -759,14 +756,51 @@ extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
 }
 
 extern "C" int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable) { if (!ctx) return LNN_INVALID_ARGUMENT; ctx->timing = enable; return LNN_OK; }
+/* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
+static int span_begin(LINNEAmdContext *ctx, int kind)
+{
+    if (!ctx->timing) return -1;
+    if (ctx->nspans == ctx->span_cap) {
+        const int ncap = ctx->span_cap ? ctx->span_cap * 2 : 256;
+        hipEvent_t *ne = (hipEvent_t *)realloc(ctx->span_ev, sizeof(hipEvent_t) * 2 * ncap);
+        if (!ne) return -1;
+        ctx->span_ev = ne;
+        int *nk = (int *)realloc(ctx->span_kind, sizeof(int) * ncap);
+        if (!nk) return -1;
+        ctx->span_kind = nk;
+        for (int i = 2 * ctx->span_cap; i < 2 * ncap; i++) if (hipEventCreate(&ctx->span_ev[i]) != hipSuccess) return -1;
+        ctx->span_cap = ncap;
+    }
+    const int id = ctx->nspans++;
+    ctx->span_kind[id] = kind;
+    (void)hipEventRecord(ctx->span_ev[2 * id], ctx->stream);
+    return id;
+}
+static void span_end(LINNEAmdContext *ctx, int id) { if (id >= 0) (void)hipEventRecord(ctx->span_ev[2 * id + 1], ctx->stream); }
+
 extern "C" double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which)
 {
-    if (!ctx || which < 0 || which > 3) return -1.0;
-    if (which == 0 && ctx->ev_valid) {
+    if (!ctx || which < 0) return -1.0;
+    if (which == 0) {
         float ms = -1.0f;
-        if (hipEventSynchronize(ctx->ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_ms[0] = ms;
+        if (!ctx->ev_valid) return -1.0;
+        if (hipEventSynchronize(ctx->ev[1]) != hipSuccess || hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) != hipSuccess) return -1.0;
+        return ms;
     }
-    return ctx->last_ms[which];
+    double sum = 0.0; int cnt = 0;
+    for (int i = 0; i < ctx->nspans; i++) if (ctx->span_kind[i] == which) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(ctx->span_ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms, ctx->span_ev[2 * i], ctx->span_ev[2 * i + 1]) != hipSuccess) return -1.0;
+        sum += ms; cnt++;
+    }
+    return cnt ? sum : -1.0;
+}
+extern "C" int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which)
+{
+    if (!ctx) return 0;
+    int cnt = 0;
+    for (int i = 0; i < ctx->nspans; i++) if (ctx->span_kind[i] == which) cnt++;
+    return cnt;
 }
 
 static int ensure_buf(LINNEAmdContext *ctx, void **ptr, uint64_t *cap, uint64_t need)
@@ -915,6 +949,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         if (chunk > lim) chunk = lim;
     }
 
+    ctx->nspans = 0;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk) {
         const uint32_t Fc = (num_frames - f0 < chunk) ? (num_frames - f0) : (uint32_t)chunk;
@@ -938,24 +973,24 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
 #undef TAKE
         if ((uint64_t)(a - (uint8_t *)ctx->arena) > ctx->arena_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
         const uint32_t sblocks = (S + 255) / 256;
-        hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, ctx->stream, p);
-        hipLaunchKernelGGL(k_load_layer0, dim3(sblocks, (uint32_t)J), dim3(256), 0, ctx->stream, p);
+        { const int sp_ = span_begin(ctx, 1); hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, ctx->stream, p); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 1); hipLaunchKernelGGL(k_load_layer0, dim3(sblocks, (uint32_t)J), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_); }
         uint32_t cur = 0;
         for (uint32_t l = 0; l < hs.L; l++) {
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
             uint32_t nt = 0, nprob = 0, nchain = 0;
             for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
-            hipLaunchKernelGGL(k_window, dim3(sblocks, nt, (uint32_t)J), dim3(256), 0, ctx->stream, p, l, cur);
-            hipLaunchKernelGGL(k_autocorr, dim3((nchain + 63) / 64, (uint32_t)J), dim3(64), 0, ctx->stream, p, l);
-            hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, ctx->stream, p, l);
-            hipLaunchKernelGGL(k_trial_residual, dim3(sblocks, nt, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur);
-            hipLaunchKernelGGL(k_loss_sum, dim3(((uint32_t)J + 63) / 64, nt), dim3(64), 0, ctx->stream, p, l);
-            hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l);
-            hipLaunchKernelGGL(k_forward, dim3(sblocks, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur);
+            { const int sp_ = span_begin(ctx, 2); hipLaunchKernelGGL(k_window, dim3(sblocks, nt, (uint32_t)J), dim3(256), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 3); hipLaunchKernelGGL(k_autocorr, dim3((nchain + 63) / 64, (uint32_t)J), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 4); hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 5); hipLaunchKernelGGL(k_trial_residual, dim3(sblocks, nt, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 6); hipLaunchKernelGGL(k_loss_sum, dim3(((uint32_t)J + 63) / 64, nt), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 7); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 8); hipLaunchKernelGGL(k_forward, dim3(sblocks, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
             cur ^= 1u;
         }
-        hipLaunchKernelGGL(k_final_loss, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, cur);
-        hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, ctx->stream, p);
+        { const int sp_ = span_begin(ctx, 9); hipLaunchKernelGGL(k_final_loss, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, cur); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 10); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, ctx->stream, p); span_end(ctx, sp_); }
         HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
@@ -978,15 +1013,17 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
     for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
     p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
+    ctx->nspans = 0;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     {
         uint32_t lds_samples = (p.S < SYN_LDS_MAX_SAMPLES) ? p.S : SYN_LDS_MAX_SAMPLES;
         lds_samples = (lds_samples + 3u) & ~3u;
         const size_t lds_bytes = sizeof(int32_t) * ((size_t)lds_samples + 128);
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_synthesize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), lds_bytes, ctx->stream, p, lds_samples);
+        { const int sp_ = span_begin(ctx, 11); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), lds_bytes, ctx->stream, p, lds_samples); span_end(ctx, sp_); }
     }
-    if (p.ms) hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p);
+    if (p.ms)
+        { const int sp_ = span_begin(ctx, 12); hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_); }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
     return LNN_OK;
