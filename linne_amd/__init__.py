@@ -111,7 +111,7 @@ class Context:
             self._check(lib.LINNEAmd_SetStream(self.h, C.c_void_p(s)), "SetStream")
 
     def close(self):
-        if getattr(self, "h", None):
+        if getattr(self, "h", None) and lib is not None:
             lib.LINNEAmd_ContextDestroy(self.h)
             self.h = None
 

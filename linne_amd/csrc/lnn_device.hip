@@ -248,55 +248,227 @@ __global__ void k_load_layer0(Plan p)
     p.sig[((size_t)job * 2 + 0) * p.S + s] = (double)p.xint[(size_t)(job / p.R) * p.S + s] * p.scale;
 }
 
-/* Welch window for every trial (lpc.c:196-205).  Q1: the middle sample of an odd-length unit is never
- * written by the reference; it still holds what the previous trial (u/2, even length 2n) left at that
- * index: its LAST unit's windowed sample at local index m. */
-__global__ void k_window(Plan p, uint32_t layer, uint32_t cur)
+/* ------------------------------------------------------------------------------------------------
+ * K_A (v2): Welch window + autocorrelation of every unit-count trial of one layer, fused.
+ *
+ * Work decomposition (DESIGN.md "autocorrelation kernel"): one wavefront per JPW jobs.  A LANE owns K = 5
+ * consecutive lags of one trial of one job and walks ALL units of that trial in order, so every lane runs the
+ * same number of steps (~ na + P) and each lag's sum stays one chain in increasing sample order.  The windowed
+ * signal of a trial is produced on the fly into a small LDS ring ("padded stream": each unit is followed by
+ * z = max(p,4) zeros, so a lane's 5-lag register window can slide across unit ends without masking and the
+ * accumulators can be flushed at a group boundary inside the zero zone).  Per 5 steps a lane issues 25 unfused
+ * mul+add pairs against 10 LDS reads.
+ * ---------------------------------------------------------------------------------------------- */
+template <int P> struct AcCfg {
+    static constexpr int K = 5;
+    static constexpr int NT = (P >= 128) ? 8 : ((P >= 64) ? 7 : (P >= 32) ? 6 : (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2);
+    static constexpr int T = (P >= 32) ? 60 : 20;                       /* tile: padded positions per LDS refill */
+    static constexpr int lanes(int t) { return ((P >> t) + 1 + K - 1) / K; }
+    static constexpr int halo(int t) { return K * lanes(t) + K; }       /* furthest window read past a group start, +1 */
+    static constexpr int rb(int t) { return T + halo(t); }              /* ring length (multiple of 5) */
+    static constexpr int lpj() { int s = 0; for (int t = 0; t < NT; t++) s += lanes(t); return s; }
+    static constexpr int ringsum() { int s = 0; for (int t = 0; t < NT; t++) s += rb(t); return s; }
+    static constexpr int maxpad() { int m = 0; for (int t = 0; t < NT; t++) { const int p = P >> t, z = p > 4 ? p : 4, v = (1 << t) * z; if (v > m) m = v; } return m; }
+    static constexpr int LPJ = lpj();
+    static constexpr int JPW = 64 / LPJ;
+    static constexpr int NS = JPW * NT;
+    static constexpr int GL = (64 / NS) >= 1 ? (64 / NS) : 1;
+    static constexpr int RINGSUM = ringsum();
+    static constexpr int MAXPAD = maxpad();
+};
+
+template <int P, bool L0>
+__global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
-    const uint32_t job = blockIdx.z, t = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
-    const DevClass &c = job_class(p, job);
-    if (t >= c.ntrials[layer] || s >= c.na) return;
-    const uint32_t u = c.trial_u[layer][t], n = c.na / u;
-    const double div = c.trial_div[layer][t];
-    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
-    const uint32_t unit = s / n, loc = s - unit * n;
-    double v;
-    if ((n & 1u) && loc == (n >> 1)) {
-        const uint32_t n2 = 2 * n;
-        const double divp = c.trial_div[layer][t - 1];
-        const double w = divp * (double)loc * (double)(n2 - 1 - loc);
-        v = x[(size_t)(u / 2 - 1) * n2 + loc] * w;
-    } else {
-        const uint32_t h = (loc < (n >> 1)) ? loc : (n - 1 - loc);
-        const double w = div * (double)h * (double)(n - 1 - h);
-        v = x[s] * w;
+    using Cfg = AcCfg<P>;
+    constexpr int K = Cfg::K, NT = Cfg::NT, T = Cfg::T;
+    __shared__ double ring[Cfg::JPW * Cfg::RINGSUM];
+    const uint32_t lane = threadIdx.x;
+
+    /* ---- accumulate role: (job, trial, lag group) ---- */
+    bool active = false;
+    uint32_t a_job = 0, a_t = 0, a_lag0 = 0, a_u = 1, a_p = P, a_upl = 1;
+    int32_t a_base = 0, a_rb = 5;          /* ring base (doubles) and ring length of my stream */
+    {
+        const uint32_t jl = lane / Cfg::LPJ;
+        uint32_t rem = lane % Cfg::LPJ;
+        if (jl < (uint32_t)Cfg::JPW) {
+            uint32_t t = 0; int32_t off = 0;
+            for (; t < (uint32_t)NT; t++) { if (rem < (uint32_t)Cfg::lanes(t)) break; rem -= Cfg::lanes(t); off += Cfg::rb(t); }
+            a_job = blockIdx.x * Cfg::JPW + jl;
+            if (a_job < p.J) {
+                const DevClass &c = job_class(p, a_job);
+                if (t < c.ntrials[layer]) {
+                    active = true;
+                    a_t = t; a_lag0 = rem * K; a_u = 1u << t; a_p = P >> t;
+                    const uint32_t n = c.na / a_u;
+                    a_upl = n + (a_p > 4 ? a_p : 4);
+                    a_base = (int32_t)(jl * Cfg::RINGSUM) + off; a_rb = Cfg::rb(t);
+                }
+            }
+        }
     }
-    p.wx[((size_t)job * LNN_MAXT + t) * p.S + s] = v;
+    uint32_t a_n = 1;
+    if (active) a_n = job_class(p, a_job).na / a_u;
+
+    /* ---- generate role: (stream, sub-lane) ---- */
+    bool gen = false;
+    uint32_t g_n = 1, g_u = 1, g_upl = 5, g_halo = 0;
+    int32_t g_base = 0, g_rb = 5, g_pos = 0;       /* ring slot of g_q */
+    uint32_t g_q = 0, g_unit = 0, g_loc = 0, g_ubase = 0;
+    double g_div = 0.0, g_stale = 0.0;
+    const double *g_xd = p.sig; const int32_t *g_xi = p.xint;      /* always dereferenceable */
+    {
+        const uint32_t gs = lane / Cfg::GL, sub = lane % Cfg::GL;
+        if (gs < (uint32_t)Cfg::NS) {
+            const uint32_t jl = gs / NT, t = gs % NT;
+            const uint32_t job = blockIdx.x * Cfg::JPW + jl;
+            if (job < p.J) {
+                const DevClass &c = job_class(p, job);
+                if (t < c.ntrials[layer]) {
+                    gen = true;
+                    g_u = 1u << t; g_n = c.na / g_u;
+                    const uint32_t pp = P >> t;
+                    g_upl = g_n + (pp > 4 ? pp : 4);
+                    g_halo = Cfg::halo(t);
+                    int32_t off = 0;
+                    for (uint32_t i = 0; i < t; i++) off += Cfg::rb(i);
+                    g_base = (int32_t)(jl * Cfg::RINGSUM) + off; g_rb = Cfg::rb(t);
+                    g_div = c.trial_div[layer][t];
+                    if (L0) g_xi = p.xint + (size_t)(job / p.R) * p.S; else g_xd = p.sig + ((size_t)job * 2 + cur) * p.S;
+                    g_q = sub; g_loc = sub; g_pos = (int32_t)sub;
+                    while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+                    if (g_n & 1u) {     /* Q1: stale middle sample = previous trial's last unit at local index m */
+                        const uint32_t m = g_n >> 1, n2 = 2 * g_n, si = (g_u / 2 - 1) * n2 + m;
+                        const double xv = L0 ? ((double)g_xi[si] * p.scale) : g_xd[si];
+                        const double wgt = c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m);
+                        g_stale = xv * wgt;
+                    }
+                }
+            }
+        }
+    }
+
+    /* per-lane accumulate state */
+    double r[K], w[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) { r[j] = 0.0; w[j] = 0.0; }
+    uint32_t a_unit = 0, flush_pos = a_n;           /* first padded position after unit 0's samples */
+    int32_t pa = 0, pw = (int32_t)a_lag0;           /* ring slots of q0 and of q0 + lag0 */
+    double *out = nullptr;
+    if (active) out = p.acorr + ((size_t)a_job * LNN_MAXT + a_t) * LNN_ACW;
+    const double *myring = ring + a_base;
+    double *gring = ring + g_base;
+
+    /* generator step: classify padded position g_q -> sample index (or zero / stale), then advance */
+    constexpr int E = (T + Cfg::GL - 1) / Cfg::GL;  /* elements one generator lane adds per tile (at most) */
+    auto gen_advance = [&]() {
+        g_q += Cfg::GL; g_loc += Cfg::GL;
+        while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+    };
+    auto gen_value = [&](double xv, uint32_t loc) -> double {
+        const uint32_t h = (loc < (g_n >> 1)) ? loc : (g_n - 1 - loc);
+        const double wgt = g_div * (double)h * (double)(g_n - 1 - h);
+        const double v = xv * wgt;
+        return ((g_n & 1u) && loc == (g_n >> 1)) ? g_stale : v;
+    };
+    auto gen_fetch = [&](uint32_t si) -> double { return L0 ? ((double)g_xi[si] * p.scale) : g_xd[si]; };
+
+    /* initial fill: padded positions [0, T + halo) */
+    if (gen) {
+        const uint32_t lim = T + g_halo;
+        while (g_q < lim) {
+            double v = 0.0;
+            if (g_unit < g_u && g_loc < g_n) v = gen_value(gen_fetch(g_ubase + g_loc), g_loc);
+            gring[g_pos] = v;
+            g_pos += Cfg::GL; if (g_pos >= g_rb) g_pos -= g_rb;
+            gen_advance();
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < K; j++) w[j] = myring[pw + j];
+        pw += K; if (pw >= a_rb) pw -= a_rb;
+    }
+
+    const uint32_t q_end = na_max + Cfg::MAXPAD + K;       /* uniform bound: past every lane's last flush */
+    for (uint32_t tile0 = 0; tile0 < q_end; tile0 += T) {
+        /* prefetch the samples of the NEXT refill (positions [tile0 + T + halo, tile0 + 2T + halo)) into registers;
+         * their latency hides behind this tile's accumulation */
+        double fx[E]; uint32_t floc[E];
+        {
+            const uint32_t lim = tile0 + 2 * T + g_halo;
+#pragma unroll
+            for (int e = 0; e < E; e++) {           /* straight-line: E independent loads in flight */
+                const bool in_range = gen && (g_q < lim);
+                const bool in_unit = in_range && (g_unit < g_u) && (g_loc < g_n);
+                const uint32_t si = in_unit ? (g_ubase + g_loc) : 0u;
+                floc[e] = in_unit ? g_loc : (in_range ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+                fx[e] = gen_fetch(si);
+                if (in_range) gen_advance();
+            }
+        }
+        if (active) {
+#pragma unroll 1
+            for (uint32_t q0 = tile0; q0 < tile0 + T; q0 += K) {
+                if (q0 >= flush_pos) {                  /* inside the zero zone after a unit: store and restart */
+                    double *o = out + (size_t)a_unit * (a_p + 1) + a_lag0;
+#pragma unroll
+                    for (int j = 0; j < K; j++) { if (a_lag0 + j <= a_p) o[j] = r[j]; r[j] = 0.0; }
+                    a_unit++;
+                    flush_pos = (a_unit < a_u) ? (flush_pos + a_upl) : 0xFFFFFFFFu;
+                }
+                double a[K], nw[K];
+#pragma unroll
+                for (int j = 0; j < K; j++) { a[j] = myring[pa + j]; nw[j] = myring[pw + j]; }
+                pa += K; if (pa >= a_rb) pa -= a_rb;
+                pw += K; if (pw >= a_rb) pw -= a_rb;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) {
+                        const double x2 = (t + j < K) ? w[t + j] : nw[t + j - K];
+                        r[j] += a[t] * x2;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < K; j++) w[j] = nw[j];
+            }
+        }
+        __syncthreads();
+        if (gen) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (floc[e] != 0xFFFFFFFFu) {
+                    const double gv = gen_value(fx[e], floc[e] < 0xFFFFFFFEu ? floc[e] : 0u);
+                    gring[g_pos] = (floc[e] == 0xFFFFFFFEu) ? 0.0 : gv;
+                    g_pos += Cfg::GL; if (g_pos >= g_rb) g_pos -= g_rb;
+                }
+            }
+        }
+        __syncthreads();
+    }
 }
 
-/* autocorrelation (lpc.c:215-249): one thread per chain (trial, unit, lag), summed in increasing i */
-__global__ void k_autocorr(Plan p, uint32_t layer)
+template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
-    const uint32_t job = blockIdx.y;
-    uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-    const DevClass &c = job_class(p, job);
-    const uint32_t P = p.P[layer];
-    uint32_t t = 0;
-    for (; t < c.ntrials[layer]; t++) {
-        const uint32_t cnt = P + c.trial_u[layer][t];
-        if (q < cnt) break;
-        q -= cnt;
+    using Cfg = AcCfg<P>;
+    const uint32_t blocks = (p.J + Cfg::JPW - 1) / Cfg::JPW;
+    if (layer == 0) hipLaunchKernelGGL((k_autocorr2<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
+    else hipLaunchKernelGGL((k_autocorr2<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
+}
+static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    switch (p.P[layer]) {
+    case 2: launch_autocorr2<2>(st, p, layer, cur, na_max); break;
+    case 4: launch_autocorr2<4>(st, p, layer, cur, na_max); break;
+    case 8: launch_autocorr2<8>(st, p, layer, cur, na_max); break;
+    case 16: launch_autocorr2<16>(st, p, layer, cur, na_max); break;
+    case 32: launch_autocorr2<32>(st, p, layer, cur, na_max); break;
+    case 64: launch_autocorr2<64>(st, p, layer, cur, na_max); break;
+    default: launch_autocorr2<128>(st, p, layer, cur, na_max); break;
     }
-    if (t >= c.ntrials[layer]) return;
-    const uint32_t u = c.trial_u[layer][t], n = c.na / u, np = P / u;
-    const uint32_t unit = q / (np + 1), lag = q - unit * (np + 1);
-    const double *w = p.wx + ((size_t)job * LNN_MAXT + t) * p.S + (size_t)unit * n;
-    double r = 0.0;
-    if (lag < n) {
-        const uint32_t cnt = n - lag;
-        for (uint32_t i = 0; i < cnt; i++) r += w[i] * w[i + lag];
-    }
-    p.acorr[((size_t)job * LNN_MAXT + t) * LNN_ACW + q] = r;
 }
 
 /* ridge + Levinson-Durbin per (trial, unit) (lpc.c:327-366, 578-633 with zero AF iterations), lanes = jobs.
@@ -343,52 +515,173 @@ __global__ void k_levinson(Plan p, uint32_t layer)
     }
 }
 
-/* trial residual magnitude (linne_network.c:318-335): residual = x[s]; residual += h[k]*x[s-p+k] in k order;
- * taps that would read before the start of the frame are skipped (unit 0 ramp, :320-327).  |residual| is
- * stored over the (dead) windowed signal; sample 0 contributes nothing to the loss. */
-#define RES_THREADS 256
-__global__ __launch_bounds__(RES_THREADS) void k_trial_residual(Plan p, uint32_t layer, uint32_t cur)
+/* ------------------------------------------------------------------------------------------------
+ * K_C / K_D (v2): the two double-precision FIR evaluations of a layer, register-blocked.
+ *   MODE 0  trial residual magnitude for every unit-count trial (linne_network.c:318-335):
+ *           residual = x[s]; residual += h[k]*x[s-p+k], k = 0..p-1; |residual| -> wx[job][trial][s]
+ *   MODE 1  forward with the chosen unit count (linne_network.c:165-210):
+ *           predict = 0; predict += h[k]*x[s-p+k]; out[s] = x[s] + predict
+ * A lane owns 4 consecutive samples and slides a 4-wide register window over the taps: per 4 taps it issues
+ * 16 unfused mul+add pairs against 4 LDS reads (2 of samples, 2 of coefficients).  Each sample's sum stays one
+ * chain in increasing tap order.  Lanes whose 4 samples touch the start of the frame (taps are skipped there),
+ * a unit boundary of a ragged tail frame, or p < 4 take the sample-at-a-time path.
+ * ---------------------------------------------------------------------------------------------- */
+#define FIR_THREADS 256
+#define FIR_TILE    (FIR_THREADS * 4)
+template <int MODE>
+__global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
-    __shared__ double xs[RES_THREADS + LNN_MAXP];
-    const uint32_t job = blockIdx.z, t = blockIdx.y, s0 = blockIdx.x * RES_THREADS, tid = threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
+    __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP];
+    const uint32_t job = blockIdx.y, s0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
     const DevClass &c = job_class(p, job);
-    if (t >= c.ntrials[layer] || s0 >= c.na) return;
-    const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u;
+    const uint32_t na = c.na;
+    if (s0 >= na) return;
+    const uint32_t P = p.P[layer];
     const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
-    /* tile [s0 - MAXP, s0 + RES_THREADS) */
-    for (uint32_t i = tid; i < RES_THREADS + LNN_MAXP; i += RES_THREADS) {
+    for (uint32_t i = tid; i < LNN_MAXP + FIR_TILE + 8; i += FIR_THREADS) {
         const int64_t g = (int64_t)s0 - LNN_MAXP + i;
-        xs[i] = (g >= 0 && g < (int64_t)c.na) ? x[g] : 0.0;
+        xs[i] = (g >= 0 && g < (int64_t)na) ? x[g] : 0.0;
     }
-    __syncthreads();
-    const uint32_t s = s0 + tid;
-    if (s >= c.na) return;
-    const uint32_t unit = s / n;
-    const double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
-    double res = xs[tid + LNN_MAXP];
-    const uint32_t kstart = (s < np) ? (np - s) : 0;       /* skip taps before sample 0 */
-    for (uint32_t k = kstart; k < np; k++) res += h[k] * xs[tid + LNN_MAXP - np + k];
-    double av = (res > 0) ? res : -res;                     /* LINNEUTILITY_ABS */
-    if (s == 0) av = 0.0;
-    p.wx[((size_t)job * LNN_MAXT + t) * p.S + s] = av;
+    const uint32_t ntr = (MODE == 0) ? c.ntrials[layer] : 1u;
+    const uint32_t s = s0 + 4 * tid;
+    const double *xc = xs + LNN_MAXP + 4 * tid;                      /* -> x[s] */
+    for (uint32_t t = 0; t < ntr; t++) {
+        const uint32_t u = (MODE == 0) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
+        const uint32_t n = na / u, np = P / u;
+        const double *hsrc = (MODE == 0) ? (p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
+        double *hbuf = hs[t & 1u];
+        if (tid < P) hbuf[tid] = hsrc[tid];
+        __syncthreads();                                             /* also covers the xs fill on the first trip */
+        if (s < na) {
+            double acc[4];
+            const bool whole = ((n & 3u) == 0) && (s >= np) && (s + 3 < na);   /* 4 samples, one unit, all taps present */
+            if (whole && (np & 3u) == 0) {
+                const double *hb = hbuf + (size_t)(s / n) * np;
+                const double *xw = xc - np;                              /* -> x[s - np], 16-byte aligned */
+                double w[4], nw[4], hh[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; w[j] = xw[j]; }
+                for (uint32_t k = 0; k < np; k += 4) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { nw[j] = xw[k + 4 + j]; hh[j] = hb[k + j]; }
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const double xv = (kk + j < 4) ? w[kk + j] : nw[kk + j - 4];
+                            acc[j] += hh[kk] * xv;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) w[j] = nw[j];
+                }
+            } else if (whole && np <= 2) {
+                const double *hb = hbuf + (size_t)(s / n) * np;
+                const double h0 = hb[0];
+                if (np == 1) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
+                } else {
+                    const double h1 = hb[1];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t sj = s + j;
+                    double v = (MODE == 0) ? xc[j] : 0.0;
+                    if (sj < na && sj != 0) {
+                        const double *hb = hbuf + (size_t)(sj / n) * np;
+                        const uint32_t kstart = (sj < np) ? (np - sj) : 0;  /* taps before sample 0 are skipped */
+                        for (uint32_t k = kstart; k < np; k++) v += hb[k] * xc[(int)j - (int)np + (int)k];
+                    }
+                    acc[j] = v;
+                }
+            }
+            if (MODE == 0) {
+                double *dst = p.wx + ((size_t)job * LNN_MAXT + t) * p.S + s;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (s + j < na) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; dst[j] = av; }
+                }
+            } else {
+                double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (s + j < na) { const double xv = xc[j]; dst[j] = (s + j == 0) ? xv : (xv + acc[j]); }
+                }
+            }
+        }
+    }
 }
 
-/* mean |residual| per trial: ONE chain over all samples of all units (linne_network.c:326,334,337) */
-__global__ void k_loss_sum(Plan p, uint32_t layer)
+/* ------------------------------------------------------------------------------------------------
+ * ordered sums (v2): 64 chains per wavefront.  Rows are staged through LDS with coalesced loads and each lane then
+ * adds its own row strictly in sample order, so every sum is the same single chain the reference evaluates.
+ *   MODE 0  mean |residual| of each trial  (rows of wx)            (linne_network.c:326,334,337)
+ *   MODE 1  L1 loss of the last layer's output (rows of sig, fabs) (linne_network.c:50-63)
+ * ---------------------------------------------------------------------------------------------- */
+#define SUM_THREADS 256
+template <int MODE>
+__global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t layer, uint32_t cur)
 {
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
-    if (job >= p.J) return;
-    const DevClass &c = job_class(p, job);
-    if (t >= c.ntrials[layer]) return;
-    const double *a = p.wx + ((size_t)job * LNN_MAXT + t) * p.S;
-    double loss = 0.0;
-    uint32_t s = 0;
-    for (; s + 8 <= c.na; s += 8) {
-        const double v0 = a[s], v1 = a[s + 1], v2 = a[s + 2], v3 = a[s + 3], v4 = a[s + 4], v5 = a[s + 5], v6 = a[s + 6], v7 = a[s + 7];
-        loss += v0; loss += v1; loss += v2; loss += v3; loss += v4; loss += v5; loss += v6; loss += v7;
+    __shared__ double tile[2][64][65];
+    __shared__ uint32_t row_na[64];
+    __shared__ const double *row_ptr[64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, row0 = blockIdx.x * 64;
+    const uint32_t nrows = (MODE == 0) ? p.J * LNN_MAXT : p.J;
+    /* wave 0's lanes own the 64 chains; all four waves stage 16 rows each */
+    uint32_t my_na = 0;
+    if (wave == 0) {
+        const uint32_t myrow = row0 + lane;
+        const double *my_ptr = p.sig;               /* always dereferenceable */
+        if (myrow < nrows) {
+            const uint32_t job = (MODE == 0) ? myrow / LNN_MAXT : myrow;
+            const DevClass &c = job_class(p, job);
+            if (MODE == 1 || (myrow % LNN_MAXT) < c.ntrials[layer]) {
+                my_na = c.na;
+                my_ptr = (MODE == 0) ? (p.wx + (size_t)myrow * p.S) : (p.sig + ((size_t)job * 2 + cur) * p.S);
+            }
+        }
+        row_na[lane] = my_na; row_ptr[lane] = my_ptr;
     }
-    for (; s < c.na; s++) loss += a[s];
-    p.tloss[(size_t)job * LNN_MAXT + t] = loss / (double)c.na;
+    __syncthreads();
+    uint32_t na_blk = 0;
+    for (uint32_t i = 0; i < 64; i++) na_blk = row_na[i] > na_blk ? row_na[i] : na_blk;     /* uniform loop bound */
+    const uint32_t ntiles = (na_blk + 63) / 64;
+    double ld[16];
+    auto fetch = [&](uint32_t tileidx) {            /* 16 unconditional loads in flight; zero beyond a row's end */
+        const uint32_t sl = tileidx * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t r = wave * 16 + i, rn = row_na[r];
+            const uint32_t idx = (sl < rn) ? sl : 0u;
+            double v = row_ptr[r][idx];
+            if (MODE == 1) v = fabs(v);
+            ld[i] = (sl < rn) ? v : 0.0;            /* adding +0.0 leaves a non-negative chain unchanged */
+        }
+    };
+    auto stash = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) tile[buf][wave * 16 + i][lane] = ld[i];
+    };
+    double sum = 0.0;
+    if (ntiles) { fetch(0); stash(0); }
+    __syncthreads();
+    for (uint32_t k = 0; k < ntiles; k++) {
+        if (k + 1 < ntiles) fetch(k + 1);
+        if (wave == 0) {
+#pragma unroll 16
+            for (uint32_t j = 0; j < 64; j++) sum += tile[k & 1u][lane][j];
+        }
+        if (k + 1 < ntiles) stash((k + 1) & 1u);
+        __syncthreads();
+    }
+    if (wave == 0 && my_na) {
+        if (MODE == 0) p.tloss[row0 + lane] = sum / (double)my_na; else p.jloss[row0 + lane] = sum / (double)my_na;
+    }
 }
 
 /* strict-< argmin over the trials (linne_network.c:338-341), keep its coefficients (== SetParameter,
@@ -426,53 +719,6 @@ __global__ void k_select(Plan p, uint32_t layer)
             }
         p.jtail[job] = tail;
     }
-}
-
-/* forward with the chosen units (linne_network.c:165-210): predict = 0; predict += h[j]*din[i-p+j]; data[i] += predict */
-__global__ __launch_bounds__(RES_THREADS) void k_forward(Plan p, uint32_t layer, uint32_t cur)
-{
-    __shared__ double xs[RES_THREADS + LNN_MAXP];
-    const uint32_t job = blockIdx.y, s0 = blockIdx.x * RES_THREADS, tid = threadIdx.x;
-    const DevClass &c = job_class(p, job);
-    if (s0 >= c.na) return;
-    const uint32_t P = p.P[layer], u = p.lunits[(size_t)job * LNN_MAXL + layer], n = c.na / u, np = P / u;
-    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
-    double *y = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
-    for (uint32_t i = tid; i < RES_THREADS + LNN_MAXP; i += RES_THREADS) {
-        const int64_t g = (int64_t)s0 - LNN_MAXP + i;
-        xs[i] = (g >= 0 && g < (int64_t)c.na) ? x[g] : 0.0;
-    }
-    __syncthreads();
-    const uint32_t s = s0 + tid;
-    if (s >= c.na) return;
-    const uint32_t unit = s / n;
-    const double *h = p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP + (size_t)unit * np;
-    double out = xs[tid + LNN_MAXP];
-    if (s != 0) {
-        double pred = 0.0;
-        const uint32_t kstart = (s < np) ? (np - s) : 0;
-        for (uint32_t k = kstart; k < np; k++) pred += h[k] * xs[tid + LNN_MAXP - np + k];
-        out += pred;
-    }
-    y[s] = out;
-}
-
-/* L1 loss of the last layer's output (linne_network.c:50-63): one chain */
-__global__ void k_final_loss(Plan p, uint32_t cur)
-{
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= p.J) return;
-    const DevClass &c = job_class(p, job);
-    const double *a = p.sig + ((size_t)job * 2 + cur) * p.S;
-    double norm = 0.0;
-    uint32_t s = 0;
-    for (; s + 8 <= c.na; s += 8) {
-        const double v0 = fabs(a[s]), v1 = fabs(a[s + 1]), v2 = fabs(a[s + 2]), v3 = fabs(a[s + 3]);
-        const double v4 = fabs(a[s + 4]), v5 = fabs(a[s + 5]), v6 = fabs(a[s + 6]), v7 = fabs(a[s + 7]);
-        norm += v0; norm += v1; norm += v2; norm += v3; norm += v4; norm += v5; norm += v6; norm += v7;
-    }
-    for (; s < c.na; s++) norm += fabs(a[s]);
-    p.jloss[job] = norm / (double)c.na;
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -651,6 +897,7 @@ struct LINNEAmdContext {
     void *arena; uint64_t arena_bytes;
     char err[256];
     int timing;
+    uint32_t na_max;                    /* largest analysis length of the current batch */
     hipEvent_t ev[2]; int ev_valid;
     /* per-kernel spans of the last call (timing enabled): HIP events on the launch stream */
     hipEvent_t *span_ev; int *span_kind; int nspans, span_cap;
@@ -837,6 +1084,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
     uint32_t *nsm = (uint32_t *)malloc(sizeof(uint32_t) * (F ? F : 1));
     if (!idx || !nsm) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
     memset(cls, 0, sizeof(cls));
+    ctx->na_max = 0;
     uint64_t sin_total = 0;
     for (uint32_t f = 0; f < F; f++) {
         const uint32_t n = h_num_samples ? h_num_samples[f] : S;
@@ -852,6 +1100,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
             if (na < hs->maxP) na = hs->maxP;
             if (na > S) na = S;
             c.na = na;
+            if (na > ctx->na_max) ctx->na_max = na;
             c.sin_off = (uint32_t)sin_total; sin_total += n;
             if (for_encode) {
                 if (na & 1u) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
@@ -980,16 +1229,17 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
             uint32_t nt = 0, nprob = 0, nchain = 0;
             for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
-            { const int sp_ = span_begin(ctx, 2); hipLaunchKernelGGL(k_window, dim3(sblocks, nt, (uint32_t)J), dim3(256), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 3); hipLaunchKernelGGL(k_autocorr, dim3((nchain + 63) / 64, (uint32_t)J), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            {
+                const int sp_ = span_begin(ctx, 3); dispatch_autocorr2(ctx->stream, p, l, cur, ctx->na_max); span_end(ctx, sp_);
+            }
             { const int sp_ = span_begin(ctx, 4); hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 5); hipLaunchKernelGGL(k_trial_residual, dim3(sblocks, nt, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 6); hipLaunchKernelGGL(k_loss_sum, dim3(((uint32_t)J + 63) / 64, nt), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 5); hipLaunchKernelGGL(k_fir2<0>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 6); hipLaunchKernelGGL(k_chain_sum<0>, dim3(((uint32_t)J * LNN_MAXT + 63) / 64), dim3(SUM_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
             { const int sp_ = span_begin(ctx, 7); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 8); hipLaunchKernelGGL(k_forward, dim3(sblocks, (uint32_t)J), dim3(RES_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 8); hipLaunchKernelGGL(k_fir2<1>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
             cur ^= 1u;
         }
-        { const int sp_ = span_begin(ctx, 9); hipLaunchKernelGGL(k_final_loss, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, cur); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 9); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, ctx->stream, p, 0u, cur); span_end(ctx, sp_); }
         { const int sp_ = span_begin(ctx, 10); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, ctx->stream, p); span_end(ctx, sp_); }
         HIPCHK(ctx, hipGetLastError());
     }

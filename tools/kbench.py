@@ -1,0 +1,30 @@
+"""small driver for profiling: encode (and optionally decode) a batch of synthetic stereo frames once or twice"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import linne_amd
+from bench import synth_track, frames_from_track, KERNEL_KINDS
+ap = argparse.ArgumentParser()
+ap.add_argument("--frames", type=int, default=1024)
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--decode", action="store_true")
+ap.add_argument("--preset", type=int, default=7)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+track = synth_track(a.frames * 10240, 2, 16, 1, dev)
+frames, nsm = frames_from_track(track, 10240)
+ctx = linne_amd.Context(0, scratch_bytes=12 << 30)
+shape = ctx.shape(2, 16, 10240, a.preset, True)
+ctx.enable_timing(True)
+for r in range(a.reps):
+    t0 = time.perf_counter()
+    res, prm, st = ctx.encode_frames(shape, frames, nsm)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"rep {r}: encode {a.frames} frames {dt*1e3:.2f} ms -> {a.frames/dt:.0f} frames/s;", {KERNEL_KINDS[k]: round(ctx.last_ms(k), 3) for k in range(1, 11) if ctx.last_ms(k) > 0})
+if a.decode:
+    for r in range(a.reps):
+        w = res.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx.decode_frames(shape, w, prm, nsm); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"rep {r}: decode {dt*1e3:.2f} ms -> {a.frames/dt:.0f} frames/s ok={bool(torch.equal(w, frames))}")
