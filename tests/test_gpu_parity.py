@@ -127,3 +127,49 @@ def test_full_size_round_trip_property(ctx):
     res, prm, st = ctx.encode_frames_host(shape, frames)
     assert np.array_equal(ctx.decode_frames_host(shape, res, prm), frames)
     assert (prm[:, :, linne_amd.PRM_UNITS:linne_amd.PRM_UNITS + 3] >= 1).all()
+
+
+def test_golden_streams_through_the_drop_in_api(product):
+    """committed golden vectors (generated by the real reference, tests/golden/make_golden.py)"""
+    import hashlib
+    import json
+    import os
+    from test_oracle_cpu import GOLD, golden_small, read_wav
+    for i, x, bits, rate, block, preset, ms, want in golden_small():
+        got = product.encode_whole(x, bits, rate, block, preset, ms)
+        assert got == want, f"small case {i}"
+        ret, dec = product.decode_whole(want)
+        assert ret == 0 and np.array_equal(dec[:x.shape[0], :x.shape[1]], x)
+    h = json.load(open(os.path.join(GOLD, "golden_hashes.json")))
+    for name, e in h.items():
+        if name.startswith("large/"):
+            x = music(*e["music_args"])
+            if hashlib.sha256(np.ascontiguousarray(x).tobytes()).hexdigest() != e["input_sha256"]:
+                continue
+            got = product.encode_whole(x, e["music_args"][2], e["rate"], e["block"], e["preset"], bool(e["ms"]))
+        elif name.startswith("wav/"):
+            x, rate, bits = read_wav(os.path.join(GOLD, name[4:].rsplit("_m", 1)[0]))
+            got = product.encode_whole(x, bits, rate, e["block"], e["preset"], bool(e["ms"]))
+        else:
+            continue
+        assert len(got) == e["bytes"] and hashlib.sha256(got).hexdigest() == e["sha256"], name
+        ret, dec = product.decode_whole(got)
+        assert ret == 0 and np.array_equal(dec, x), name
+
+
+def test_reference_cli_links_against_liblinne_amd_unchanged(tmp_path):
+    """oracle/_ref/linne_dropin = the reference's tools/linne_codec/linne_codec.c compiled against this repo's
+    include/ and linked with liblinne_amd.so; its .lnn must equal the reference CLI's, and decode must restore the WAV"""
+    import os
+    import subprocess
+    from refs import ROOT
+    dropin, refcli = os.path.join(ROOT, "oracle", "_ref", "linne_dropin"), os.path.join(ROOT, "oracle", "_ref", "linne_ref")
+    if not (os.path.exists(dropin) and os.path.exists(refcli)):
+        pytest.skip("oracle/_ref CLI binaries not built")
+    wav = os.path.join(ROOT, "tests", "golden", "ref_16bit_2ch.wav")
+    a, b, w = str(tmp_path / "a.lnn"), str(tmp_path / "b.lnn"), str(tmp_path / "back.wav")
+    subprocess.run([refcli, "-e", "-m", "7", wav, a], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([dropin, "-e", "-m", "7", wav, b], check=True, stdout=subprocess.DEVNULL)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    subprocess.run([dropin, "-d", b, w], check=True, stdout=subprocess.DEVNULL)
+    assert open(w, "rb").read()[-176400:] == open(wav, "rb").read()[-176400:]     # PCM payload (44100 x 2 ch x 2 B)
