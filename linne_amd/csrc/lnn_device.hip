@@ -357,7 +357,9 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
     int32_t pa = 0, pw = (int32_t)a_lag0;           /* ring slots of q0 and of q0 + lag0 */
     double *out = nullptr;
     if (active) out = p.acorr + ((size_t)a_job * LNN_MAXT + a_t) * LNN_ACW;
-    const double *myring = ring + a_base;
+    /* volatile LDS pointer: keeps the 8-byte reads unmerged (ds_read2_b64 runs at half the rate of two ds_read_b64) */
+    typedef const volatile __attribute__((address_space(3))) double *lds_ro_ptr;
+    lds_ro_ptr myring = (lds_ro_ptr)(ring + a_base);
     double *gring = ring + g_base;
 
     /* generator step: classify padded position g_q -> sample index (or zero / stale), then advance */
@@ -527,12 +529,15 @@ __global__ void k_levinson(Plan p, uint32_t layer)
  * a unit boundary of a ragged tail frame, or p < 4 take the sample-at-a-time path.
  * ---------------------------------------------------------------------------------------------- */
 #define FIR_THREADS 256
-#define FIR_TILE    (FIR_THREADS * 4)
+#define FIR_SPL     8                       /* consecutive samples per lane */
+#define FIR_TILE    (FIR_THREADS * FIR_SPL)
+typedef double lnn_d2 __attribute__((ext_vector_type(2)));
 template <int MODE>
 __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
     __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP];
+    __shared__ __attribute__((aligned(16))) double ob[FIR_THREADS / 64][64 * FIR_SPL];   /* per-wave store transpose */
     const uint32_t job = blockIdx.y, s0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
@@ -544,8 +549,8 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
         xs[i] = (g >= 0 && g < (int64_t)na) ? x[g] : 0.0;
     }
     const uint32_t ntr = (MODE == 0) ? c.ntrials[layer] : 1u;
-    const uint32_t s = s0 + 4 * tid;
-    const double *xc = xs + LNN_MAXP + 4 * tid;                      /* -> x[s] */
+    const uint32_t s = s0 + FIR_SPL * tid;
+    const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
     for (uint32_t t = 0; t < ntr; t++) {
         const uint32_t u = (MODE == 0) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
         const uint32_t n = na / u, np = P / u;
@@ -553,43 +558,45 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
         double *hbuf = hs[t & 1u];
         if (tid < P) hbuf[tid] = hsrc[tid];
         __syncthreads();                                             /* also covers the xs fill on the first trip */
+        double acc[FIR_SPL];
         if (s < na) {
-            double acc[4];
-            const bool whole = ((n & 3u) == 0) && (s >= np) && (s + 3 < na);   /* 4 samples, one unit, all taps present */
+            /* all FIR_SPL samples in one unit, every tap present */
+            const bool whole = ((n & (FIR_SPL - 1)) == 0) && (s >= np) && (s + FIR_SPL - 1 < na);
             if (whole && (np & 3u) == 0) {
                 const double *hb = hbuf + (size_t)(s / n) * np;
-                const double *xw = xc - np;                              /* -> x[s - np], 16-byte aligned */
-                double w[4], nw[4], hh[4];
+                const double *xw = xc - np;                              /* -> x[s - np] */
+                double w[FIR_SPL + 4];                                   /* sliding window: x[s-np+k .. +FIR_SPL+3] */
 #pragma unroll
-                for (int j = 0; j < 4; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; w[j] = xw[j]; }
+                for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE == 0) ? xc[j] : 0.0;
                 for (uint32_t k = 0; k < np; k += 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { nw[j] = xw[k + 4 + j]; hh[j] = hb[k + j]; }
+                    const lnn_d2 n0 = *(const lnn_d2 *)(xw + k + FIR_SPL), n1 = *(const lnn_d2 *)(xw + k + FIR_SPL + 2);
+                    const lnn_d2 h01 = *(const lnn_d2 *)(hb + k), h23 = *(const lnn_d2 *)(hb + k + 2);
+                    w[FIR_SPL] = n0.x; w[FIR_SPL + 1] = n0.y; w[FIR_SPL + 2] = n1.x; w[FIR_SPL + 3] = n1.y;
+                    const double hh[4] = { h01.x, h01.y, h23.x, h23.y };
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
 #pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const double xv = (kk + j < 4) ? w[kk + j] : nw[kk + j - 4];
-                            acc[j] += hh[kk] * xv;
-                        }
+                        for (int j = 0; j < FIR_SPL; j++) acc[j] += hh[kk] * w[kk + j];
                     }
 #pragma unroll
-                    for (int j = 0; j < 4; j++) w[j] = nw[j];
+                    for (int j = 0; j < FIR_SPL; j++) w[j] = w[j + 4];
                 }
             } else if (whole && np <= 2) {
                 const double *hb = hbuf + (size_t)(s / n) * np;
                 const double h0 = hb[0];
                 if (np == 1) {
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
                 } else {
                     const double h1 = hb[1];
 #pragma unroll
-                    for (int j = 0; j < 4; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
                 }
             } else {
 #pragma unroll 1
-                for (int j = 0; j < 4; j++) {
+                for (int j = 0; j < FIR_SPL; j++) {
                     const uint32_t sj = s + j;
                     double v = (MODE == 0) ? xc[j] : 0.0;
                     if (sj < na && sj != 0) {
@@ -600,18 +607,31 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
                     acc[j] = v;
                 }
             }
-            if (MODE == 0) {
-                double *dst = p.wx + ((size_t)job * LNN_MAXT + t) * p.S + s;
+            /* results: |residual| (MODE 0) or x + predict (MODE 1) */
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (s + j < na) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; dst[j] = av; }
-                }
-            } else {
-                double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+            for (int j = 0; j < FIR_SPL; j++) {
+                if (MODE == 0) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; acc[j] = av; }
+                else { const double xv = xc[j]; acc[j] = (s + j == 0) ? xv : (xv + acc[j]); }
+            }
+        }
+        {   /* coalesced store: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive lanes write
+             * consecutive 16-byte pieces (a lane's own 8 results are 64 bytes apart from its neighbour's) */
+            const uint32_t wv = tid >> 6, ln = tid & 63u, wbase = s0 + wv * 64 * FIR_SPL;
+            double *dst = (MODE == 0) ? (p.wx + ((size_t)job * LNN_MAXT + t) * p.S) : (p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S);
+            if (wbase < na) {
+                if (s < na) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (s + j < na) { const double xv = xc[j]; dst[j] = (s + j == 0) ? xv : (xv + acc[j]); }
+                    for (int j = 0; j < FIR_SPL; j += 2) { lnn_d2 v; v.x = acc[j]; v.y = acc[j + 1]; *(lnn_d2 *)(&ob[wv][ln * FIR_SPL + j]) = v; }
                 }
+                __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0): the wave's own LDS writes have landed */
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < FIR_SPL / 2; i++) {
+                    const uint32_t e = 2 * ln + 128 * i, g = wbase + e;
+                    if (g + 1 < na) *(lnn_d2 *)(dst + g) = *(const lnn_d2 *)(&ob[wv][e]);
+                    else if (g < na) dst[g] = ob[wv][e];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
