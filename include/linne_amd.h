@@ -112,6 +112,10 @@ int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmd
 int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         int32_t *data, const uint32_t *num_samples, uint32_t num_frames, const int32_t *params);
 
+/* Number of (job, layer) unit-count searches of the last EncodeFramesDevice call that the certified order-free
+ * search could not decide and that therefore ran the exact ordered sums (synchronises; -1 on error). */
+int64_t LINNEAmd_GetLastFallbackCount(struct LINNEAmdContext *ctx);
+
 /* blocks until everything enqueued on the context's stream has finished */
 int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
 

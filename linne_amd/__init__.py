@@ -37,7 +37,7 @@ API_SYMBOLS = [
 AMD_SYMBOLS = [
     "LINNEAmd_GetDeviceCount", "LINNEAmd_ContextCreate", "LINNEAmd_ContextDestroy", "LINNEAmd_GetLastError",
     "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
-    "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastTimingMs",
+    "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
 ]
 
@@ -75,6 +75,8 @@ def _load():
                                             C.c_void_p, C.c_void_p, C.c_void_p]
     L.LINNEAmd_DecodeFramesHost.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.LINNEAmd_Synchronize.argtypes = [C.c_void_p]
+    L.LINNEAmd_GetLastFallbackCount.restype = C.c_int64
+    L.LINNEAmd_GetLastFallbackCount.argtypes = [C.c_void_p]
     L.LINNEAmd_GetLastTimingMs.restype = C.c_double
     L.LINNEAmd_GetLastTimingMs.argtypes = [C.c_void_p, C.c_int]
     L.LINNEAmd_EnableTiming.argtypes = [C.c_void_p, C.c_int]
@@ -137,6 +139,9 @@ class Context:
 
     def last_launches(self, which):
         return int(lib.LINNEAmd_GetLastTimingLaunches(self.h, which))
+
+    def last_fallback_count(self):
+        return int(lib.LINNEAmd_GetLastFallbackCount(self.h))
 
     def synchronize(self):
         self._check(lib.LINNEAmd_Synchronize(self.h), "Synchronize")

@@ -57,7 +57,10 @@ struct Plan {
     double *acorr;                      /* [J][MAXT][ACW]              */
     double *tcoef;                      /* [J][MAXT][MAXP]  filter order (reversed LPC order) */
     double *ptail; uint8_t *ptail_set;  /* [J][MAXT][MAXU]             */
-    double *tloss;                      /* [J][MAXT]                   */
+    double *tloss;                      /* [J][MAXT] exact mean |residual| (ordered chain)            */
+    double *tsum;                       /* [J][MAXT] order-free sum of |residual| (certified search)  */
+    uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
+    uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
     double *lparams;                    /* [J][MAXL][MAXP]             */
     uint32_t *lunits;                   /* [J][MAXL]                   */
     double *jloss, *jtail;              /* [J]                         */
@@ -539,6 +542,7 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
     __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP];
     __shared__ __attribute__((aligned(16))) double ob[FIR_THREADS / 64][64 * FIR_SPL];   /* per-wave store transpose */
     const uint32_t job = blockIdx.y, s0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
+    if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
     if (s0 >= na) return;
@@ -548,13 +552,13 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
         const int64_t g = (int64_t)s0 - LNN_MAXP + i;
         xs[i] = (g >= 0 && g < (int64_t)na) ? x[g] : 0.0;
     }
-    const uint32_t ntr = (MODE == 0) ? c.ntrials[layer] : 1u;
+    const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
     const uint32_t s = s0 + FIR_SPL * tid;
     const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
     for (uint32_t t = 0; t < ntr; t++) {
-        const uint32_t u = (MODE == 0) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
+        const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
         const uint32_t n = na / u, np = P / u;
-        const double *hsrc = (MODE == 0) ? (p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
+        const double *hsrc = (MODE != 1) ? (p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
         double *hbuf = hs[t & 1u];
         if (tid < P) hbuf[tid] = hsrc[tid];
         __syncthreads();                                             /* also covers the xs fill on the first trip */
@@ -569,7 +573,7 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
 #pragma unroll
                 for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
 #pragma unroll
-                for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE == 0) ? xc[j] : 0.0;
+                for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE != 1) ? xc[j] : 0.0;
                 for (uint32_t k = 0; k < np; k += 4) {
                     const lnn_d2 n0 = *(const lnn_d2 *)(xw + k + FIR_SPL), n1 = *(const lnn_d2 *)(xw + k + FIR_SPL + 2);
                     const lnn_d2 h01 = *(const lnn_d2 *)(hb + k), h23 = *(const lnn_d2 *)(hb + k + 2);
@@ -588,17 +592,17 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
                 const double h0 = hb[0];
                 if (np == 1) {
 #pragma unroll
-                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
                 } else {
                     const double h1 = hb[1];
 #pragma unroll
-                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE == 0) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
                 }
             } else {
 #pragma unroll 1
                 for (int j = 0; j < FIR_SPL; j++) {
                     const uint32_t sj = s + j;
-                    double v = (MODE == 0) ? xc[j] : 0.0;
+                    double v = (MODE != 1) ? xc[j] : 0.0;
                     if (sj < na && sj != 0) {
                         const double *hb = hbuf + (size_t)(sj / n) * np;
                         const uint32_t kstart = (sj < np) ? (np - sj) : 0;  /* taps before sample 0 are skipped */
@@ -610,11 +614,22 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
             /* results: |residual| (MODE 0) or x + predict (MODE 1) */
 #pragma unroll
             for (int j = 0; j < FIR_SPL; j++) {
-                if (MODE == 0) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; acc[j] = av; }
+                if (MODE != 1) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; acc[j] = av; }
                 else { const double xv = xc[j]; acc[j] = (s + j == 0) ? xv : (xv + acc[j]); }
             }
         }
-        {   /* coalesced store: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive lanes write
+        if (MODE == 2) {
+            /* order-free partial sum of this wave's |residual| values; the exact ordered chain is evaluated later only for
+             * jobs whose argmin these sums cannot certify (k_select) */
+            double ps = 0.0;
+            if (s < na) {
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) if (s + j < na) ps += acc[j];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
+            if ((tid & 63u) == 0) atomicAdd(&p.tsum[(size_t)job * LNN_MAXT + t], ps);
+        } else {   /* coalesced store: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive lanes write
              * consecutive 16-byte pieces (a lane's own 8 results are 64 bytes apart from its neighbour's) */
             const uint32_t wv = tid >> 6, ln = tid & 63u, wbase = s0 + wv * 64 * FIR_SPL;
             double *dst = (MODE == 0) ? (p.wx + ((size_t)job * LNN_MAXT + t) * p.S) : (p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S);
@@ -660,7 +675,7 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
         if (myrow < nrows) {
             const uint32_t job = (MODE == 0) ? myrow / LNN_MAXT : myrow;
             const DevClass &c = job_class(p, job);
-            if (MODE == 1 || (myrow % LNN_MAXT) < c.ntrials[layer]) {
+            if (MODE == 1 || ((myrow % LNN_MAXT) < c.ntrials[layer] && p.uncertain[job])) {
                 my_na = c.na;
                 my_ptr = (MODE == 0) ? (p.wx + (size_t)myrow * p.S) : (p.sig + ((size_t)job * 2 + cur) * p.S);
             }
@@ -708,18 +723,38 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
  * :350-376, which recomputes the same values) and, for the last layer, the value the layer leaves in
  * parcor[P0] (Q2): the last call in reference order -- trials in order, then SetParameter's units -- that
  * wrote it. */
-__global__ void k_select(Plan p, uint32_t layer)
+__global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
 {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= p.J) return;
+    if (exact && !p.uncertain[job]) return;
     const DevClass &c = job_class(p, job);
     double min_loss = (double)FLT_MAX;
-    uint32_t best = 0; int found = 0;
-    for (uint32_t t = 0; t < c.ntrials[layer]; t++) {
-        const double l = p.tloss[(size_t)job * LNN_MAXT + t];
-        if (l < min_loss) { min_loss = l; best = t; found = 1; }
+    uint32_t best = 0;
+    const uint32_t nt = c.ntrials[layer];
+    if (exact) {
+        for (uint32_t t = 0; t < nt; t++) {
+            const double l = p.tloss[(size_t)job * LNN_MAXT + t];
+            if (l < min_loss) { min_loss = l; best = t; }
+        }
+    } else {
+        /* Certified search.  m_t below is the mean of an order-free sum of the same non-negative terms the reference
+         * adds sequentially; both sums are within gamma_n * S of the exact sum S, so they differ by at most
+         * rel = (2 na + 8) * 2^-53 relatively.  If the smallest mean is separated from every other by more than that,
+         * the reference's strict-< argmin (linne_network.c:338-341) is the same trial; otherwise the job is flagged and
+         * the ordered chains are evaluated (k_fir2<0>, k_chain_sum<0>, k_select exact). */
+        double m[LNN_MAXT];
+        const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
+        int ok = 1;
+        for (uint32_t t = 0; t < nt; t++) {
+            m[t] = p.tsum[(size_t)job * LNN_MAXT + t] / (double)c.na;
+            if (!(m[t] >= 0.0) || !(m[t] < (double)FLT_MAX)) ok = 0;
+            if (m[t] < min_loss) { min_loss = m[t]; best = t; }
+        }
+        for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) > min_loss * (1.0 + rel))) ok = 0;
+        p.uncertain[job] = ok ? 0 : 1;
+        if (!ok) atomicAdd(p.ucount, 1u);
     }
-    (void)found;
     const uint32_t P = p.P[layer];
     p.lunits[(size_t)job * LNN_MAXL + layer] = c.trial_u[layer][best];
     const double *h = p.tcoef + ((size_t)job * LNN_MAXT + best) * LNN_MAXP;
@@ -922,6 +957,7 @@ struct LINNEAmdContext {
     /* per-kernel spans of the last call (timing enabled): HIP events on the launch stream */
     hipEvent_t *span_ev; int *span_kind; int nspans, span_cap;
     /* cached class tables */
+    uint32_t *d_ucount;
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
 };
 
@@ -967,6 +1003,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     if ((e = hipMalloc(&ctx->arena, scratch_bytes)) != hipSuccess) { CC_FAIL("hipMalloc(arena)"); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
     ctx->arena_bytes = scratch_bytes;
     if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
+    if ((e = hipMalloc((void **)&ctx->d_ucount, sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
     return ctx;
@@ -979,6 +1016,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     hipStreamSynchronize(ctx->stream);
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->d_cls) hipFree(ctx->d_cls);
+    if (ctx->d_ucount) hipFree(ctx->d_ucount);
     if (ctx->d_sin) hipFree(ctx->d_sin);
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
@@ -1012,6 +1050,15 @@ extern "C" int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t byt
     if (ctx->arena) HIPCHK(ctx, hipFree(ctx->arena));
     ctx->arena = fresh; ctx->arena_bytes = bytes;
     return LNN_OK;
+}
+
+extern "C" int64_t LINNEAmd_GetLastFallbackCount(struct LINNEAmdContext *ctx)
+{
+    if (!ctx) return -1;
+    uint32_t v = 0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess
+            || hipMemcpy(&v, ctx->d_ucount, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (int64_t)v;
 }
 
 extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
@@ -1181,7 +1228,7 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     b += J * LNN_MAXT * LNN_ACW * sizeof(double);
     b += J * LNN_MAXT * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXT * LNN_MAXU * (sizeof(double) + 1);
-    b += J * LNN_MAXT * sizeof(double);
+    b += J * LNN_MAXT * sizeof(double) * 2 + J;
     b += J * LNN_MAXL * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXL * sizeof(uint32_t);
     b += J * 2 * sizeof(double);
@@ -1219,6 +1266,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     }
 
     ctx->nspans = 0;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount, 0, sizeof(uint32_t), ctx->stream));
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk) {
         const uint32_t Fc = (num_frames - f0 < chunk) ? (num_frames - f0) : (uint32_t)chunk;
@@ -1230,14 +1278,14 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
         p.pcm = d_pcm + (size_t)f0 * C * S; p.resid = d_residual + (size_t)f0 * C * S;
         p.prm = d_params + (size_t)f0 * C * LINNE_AMD_PARAM_WORDS; p.stats = d_stats + (size_t)f0 * C * LINNE_AMD_STAT_WORDS;
-        p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin;
+        p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.ucount = ctx->d_ucount;
         uint8_t *a = (uint8_t *)ctx->arena;
 #define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
         TAKE(p.xint, int32_t, CF * S); TAKE(p.xtmp, int32_t, CF * S);
         TAKE(p.sig, double, J * 2 * S); TAKE(p.wx, double, J * LNN_MAXT * S);
         TAKE(p.acorr, double, J * LNN_MAXT * LNN_ACW); TAKE(p.tcoef, double, J * LNN_MAXT * LNN_MAXP);
         TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
-        TAKE(p.tloss, double, J * LNN_MAXT); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
+        TAKE(p.tloss, double, J * LNN_MAXT); TAKE(p.tsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
 #undef TAKE
         if ((uint64_t)(a - (uint8_t *)ctx->arena) > ctx->arena_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
@@ -1253,9 +1301,13 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 const int sp_ = span_begin(ctx, 3); dispatch_autocorr2(ctx->stream, p, l, cur, ctx->na_max); span_end(ctx, sp_);
             }
             { const int sp_ = span_begin(ctx, 4); hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 5); hipLaunchKernelGGL(k_fir2<0>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 6); hipLaunchKernelGGL(k_chain_sum<0>, dim3(((uint32_t)J * LNN_MAXT + 63) / 64), dim3(SUM_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 7); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
+            HIPCHK(ctx, hipMemsetAsync(p.tsum, 0, sizeof(double) * J * LNN_MAXT, ctx->stream));
+            { const int sp_ = span_begin(ctx, 5); hipLaunchKernelGGL(k_fir2<2>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 7); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l, 0u); span_end(ctx, sp_); }
+            /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
+            { const int sp_ = span_begin(ctx, 6); hipLaunchKernelGGL(k_fir2<0>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur);
+              hipLaunchKernelGGL(k_chain_sum<0>, dim3(((uint32_t)J * LNN_MAXT + 63) / 64), dim3(SUM_THREADS), 0, ctx->stream, p, l, cur);
+              hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l, 1u); span_end(ctx, sp_); }
             { const int sp_ = span_begin(ctx, 8); hipLaunchKernelGGL(k_fir2<1>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
             cur ^= 1u;
         }

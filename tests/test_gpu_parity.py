@@ -127,6 +127,7 @@ def test_full_size_round_trip_property(ctx):
     res, prm, st = ctx.encode_frames_host(shape, frames)
     assert np.array_equal(ctx.decode_frames_host(shape, res, prm), frames)
     assert (prm[:, :, linne_amd.PRM_UNITS:linne_amd.PRM_UNITS + 3] >= 1).all()
+    assert ctx.last_fallback_count() == 0        # ordinary audio: every search is certified by the order-free sums
 
 
 def test_golden_streams_through_the_drop_in_api(product):
@@ -173,3 +174,22 @@ def test_reference_cli_links_against_liblinne_amd_unchanged(tmp_path):
     assert open(a, "rb").read() == open(b, "rb").read()
     subprocess.run([dropin, "-d", b, w], check=True, stdout=subprocess.DEVNULL)
     assert open(w, "rb").read()[-176400:] == open(wav, "rb").read()[-176400:]     # PCM payload (44100 x 2 ch x 2 B)
+
+
+@pytest.mark.parametrize("kind", ["silence", "positive_const", "negative_const", "nyquist", "sine", "chirp", "white_noise"])
+def test_hotpath_degenerate_signals(ctx, oracle, kind):
+    """signals whose trial losses tie exactly (all-zero residuals) or nearly: the certified order-free search must
+    hand them to the exact ordered chains and still pick the reference's unit counts"""
+    nch, bits, block, preset = 2, 16, 1024, 7
+    x = waveform(kind, nch, 4 * block, bits, seed=3)
+    frames = np.ascontiguousarray(x.reshape(nch, 4, block).transpose(1, 0, 2))
+    shape = ctx.shape(nch, bits, block, preset, True)
+    res, prm, st = ctx.encode_frames_host(shape, frames)
+    for f in range(4):
+        enc = oracle.encoder(nch, bits, 44100, block, preset, True)
+        tap, ores = enc.hotpath(frames[f])
+        enc.close()
+        _check_taps(tap, prm[f], st[f], preset, nch, f"{kind} frame {f}")
+        assert np.array_equal(ores, res[f])
+    if kind in ("silence", "positive_const", "negative_const"):
+        assert ctx.last_fallback_count() > 0, "exact ties must take the ordered-chain fallback"
