@@ -32,6 +32,7 @@
 #define LNN_MAXCLS      16
 #define LNN_MAXCH       8
 #define LNN_ACW         256     /* autocorrelation words per (job, trial): P + u <= 256 */
+#define LNN_MAXSUB      8
 
 /* one distinct frame length of a batch (full frames, the ragged tail, ...) */
 struct DevClass {
@@ -42,6 +43,7 @@ struct DevClass {
     uint32_t ntrials[LNN_MAXL];
     uint32_t trial_u[LNN_MAXL][LNN_MAXT];
     double   trial_div[LNN_MAXL][LNN_MAXT];   /* 4*pow(na/u - 1, -2) from the host libm (lpc.c:199)  */
+    uint32_t wt_off[LNN_MAXL][LNN_MAXT];      /* offset of the trial's Welch weight table (padded unit: n + max(p,4) entries) */
 };
 
 struct Plan {
@@ -50,7 +52,7 @@ struct Plan {
     double regs[LNN_MAXR];
     double scale;                       /* 2^-(bits-1), exact */
     const int32_t *pcm; int32_t *resid; int32_t *prm; double *stats;
-    const uint32_t *cls_of_frame; const DevClass *cls; const double *sintab;
+    const uint32_t *cls_of_frame; const DevClass *cls; const double *sintab; const double *wtab;
     int32_t *xint, *xtmp;               /* [F*C][S]                    */
     double *sig;                        /* [J][2][S]                   */
     double *wx;                         /* [J][MAXT][S] windowed signal, later |trial residual| */
@@ -319,7 +321,8 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
     uint32_t g_n = 1, g_u = 1, g_upl = 5, g_halo = 0;
     int32_t g_base = 0, g_rb = 5, g_pos = 0;       /* ring slot of g_q */
     uint32_t g_q = 0, g_unit = 0, g_loc = 0, g_ubase = 0;
-    double g_div = 0.0, g_stale = 0.0;
+    double g_stale = 0.0;
+    const double *g_wt = p.wtab;                    /* Welch weights of my trial, one padded unit */
     const double *g_xd = p.sig; const int32_t *g_xi = p.xint;      /* always dereferenceable */
     {
         const uint32_t gs = lane / Cfg::GL, sub = lane % Cfg::GL;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
                     int32_t off = 0;
                     for (uint32_t i = 0; i < t; i++) off += Cfg::rb(i);
                     g_base = (int32_t)(jl * Cfg::RINGSUM) + off; g_rb = Cfg::rb(t);
-                    g_div = c.trial_div[layer][t];
+                    g_wt = p.wtab + c.wt_off[layer][t];
                     if (L0) g_xi = p.xint + (size_t)(job / p.R) * p.S; else g_xd = p.sig + ((size_t)job * 2 + cur) * p.S;
                     g_q = sub; g_loc = sub; g_pos = (int32_t)sub;
                     while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
@@ -371,10 +374,9 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
         g_q += Cfg::GL; g_loc += Cfg::GL;
         while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
     };
-    auto gen_value = [&](double xv, uint32_t loc) -> double {
-        const uint32_t h = (loc < (g_n >> 1)) ? loc : (g_n - 1 - loc);
-        const double wgt = g_div * (double)h * (double)(g_n - 1 - h);
-        const double v = xv * wgt;
+    /* element of the padded stream: x[unit*n + loc] * w(loc); w is 0 in the zero zone; Q1 replaces an odd unit's middle */
+    auto gen_value = [&](double xv, double wv, uint32_t loc) -> double {
+        const double v = xv * wv;
         return ((g_n & 1u) && loc == (g_n >> 1)) ? g_stale : v;
     };
     auto gen_fetch = [&](uint32_t si) -> double { return L0 ? ((double)g_xi[si] * p.scale) : g_xd[si]; };
@@ -384,7 +386,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
         const uint32_t lim = T + g_halo;
         while (g_q < lim) {
             double v = 0.0;
-            if (g_unit < g_u && g_loc < g_n) v = gen_value(gen_fetch(g_ubase + g_loc), g_loc);
+            if (g_unit < g_u && g_loc < g_n) v = gen_value(gen_fetch(g_ubase + g_loc), g_wt[g_loc], g_loc);
             gring[g_pos] = v;
             g_pos += Cfg::GL; if (g_pos >= g_rb) g_pos -= g_rb;
             gen_advance();
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
     for (uint32_t tile0 = 0; tile0 < q_end; tile0 += T) {
         /* prefetch the samples of the NEXT refill (positions [tile0 + T + halo, tile0 + 2T + halo)) into registers;
          * their latency hides behind this tile's accumulation */
-        double fx[E]; uint32_t floc[E];
+        double fx[E], fw[E]; uint32_t floc[E];
         {
             const uint32_t lim = tile0 + 2 * T + g_halo;
 #pragma unroll
@@ -411,6 +413,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
                 const uint32_t si = in_unit ? (g_ubase + g_loc) : 0u;
                 floc[e] = in_unit ? g_loc : (in_range ? 0xFFFFFFFEu : 0xFFFFFFFFu);
                 fx[e] = gen_fetch(si);
+                fw[e] = g_wt[in_unit ? g_loc : 0u];
                 if (in_range) gen_advance();
             }
         }
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (floc[e] != 0xFFFFFFFFu) {
-                    const double gv = gen_value(fx[e], floc[e] < 0xFFFFFFFEu ? floc[e] : 0u);
+                    const double gv = gen_value(fx[e], fw[e], floc[e]);
                     gring[g_pos] = (floc[e] == 0xFFFFFFFEu) ? 0.0 : gv;
                     g_pos += Cfg::GL; if (g_pos >= g_rb) g_pos -= g_rb;
                 }
@@ -454,6 +457,129 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
         }
         __syncthreads();
     }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K_A for the short layers (P <= 16): every lane is an independent (job, trial, 5-lag group) and produces its own
+ * padded windowed stream on the fly (one new element per step, prefetched one 5-step group ahead), so there is no
+ * tile loop, no barrier and no shared staging; lanes whose lag group does not start at 0 re-read x[q] from a
+ * lane-private LDS delay ring.  Same chains, same order as k_autocorr2.
+ * ---------------------------------------------------------------------------------------------- */
+template <int P, bool L0>
+__global__ __launch_bounds__(64) void k_autocorr_small(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    using Cfg = AcCfg<P>;
+    constexpr int K = Cfg::K, NT = Cfg::NT;
+    constexpr bool NEED_A = (P + 1 > K);            /* some trial has more than one lag group */
+    constexpr int RL = 32;                          /* delay ring length per lane (>= largest lag0 + 2K) */
+    __shared__ double dring[NEED_A ? RL : 1][64];
+    const uint32_t lane = threadIdx.x;
+    bool active = false;
+    uint32_t job = 0, t = 0, lag0 = 0, u = 1, np = P, n = 1, upl = 8;
+    {
+        const uint32_t jl = lane / Cfg::LPJ;
+        uint32_t rem = lane % Cfg::LPJ;
+        if (jl < (uint32_t)Cfg::JPW) {
+            for (; t < (uint32_t)NT; t++) { if (rem < (uint32_t)Cfg::lanes(t)) break; rem -= Cfg::lanes(t); }
+            job = blockIdx.x * Cfg::JPW + jl;
+            if (job < p.J && t < job_class(p, job).ntrials[layer]) {
+                active = true; lag0 = rem * K; u = 1u << t; np = P >> t;
+                n = job_class(p, job).na / u;
+                upl = n + (np > 4 ? np : 4);
+            }
+        }
+    }
+    if (!active) { job = 0; t = 0; }
+    const DevClass &c = job_class(p, job);
+    const double *wt = p.wtab + (active ? c.wt_off[layer][t] : 0u);
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
+    const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
+    double stale = 0.0;
+    if (active && (n & 1u)) {                       /* Q1, as in k_autocorr2 */
+        const uint32_t m = n >> 1, n2 = 2 * n, si = (u / 2 - 1) * n2 + m;
+        const double xv = L0 ? ((double)xi[si] * p.scale) : xd[si];
+        stale = xv * (c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m));
+    }
+    /* generator of the padded stream S[pos]: unit / local index tracked incrementally */
+    uint32_t g_unit = 0, g_loc = 0, g_ubase = 0;
+    auto gen_issue = [&](double &rx, double &rw, uint32_t &rloc) {      /* loads for the element at the current position */
+        const bool in_unit = active && (g_unit < u) && (g_loc < n);
+        const uint32_t si = in_unit ? (g_ubase + g_loc) : 0u;
+        rx = L0 ? ((double)xi[si] * p.scale) : xd[si];
+        rw = wt[in_unit ? g_loc : 0u];
+        rloc = in_unit ? g_loc : 0xFFFFFFFFu;
+        g_loc++;
+        if (g_loc >= upl) { g_loc = 0; g_unit++; g_ubase += n; }
+    };
+    auto gen_finish = [&](double rx, double rw, uint32_t rloc) -> double {
+        const double v = rx * rw;
+        const double vv = ((n & 1u) && rloc == (n >> 1)) ? stale : v;
+        return (rloc == 0xFFFFFFFFu) ? 0.0 : vv;
+    };
+    double r[K], w[K], fx[K], fw[K]; uint32_t fl[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) r[j] = 0.0;
+    /* positions 0 .. lag0+K-1 prime the window (and the delay ring); then prefetch the first group's new elements */
+    for (uint32_t pos = 0; pos < lag0 + K; pos++) {
+        double rx, rw; uint32_t rl;
+        gen_issue(rx, rw, rl);
+        const double v = gen_finish(rx, rw, rl);
+        if (NEED_A) dring[pos % RL][lane] = v;
+        if (pos >= lag0) {
+#pragma unroll
+            for (int j = 0; j < K; j++) if ((int)(pos - lag0) == j) w[j] = v;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) gen_issue(fx[j], fw[j], fl[j]);
+    uint32_t a_unit = 0, flush_pos = n;
+    double *out = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW;
+    const uint32_t q_end = na_max + Cfg::MAXPAD + K;
+    uint32_t slot_a = 0, slot_w = (lag0 + K) % RL;
+#pragma unroll 1
+    for (uint32_t q0 = 0; q0 < q_end; q0 += K) {
+        if (active && q0 >= flush_pos) {
+            double *o = out + (size_t)a_unit * (np + 1) + lag0;
+#pragma unroll
+            for (int j = 0; j < K; j++) { if (lag0 + j <= np) o[j] = r[j]; r[j] = 0.0; }
+            a_unit++;
+            flush_pos = (a_unit < u) ? (flush_pos + upl) : 0xFFFFFFFFu;
+        }
+        double nw[K], a[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) nw[j] = gen_finish(fx[j], fw[j], fl[j]);
+#pragma unroll
+        for (int j = 0; j < K; j++) gen_issue(fx[j], fw[j], fl[j]);      /* next group's loads fly during this group's MACs */
+        if (NEED_A) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                dring[(slot_w + j) % RL][lane] = nw[j];
+                a[j] = dring[(slot_a + j) % RL][lane];
+            }
+            slot_a = (slot_a + K) % RL; slot_w = (slot_w + K) % RL;
+        } else {
+#pragma unroll
+            for (int j = 0; j < K; j++) a[j] = w[j];
+        }
+#pragma unroll
+        for (int tt = 0; tt < K; tt++) {
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const double x2 = (tt + j < K) ? w[tt + j] : nw[tt + j - K];
+                r[j] += a[tt] * x2;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) w[j] = nw[j];
+    }
+}
+
+template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    using Cfg = AcCfg<P>;
+    const uint32_t blocks = (p.J + Cfg::JPW - 1) / Cfg::JPW;
+    if (layer == 0) hipLaunchKernelGGL((k_autocorr_small<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
+    else hipLaunchKernelGGL((k_autocorr_small<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
 }
 
 template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
@@ -466,10 +592,10 @@ template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uin
 static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     switch (p.P[layer]) {
-    case 2: launch_autocorr2<2>(st, p, layer, cur, na_max); break;
-    case 4: launch_autocorr2<4>(st, p, layer, cur, na_max); break;
-    case 8: launch_autocorr2<8>(st, p, layer, cur, na_max); break;
-    case 16: launch_autocorr2<16>(st, p, layer, cur, na_max); break;
+    case 2: launch_autocorr_small<2>(st, p, layer, cur, na_max); break;
+    case 4: launch_autocorr_small<4>(st, p, layer, cur, na_max); break;
+    case 8: launch_autocorr_small<8>(st, p, layer, cur, na_max); break;
+    case 16: launch_autocorr_small<16>(st, p, layer, cur, na_max); break;
     case 32: launch_autocorr2<32>(st, p, layer, cur, na_max); break;
     case 64: launch_autocorr2<64>(st, p, layer, cur, na_max); break;
     default: launch_autocorr2<128>(st, p, layer, cur, na_max); break;
@@ -490,6 +616,7 @@ __global__ void k_levinson(Plan p, uint32_t layer)
     }
     if (t >= c.ntrials[layer]) return;
     const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u, unit = pr;
+    if (np >= 16u) return;                                  /* orders >= 16 are solved by k_levinson_wave */
     const uint32_t P0 = p.P[0];
     const double reg = p.regs[job % p.R];
     const double *r = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
@@ -520,6 +647,71 @@ __global__ void k_levinson(Plan p, uint32_t layer)
     }
 }
 
+/* Levinson-Durbin for the large problems (order >= 16), one wavefront per (job, trial, unit).  The coefficient vector
+ * lives in LDS; the products a[i]*r[k+1-i] of a step are formed in parallel, their sum -- one chain in increasing i,
+ * lpc.c:295-297 -- is added in order by every lane redundantly (so gamma needs no broadcast), and the pairwise update
+ * a[i] <- a[i] + gamma*a[k+1-i] is element-parallel.  Same operations, same order as the scalar `levinson` above. */
+#define LEV_WAVE_MIN_ORDER 16u
+__global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
+{
+    __shared__ double sa[LNN_MAXP + 2], sr[LNN_MAXP + 2], sp[LNN_MAXP + 2];
+    const uint32_t job = blockIdx.y, lane = threadIdx.x;
+    const DevClass &c = job_class(p, job);
+    uint32_t pr = blockIdx.x, t = 0;
+    for (; t < c.ntrials[layer]; t++) {
+        if (pr < c.trial_u[layer][t]) break;
+        pr -= c.trial_u[layer][t];
+    }
+    if (t >= c.ntrials[layer]) return;
+    const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u, unit = pr, P0 = p.P[0];
+    if (np < LEV_WAVE_MIN_ORDER) return;
+    const double reg = p.regs[job % p.R];
+    const double *r = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    const bool last = (layer + 1 == p.L);
+    for (uint32_t i = lane; i <= np; i += 64) sr[i] = r[i];
+    for (uint32_t i = lane; i < np + 2; i += 64) sa[i] = 0.0;
+    __syncthreads();
+    double tail = 0.0; int tail_set = 0;
+    const double r0 = sr[0] * (1.0 + reg);
+    const bool zero = (n < np) || (fabs(r0) < (double)FLT_EPSILON);
+    if (zero) {
+        for (uint32_t k = lane; k < np; k += 64) h[k] = 0.0;
+        if (np >= P0) { tail = 0.0; tail_set = 1; }
+    } else {
+        const double r1 = sr[1];
+        double ek = r0;
+        const double a1 = -r1 / r0;
+        ek += r1 * a1;
+        if (lane == 0) { sa[0] = 1.0; sa[1] = a1; }
+        __syncthreads();
+        for (uint32_t k = 1; k < np; k++) {
+            for (uint32_t i = lane; i <= k; i += 64) sp[i] = sa[i] * sr[k + 1 - i];
+            __syncthreads();
+            double gamma = 0.0;
+            for (uint32_t i = 0; i <= k; i++) gamma += sp[i];
+            gamma /= -ek;
+            ek *= (1.0 - gamma * gamma);
+            /* pairwise in-place update from the old vector: read, barrier, write */
+            double na0 = 0.0, na1 = 0.0;
+            const uint32_t i0 = lane + 1, i1 = lane + 65;
+            if (i0 <= k) na0 = sa[i0] + gamma * sa[k + 1 - i0];
+            if (i1 <= k) na1 = sa[i1] + gamma * sa[k + 1 - i1];
+            __syncthreads();
+            if (i0 <= k) sa[i0] = na0;
+            if (i1 <= k) sa[i1] = na1;
+            if (lane == 0) { sa[0] = 1.0 + gamma * 0.0; sa[k + 1] = 0.0 + gamma * 1.0; }
+            __syncthreads();
+            if (last && k == P0) { tail = -gamma; tail_set = 1; }
+        }
+        for (uint32_t k = lane; k < np; k += 64) h[k] = sa[np - k];
+    }
+    if (last && lane == 0) {
+        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
+        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * K_C / K_D (v2): the two double-precision FIR evaluations of a layer, register-blocked.
  *   MODE 0  trial residual magnitude for every unit-count trial (linne_network.c:318-335):
@@ -539,7 +731,7 @@ template <int MODE>
 __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
-    __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP];
+    __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP + 8];   /* +8: the pipelined loop reads one step ahead */
     __shared__ __attribute__((aligned(16))) double ob[FIR_THREADS / 64][64 * FIR_SPL];   /* per-wave store transpose */
     const uint32_t job = blockIdx.y, s0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
     if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
@@ -574,11 +766,14 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
                 for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
 #pragma unroll
                 for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE != 1) ? xc[j] : 0.0;
+                /* software pipeline: the LDS reads of step k+4 are issued before the 32 MACs of step k */
+                lnn_d2 n0 = *(const lnn_d2 *)(xw + FIR_SPL), n1 = *(const lnn_d2 *)(xw + FIR_SPL + 2);
+                lnn_d2 h01 = *(const lnn_d2 *)(hb), h23 = *(const lnn_d2 *)(hb + 2);
                 for (uint32_t k = 0; k < np; k += 4) {
-                    const lnn_d2 n0 = *(const lnn_d2 *)(xw + k + FIR_SPL), n1 = *(const lnn_d2 *)(xw + k + FIR_SPL + 2);
-                    const lnn_d2 h01 = *(const lnn_d2 *)(hb + k), h23 = *(const lnn_d2 *)(hb + k + 2);
                     w[FIR_SPL] = n0.x; w[FIR_SPL + 1] = n0.y; w[FIR_SPL + 2] = n1.x; w[FIR_SPL + 3] = n1.y;
                     const double hh[4] = { h01.x, h01.y, h23.x, h23.y };
+                    n0 = *(const lnn_d2 *)(xw + k + 4 + FIR_SPL); n1 = *(const lnn_d2 *)(xw + k + 4 + FIR_SPL + 2);   /* in bounds: xs/hs are padded */
+                    h01 = *(const lnn_d2 *)(hb + k + 4); h23 = *(const lnn_d2 *)(hb + k + 6);
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
 #pragma unroll
@@ -958,7 +1153,10 @@ struct LINNEAmdContext {
     hipEvent_t *span_ev; int *span_kind; int nspans, span_cap;
     /* cached class tables */
     uint32_t *d_ucount;
-    DevClass *d_cls; double *d_sin; uint64_t sin_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
+    /* frame groups of one call rotate over these streams so that the latency-bound phases of one group (short
+     * layers, Levinson, ordered sums) overlap the throughput-bound phases of another */
+    hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub;
+    DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -1004,6 +1202,18 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     ctx->arena_bytes = scratch_bytes;
     if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
     if ((e = hipMalloc((void **)&ctx->d_ucount, sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
+    {
+        const char *env = getenv("LINNE_AMD_STREAMS");
+        int ns = env ? atoi(env) : 1;
+        if (ns < 1) ns = 1;
+        if (ns > LNN_MAXSUB) ns = LNN_MAXSUB;
+        ctx->nsub = 0;
+        for (int i = 0; i < ns; i++) {
+            if (hipStreamCreateWithFlags(&ctx->sub[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming) != hipSuccess) break;
+            ctx->nsub++;
+        }
+        if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) ctx->nsub = 0;
+    }
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
     return ctx;
@@ -1017,7 +1227,10 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->arena) hipFree(ctx->arena);
     if (ctx->d_cls) hipFree(ctx->d_cls);
     if (ctx->d_ucount) hipFree(ctx->d_ucount);
+    for (int i = 0; i < ctx->nsub; i++) { hipStreamSynchronize(ctx->sub[i]); hipStreamDestroy(ctx->sub[i]); hipEventDestroy(ctx->sub_done[i]); }
+    if (ctx->nsub) hipEventDestroy(ctx->ev_start);
     if (ctx->d_sin) hipFree(ctx->d_sin);
+    if (ctx->d_wt) hipFree(ctx->d_wt);
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
     hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
@@ -1071,7 +1284,7 @@ extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
 
 extern "C" int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable) { if (!ctx) return LNN_INVALID_ARGUMENT; ctx->timing = enable; return LNN_OK; }
 /* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
-static int span_begin(LINNEAmdContext *ctx, int kind)
+static int span_begin(LINNEAmdContext *ctx, int kind, hipStream_t st)
 {
     if (!ctx->timing) return -1;
     if (ctx->nspans == ctx->span_cap) {
@@ -1087,10 +1300,10 @@ static int span_begin(LINNEAmdContext *ctx, int kind)
     }
     const int id = ctx->nspans++;
     ctx->span_kind[id] = kind;
-    (void)hipEventRecord(ctx->span_ev[2 * id], ctx->stream);
+    (void)hipEventRecord(ctx->span_ev[2 * id], st);
     return id;
 }
-static void span_end(LINNEAmdContext *ctx, int id) { if (id >= 0) (void)hipEventRecord(ctx->span_ev[2 * id + 1], ctx->stream); }
+static void span_end(LINNEAmdContext *ctx, int id, hipStream_t st) { if (id >= 0) (void)hipEventRecord(ctx->span_ev[2 * id + 1], st); }
 
 extern "C" double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which)
 {
@@ -1152,7 +1365,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
     if (!idx || !nsm) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
     memset(cls, 0, sizeof(cls));
     ctx->na_max = 0;
-    uint64_t sin_total = 0;
+    uint64_t sin_total = 0, wt_total = 0;
     for (uint32_t f = 0; f < F; f++) {
         const uint32_t n = h_num_samples ? h_num_samples[f] : S;
         if (n == 0 || n > S) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
@@ -1178,6 +1391,8 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
                         if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
                         c.trial_u[l][nt] = u;
                         c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
+                        c.wt_off[l][nt] = (uint32_t)wt_total;
+                        { const uint32_t pu = hs->P[l] / u; wt_total += na / u + (pu > 4 ? pu : 4); }
                         nt++;
                     }
                     c.ntrials[l] = nt;
@@ -1195,18 +1410,33 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && for_encode) {
         double *tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
-        if (!tab) e = hipErrorOutOfMemory;
+        double *wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
+        if (!tab || !wt) e = hipErrorOutOfMemory;
         else {
             for (uint32_t k = 0; k < ncls; k++) {
                 const uint32_t n = cls[k].n;
                 for (uint32_t s = 0; s < n; s++) tab[cls[k].sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
+                /* Welch weights per trial over one padded unit (lpc.c:199-204): w[loc] = (div * h) * (n-1-h), h = min(loc, n-1-loc);
+                 * zero in the zero zone; the (never written) middle of an odd unit is handled on the device (Q1) */
+                for (uint32_t l = 0; l < hs->L; l++)
+                    for (uint32_t t = 0; t < cls[k].ntrials[l]; t++) {
+                        const uint32_t u = cls[k].trial_u[l][t], nu = cls[k].na / u;
+                        const double div = cls[k].trial_div[l][t];
+                        double *w = wt + cls[k].wt_off[l][t];
+                        for (uint32_t loc = 0; loc < nu; loc++) {
+                            const uint32_t h = (loc < (nu >> 1)) ? loc : (nu - 1 - loc);
+                            w[loc] = div * (double)h * (double)(nu - 1 - h);
+                        }
+                    }
             }
             ret = ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1));
+            if (ret == LNN_OK) ret = ensure_buf(ctx, (void **)&ctx->d_wt, &ctx->wt_cap, sizeof(double) * (wt_total ? wt_total : 1));
             if (ret == LNN_OK) e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
+            if (ret == LNN_OK && e == hipSuccess) e = hipMemcpyAsync(ctx->d_wt, wt, sizeof(double) * wt_total, hipMemcpyHostToDevice, ctx->stream);
             if (ret == LNN_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-            free(tab);
-            if (ret != LNN_OK) { free(idx); free(nsm); return ret; }
         }
+        free(tab); free(wt);
+        if (ret != LNN_OK) { free(idx); free(nsm); return ret; }
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     /* idx/nsm/cls are stack or freed below */
     free(nsm);
@@ -1251,24 +1481,36 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
 
     const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
     const uint64_t per_frame = frame_scratch_bytes(shape, &hs);
-    uint64_t chunk = (ctx->arena_bytes - 65536) / per_frame;
-    if (chunk == 0) {       /* grow the arena to hold at least one frame */
+    if (ctx->arena_bytes < per_frame * 4 + 65536) {       /* grow the arena to hold at least a few frames */
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(ctx->arena)); ctx->arena = NULL; ctx->arena_bytes = 0;
         HIPCHK(ctx, hipMalloc(&ctx->arena, per_frame * 4 + 65536));
         ctx->arena_bytes = per_frame * 4 + 65536;
-        chunk = 4;
     }
-    if (chunk > num_frames) chunk = num_frames;
-    {   /* grid.y / grid.z carry the job index: J = chunk * C * R must stay below 65536 */
+    /* frame groups ("chunks") rotate over nsub streams, each with its own slice of the arena */
+    uint32_t nsub = ctx->nsub > 0 ? (uint32_t)ctx->nsub : 1u;
+    while (nsub > 1 && ((ctx->arena_bytes - 65536) / nsub < per_frame * 2 || num_frames < nsub * 64u)) nsub--;
+    const uint64_t part_bytes = ((ctx->arena_bytes - 65536) / nsub) & ~(uint64_t)255;
+    uint64_t chunk = part_bytes / per_frame;
+    if (chunk == 0) chunk = 1;
+    {   /* even split over the streams; grid.y / grid.z carry the job index: J = chunk * C * R must stay below 65536 */
+        const uint64_t even = (num_frames + nsub - 1) / nsub;
+        if (chunk > even) chunk = even;
         const uint64_t lim = 65535u / ((uint64_t)C * hs.R);
         if (chunk > lim) chunk = lim;
     }
-
     ctx->nspans = 0;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount, 0, sizeof(uint32_t), ctx->stream));
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
-    for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk) {
+    const bool use_sub = ctx->nsub > 0;
+    if (use_sub) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+        for (uint32_t i = 0; i < nsub; i++) HIPCHK(ctx, hipStreamWaitEvent(ctx->sub[i], ctx->ev_start, 0));
+    }
+    uint32_t chunk_index = 0;
+    for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk, chunk_index++) {
+        const uint32_t slot = chunk_index % nsub;
+        hipStream_t st = use_sub ? ctx->sub[slot] : ctx->stream;
         const uint32_t Fc = (num_frames - f0 < chunk) ? (num_frames - f0) : (uint32_t)chunk;
         const uint64_t CF = (uint64_t)Fc * C, J = CF * hs.R;
         Plan p; memset(&p, 0, sizeof(p));
@@ -1278,8 +1520,9 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
         p.pcm = d_pcm + (size_t)f0 * C * S; p.resid = d_residual + (size_t)f0 * C * S;
         p.prm = d_params + (size_t)f0 * C * LINNE_AMD_PARAM_WORDS; p.stats = d_stats + (size_t)f0 * C * LINNE_AMD_STAT_WORDS;
-        p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.ucount = ctx->d_ucount;
-        uint8_t *a = (uint8_t *)ctx->arena;
+        p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount;
+        uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
+        uint8_t *a = abase;
 #define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
         TAKE(p.xint, int32_t, CF * S); TAKE(p.xtmp, int32_t, CF * S);
         TAKE(p.sig, double, J * 2 * S); TAKE(p.wx, double, J * LNN_MAXT * S);
@@ -1288,32 +1531,38 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TAKE(p.tloss, double, J * LNN_MAXT); TAKE(p.tsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
 #undef TAKE
-        if ((uint64_t)(a - (uint8_t *)ctx->arena) > ctx->arena_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
+        if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
         const uint32_t sblocks = (S + 255) / 256;
-        { const int sp_ = span_begin(ctx, 1); hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, ctx->stream, p); span_end(ctx, sp_); }
-        { const int sp_ = span_begin(ctx, 1); hipLaunchKernelGGL(k_load_layer0, dim3(sblocks, (uint32_t)J), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, st, p); span_end(ctx, sp_, st); }
+        { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_load_layer0, dim3(sblocks, (uint32_t)J), dim3(256), 0, st, p); span_end(ctx, sp_, st); }
         uint32_t cur = 0;
         for (uint32_t l = 0; l < hs.L; l++) {
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
             uint32_t nt = 0, nprob = 0, nchain = 0;
             for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
             {
-                const int sp_ = span_begin(ctx, 3); dispatch_autocorr2(ctx->stream, p, l, cur, ctx->na_max); span_end(ctx, sp_);
+                const int sp_ = span_begin(ctx, 3, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max); span_end(ctx, sp_, st);
             }
-            { const int sp_ = span_begin(ctx, 4); hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, ctx->stream, p, l); span_end(ctx, sp_); }
-            HIPCHK(ctx, hipMemsetAsync(p.tsum, 0, sizeof(double) * J * LNN_MAXT, ctx->stream));
-            { const int sp_ = span_begin(ctx, 5); hipLaunchKernelGGL(k_fir2<2>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 7); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l, 0u); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 4, st);
+              uint32_t nbig = 0; for (uint32_t u = 1; u <= maxu && hs.P[l] / u >= 16u; u <<= 1) nbig += u;
+              if (nbig) hipLaunchKernelGGL(k_levinson_wave, dim3(nbig, (uint32_t)J), dim3(64), 0, st, p, l);
+              hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
+            HIPCHK(ctx, hipMemsetAsync(p.tsum, 0, sizeof(double) * J * LNN_MAXT, st));
+            { const int sp_ = span_begin(ctx, 5, st); hipLaunchKernelGGL(k_fir2<2>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
-            { const int sp_ = span_begin(ctx, 6); hipLaunchKernelGGL(k_fir2<0>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur);
-              hipLaunchKernelGGL(k_chain_sum<0>, dim3(((uint32_t)J * LNN_MAXT + 63) / 64), dim3(SUM_THREADS), 0, ctx->stream, p, l, cur);
-              hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, ctx->stream, p, l, 1u); span_end(ctx, sp_); }
-            { const int sp_ = span_begin(ctx, 8); hipLaunchKernelGGL(k_fir2<1>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, ctx->stream, p, l, cur); span_end(ctx, sp_); }
+            { const int sp_ = span_begin(ctx, 6, st); hipLaunchKernelGGL(k_fir2<0>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
+              hipLaunchKernelGGL(k_chain_sum<0>, dim3(((uint32_t)J * LNN_MAXT + 63) / 64), dim3(SUM_THREADS), 0, st, p, l, cur);
+              hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 8, st); hipLaunchKernelGGL(k_fir2<1>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
-        { const int sp_ = span_begin(ctx, 9); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, ctx->stream, p, 0u, cur); span_end(ctx, sp_); }
-        { const int sp_ = span_begin(ctx, 10); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, ctx->stream, p); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
+        { const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st); }
         HIPCHK(ctx, hipGetLastError());
+    }
+    if (use_sub) {
+        for (uint32_t i = 0; i < nsub; i++) { HIPCHK(ctx, hipEventRecord(ctx->sub_done[i], ctx->sub[i])); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[i], 0)); }
     }
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
     return LNN_OK;
@@ -1342,10 +1591,10 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
         lds_samples = (lds_samples + 3u) & ~3u;
         const size_t lds_bytes = sizeof(int32_t) * ((size_t)lds_samples + 128);
         HIPCHK(ctx, hipFuncSetAttribute((const void *)k_synthesize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        { const int sp_ = span_begin(ctx, 11); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), lds_bytes, ctx->stream, p, lds_samples); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), lds_bytes, ctx->stream, p, lds_samples); span_end(ctx, sp_, ctx->stream); }
     }
     if (p.ms)
-        { const int sp_ = span_begin(ctx, 12); hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_); }
+        { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
     return LNN_OK;

@@ -10,13 +10,14 @@ ap.add_argument("--frames", type=int, default=1024)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--decode", action="store_true")
 ap.add_argument("--preset", type=int, default=7)
+ap.add_argument("--no-timing", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 track = synth_track(a.frames * 10240, 2, 16, 1, dev)
 frames, nsm = frames_from_track(track, 10240)
 ctx = linne_amd.Context(0, scratch_bytes=12 << 30)
 shape = ctx.shape(2, 16, 10240, a.preset, True)
-ctx.enable_timing(True)
+ctx.enable_timing(not a.no_timing)
 for r in range(a.reps):
     t0 = time.perf_counter()
     res, prm, st = ctx.encode_frames(shape, frames, nsm)
