@@ -123,7 +123,8 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * context's stream around each launch (only while timing is enabled).  GetLastTimingMs returns the summed
  * milliseconds of all launches of one kernel kind (negative if none was recorded), GetLastTimingLaunches their
  * count.  which: 0 whole call, 1 prep, 2 window, 3 autocorrelation, 4 levinson, 5 trial residual, 6 loss sum,
- * 7 select, 8 forward, 9 final loss, 10 finalize (quantise + FIR cascade), 11 synthesis, 12 MS->LR. */
+ * 7 select, 8 forward, 9 final loss, 10 finalize (quantise + FIR cascade), 11 synthesis, 12 MS->LR,
+ * 13 block-type statistics (runs on a side stream beside the analysis). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);

@@ -132,7 +132,6 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
 {
     __shared__ int64_t sh[PREP_THREADS];
     __shared__ int32_t sh_coef;
-    __shared__ double sh_r[LNN_MAXCH][8];
     const uint32_t f = blockIdx.x, tid = threadIdx.x;
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
@@ -207,8 +206,18 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
         /* two stages: xa -> xb -> xa, the pre-emphasised channel is back in xa */
     }
 
-    /* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW
-     * channel at order P0 = layer-0 size, one chain per (channel, lag) */
+}
+
+/* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW channel at
+ * order P0 = layer-0 size, one chain per (channel, lag), then Levinson-Durbin.  Independent of the analysis, so it runs
+ * on a side stream concurrently with it. */
+__global__ __launch_bounds__(64) void k_stats(Plan p)
+{
+    __shared__ double sh_r[LNN_MAXCH][8];
+    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const DevClass &c = p.cls[p.cls_of_frame[f]];
+    const uint32_t n = c.n, S = p.S, C = p.C;
+    const int32_t *in = p.pcm + (size_t)f * C * S;
     const uint32_t P0 = p.P[0];
     const double *sinw = p.sintab + c.sin_off;
     if (tid < C * (P0 + 1)) {
@@ -216,7 +225,20 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
         const int32_t *x = in + (size_t)ch * S;
         double r = 0.0;
         if (lag < n) {
-            for (uint32_t i = 0; i + lag < n; i++) {
+            const uint32_t cnt = n - lag;
+            uint32_t i = 0;
+            for (; i + 8 <= cnt; i += 8) {              /* loads and products of 8 steps are independent; the adds stay in order */
+                double pr[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const double a = ((double)x[i + k] * p.scale) * sinw[i + k];
+                    const double b = ((double)x[i + k + lag] * p.scale) * sinw[i + k + lag];
+                    pr[k] = a * b;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) r += pr[k];
+            }
+            for (; i < cnt; i++) {
                 const double a = ((double)x[i] * p.scale) * sinw[i];
                 const double b = ((double)x[i + lag] * p.scale) * sinw[i + lag];
                 r += a * b;
@@ -1156,6 +1178,7 @@ struct LINNEAmdContext {
     /* frame groups of one call rotate over these streams so that the latency-bound phases of one group (short
      * layers, Levinson, ordered sums) overlap the throughput-bound phases of another */
     hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub;
+    hipStream_t side; hipEvent_t side_done; int has_side;     /* block-type statistics run beside the analysis */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
 };
 
@@ -1213,6 +1236,8 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
             ctx->nsub++;
         }
         if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) ctx->nsub = 0;
+        ctx->has_side = (ctx->nsub > 0) && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess
+                && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
     }
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
@@ -1229,6 +1254,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_ucount) hipFree(ctx->d_ucount);
     for (int i = 0; i < ctx->nsub; i++) { hipStreamSynchronize(ctx->sub[i]); hipStreamDestroy(ctx->sub[i]); hipEventDestroy(ctx->sub_done[i]); }
     if (ctx->nsub) hipEventDestroy(ctx->ev_start);
+    if (ctx->has_side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); hipEventDestroy(ctx->side_done); }
     if (ctx->d_sin) hipFree(ctx->d_sin);
     if (ctx->d_wt) hipFree(ctx->d_wt);
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
@@ -1507,6 +1533,17 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         for (uint32_t i = 0; i < nsub; i++) HIPCHK(ctx, hipStreamWaitEvent(ctx->sub[i], ctx->ev_start, 0));
     }
+    {   /* statistics of every frame of the call: one launch beside the analysis */
+        Plan ps; memset(&ps, 0, sizeof(ps));
+        ps.C = C; ps.S = S; ps.bits = shape->bits_per_sample; ps.L = hs.L; ps.R = hs.R; ps.F = num_frames;
+        for (uint32_t l = 0; l < hs.L; l++) ps.P[l] = hs.P[l];
+        ps.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
+        ps.pcm = d_pcm; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
+        hipStream_t ss = ctx->stream;
+        if (ctx->has_side && use_sub) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
+        const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames), dim3(64), 0, ss, ps); span_end(ctx, sp_, ss);
+        if (ss != ctx->stream) HIPCHK(ctx, hipEventRecord(ctx->side_done, ss));
+    }
     uint32_t chunk_index = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk, chunk_index++) {
         const uint32_t slot = chunk_index % nsub;
@@ -1561,6 +1598,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         { const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st); }
         HIPCHK(ctx, hipGetLastError());
     }
+    if (ctx->has_side && use_sub) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     if (use_sub) {
         for (uint32_t i = 0; i < nsub; i++) { HIPCHK(ctx, hipEventRecord(ctx->sub_done[i], ctx->sub[i])); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[i], 0)); }
     }
