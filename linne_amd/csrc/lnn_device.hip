@@ -55,7 +55,6 @@ struct Plan {
     const uint32_t *cls_of_frame; const DevClass *cls; const double *sintab; const double *wtab;
     int32_t *xint, *xtmp;               /* [F*C][S]                    */
     double *sig;                        /* [J][2][S]                   */
-    double *wx;                         /* [J][MAXT][S] windowed signal, later |trial residual| */
     double *acorr;                      /* [J][MAXT][ACW]              */
     double *tcoef;                      /* [J][MAXT][MAXP]  filter order (reversed LPC order) */
     double *ptail; uint8_t *ptail_set;  /* [J][MAXT][MAXU]             */
@@ -755,18 +754,22 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
     __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP + 8];   /* +8: the pipelined loop reads one step ahead */
     __shared__ __attribute__((aligned(16))) double ob[FIR_THREADS / 64][64 * FIR_SPL];   /* per-wave store transpose */
-    const uint32_t job = blockIdx.y, s0 = blockIdx.x * FIR_TILE, tid = threadIdx.x;
+    __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
+    const uint32_t job = blockIdx.y, tid = threadIdx.x;
     if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
-    if (s0 >= na) return;
     const uint32_t P = p.P[layer];
     const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
+    if (MODE == 0 && tid < LNN_MAXT) chain[tid] = 0.0;
+    /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
+    for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.x * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
+    __syncthreads();
     for (uint32_t i = tid; i < LNN_MAXP + FIR_TILE + 8; i += FIR_THREADS) {
         const int64_t g = (int64_t)s0 - LNN_MAXP + i;
         xs[i] = (g >= 0 && g < (int64_t)na) ? x[g] : 0.0;
     }
-    const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
     const uint32_t s = s0 + FIR_SPL * tid;
     const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
     for (uint32_t t = 0; t < ntr; t++) {
@@ -846,10 +849,25 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
             if ((tid & 63u) == 0) atomicAdd(&p.tsum[(size_t)job * LNN_MAXT + t], ps);
+        } else if (MODE == 0) {
+            /* exact path: the tile's |residual| values go to LDS in sample order and ONE lane adds them to the trial's
+             * running sum, continuing the single chain of linne_network.c:326-337 across tiles */
+            if (s < na) {
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) ob[0][FIR_SPL * tid + j] = (s + j < na) ? acc[j] : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t cnt = (na - s0 < FIR_TILE) ? (na - s0) : FIR_TILE;
+                double v = chain[t];
+                for (uint32_t i = 0; i < cnt; i++) v += ob[0][i];
+                chain[t] = v;
+            }
+            __syncthreads();
         } else {   /* coalesced store: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive lanes write
              * consecutive 16-byte pieces (a lane's own 8 results are 64 bytes apart from its neighbour's) */
             const uint32_t wv = tid >> 6, ln = tid & 63u, wbase = s0 + wv * 64 * FIR_SPL;
-            double *dst = (MODE == 0) ? (p.wx + ((size_t)job * LNN_MAXT + t) * p.S) : (p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S);
+            double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
             if (wbase < na) {
                 if (s < na) {
 #pragma unroll
@@ -866,6 +884,11 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
                 __builtin_amdgcn_wave_barrier();
             }
         }
+    }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        if (tid < ntr) p.tloss[(size_t)job * LNN_MAXT + tid] = chain[tid] / (double)na;
     }
 }
 
@@ -894,7 +917,7 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
             const DevClass &c = job_class(p, job);
             if (MODE == 1 || ((myrow % LNN_MAXT) < c.ntrials[layer] && p.uncertain[job])) {
                 my_na = c.na;
-                my_ptr = (MODE == 0) ? (p.wx + (size_t)myrow * p.S) : (p.sig + ((size_t)job * 2 + cur) * p.S);
+                my_ptr = p.sig + ((size_t)job * 2 + cur) * p.S;
             }
         }
         row_na[lane] = my_na; row_ptr[lane] = my_ptr;
@@ -959,7 +982,7 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
          * adds sequentially; both sums are within gamma_n * S of the exact sum S, so they differ by at most
          * rel = (2 na + 8) * 2^-53 relatively.  If the smallest mean is separated from every other by more than that,
          * the reference's strict-< argmin (linne_network.c:338-341) is the same trial; otherwise the job is flagged and
-         * the ordered chains are evaluated (k_fir2<0>, k_chain_sum<0>, k_select exact). */
+         * the ordered chains are evaluated (k_fir2<0>, then k_select exact). */
         double m[LNN_MAXT];
         const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
         int ok = 1;
@@ -1480,7 +1503,6 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     uint64_t b = 0;
     b += 2 * C * S * sizeof(int32_t);
     b += J * 2 * S * sizeof(double);
-    b += J * LNN_MAXT * S * sizeof(double);
     b += J * LNN_MAXT * LNN_ACW * sizeof(double);
     b += J * LNN_MAXT * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXT * LNN_MAXU * (sizeof(double) + 1);
@@ -1562,7 +1584,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         uint8_t *a = abase;
 #define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
         TAKE(p.xint, int32_t, CF * S); TAKE(p.xtmp, int32_t, CF * S);
-        TAKE(p.sig, double, J * 2 * S); TAKE(p.wx, double, J * LNN_MAXT * S);
+        TAKE(p.sig, double, J * 2 * S);
         TAKE(p.acorr, double, J * LNN_MAXT * LNN_ACW); TAKE(p.tcoef, double, J * LNN_MAXT * LNN_MAXP);
         TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
         TAKE(p.tloss, double, J * LNN_MAXT); TAKE(p.tsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
@@ -1588,8 +1610,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             { const int sp_ = span_begin(ctx, 5, st); hipLaunchKernelGGL(k_fir2<2>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
-            { const int sp_ = span_begin(ctx, 6, st); hipLaunchKernelGGL(k_fir2<0>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
-              hipLaunchKernelGGL(k_chain_sum<0>, dim3(((uint32_t)J * LNN_MAXT + 63) / 64), dim3(SUM_THREADS), 0, st, p, l, cur);
+            { const int sp_ = span_begin(ctx, 6, st); hipLaunchKernelGGL(k_fir2<0>, dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 8, st); hipLaunchKernelGGL(k_fir2<1>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             cur ^= 1u;
