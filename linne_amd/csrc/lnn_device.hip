@@ -1117,59 +1117,79 @@ __device__ __forceinline__ int32_t wave_sum_i32(int32_t v)
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-#define SYN_LDS_MAX_SAMPLES 36864      /* 144 KiB of the CU's 160 KiB LDS */
-__global__ __launch_bounds__(64) void k_synthesize(DecPlan p, uint32_t lds_samples)
+/* One wavefront per channel-frame, data streamed through registers in 64-sample chunks (coalesced loads/stores):
+ *   - the 128-slot history ring of the recurrence lives in two registers per lane (slot = sample index mod 128);
+ *     the chunk being reconstructed IS one of them, so finished samples are already where the next steps need them
+ *     and the chunk is stored from that register;
+ *   - taps are spread over the lanes, the rotating zero-extended coefficient ring sits in 512 B of LDS, the int32
+ *     dot product is reduced with the DPP tree (wrap-around addition is associative);
+ *   - the residual of the step is picked from the loaded chunk with a scalar readlane; the next chunk's load is in
+ *     flight meanwhile.
+ * No per-channel LDS staging, so occupancy is limited by registers only. */
+__global__ __launch_bounds__(64) void k_synthesize(DecPlan p)
 {
-    extern __shared__ __attribute__((aligned(16))) int32_t lds[];   /* lds_samples words + 128 coefficient words */
-    int32_t *cpad = lds + lds_samples;
+    __shared__ int32_t cpad[128];
     const uint32_t cf = blockIdx.x, lane = threadIdx.x;
     const uint32_t n = p.nsmp[cf / p.C], S = p.S;
     const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
     int32_t *g = p.data + (size_t)cf * S;
-    const bool use_lds = (n <= lds_samples);
-    int32_t *d = use_lds ? lds : g;
-    if (use_lds) { for (uint32_t s = lane; s < n; s += 64) lds[s] = g[s]; }
-    __syncthreads();
-    /* linne_decoder.c:503-509: layers in reverse order; linne_lpc_synthesize.c:8-83: units independent */
+    /* linne_decoder.c:503-509: layers in reverse order; linne_lpc_synthesize.c:8-83: units are independent */
     for (int32_t l = (int32_t)p.L - 1; l >= 0; l--) {
         const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
-        const uint32_t np = p.P[l] / units, ns = n / units;
+        const uint32_t np = p.P[l] / (units ? units : 1u), ns = n / (units ? units : 1u);
         const uint32_t half = 1u << ((rs - 1u) & 31u);
-        if (ns < np) continue;
+        if (units == 0 || np == 0 || ns < np) continue;
         for (uint32_t unit = 0; unit < units; unit++) {
-            int32_t *x = d + (size_t)unit * ns;
-            /* zero-extended coefficient ring: tap j of the 128-window [t-128, t) */
-            __syncthreads();
+            int32_t *x = g + (size_t)unit * ns;
+            __syncthreads();                /* previous unit/layer: its stores are issued, cpad is free */
             for (uint32_t j = lane; j < 128; j += 64) cpad[j] = (j >= 128 - np) ? rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + unit * np + (j - (128 - np))] : 0;
             __syncthreads();
-            /* history ring: slot m holds x[t'] with t' = m (mod 128); preload the first np samples */
-            int32_t h0 = 0, h1 = 0;
-            if (lane < np) h0 = x[lane];
-            if (lane + 64 < np) h1 = x[lane + 64];
-            for (uint32_t t = np; t < ns; t++) {
-                const int32_t ca = cpad[(lane - t) & 127u], cb = cpad[(lane + 64u - t) & 127u];
-                const int32_t acc = (int32_t)((uint32_t)h0 * (uint32_t)ca + (uint32_t)h1 * (uint32_t)cb);
-                const uint32_t pred = half + (uint32_t)wave_sum_i32(acc);
-                const int32_t y = (int32_t)((uint32_t)x[t] - (uint32_t)((int32_t)pred >> (rs & 31u)));
-                if (lane == 0) x[t] = y;
-                const uint32_t slot = t & 127u;
-                if (lane == (slot & 63u)) { if (slot & 64u) h1 = y; else h0 = y; }
+            /* history: slot m holds x[t'] with t' = m (mod 128); the first np samples pass through unchanged */
+            int32_t h0 = (lane < np) ? x[lane] : 0, h1 = (lane + 64 < np) ? x[lane + 64] : 0;
+            const uint32_t c_first = np & ~63u;
+            int32_t vin = (c_first + lane < ns) ? x[c_first + lane] : 0;
+            for (uint32_t c0 = c_first; c0 < ns; c0 += 64) {
+                const int32_t cur = vin;
+                if (c0 + 64 < ns) vin = (c0 + 64 + lane < ns) ? x[c0 + 64 + lane] : 0;       /* prefetch the next chunk */
+                const uint32_t t_begin = (c0 > np) ? c0 : np, t_end = (c0 + 64 < ns) ? (c0 + 64) : ns;
+                const bool odd = (c0 >> 6) & 1u;
+                int32_t hr = odd ? h1 : h0;                 /* the register this chunk is reconstructed into */
+                for (uint32_t t = t_begin; t < t_end; t++) {
+                    const int32_t ca = cpad[(lane - t) & 127u], cb = cpad[(lane + 64u - t) & 127u];
+                    const int32_t ha = odd ? h0 : hr, hb = odd ? hr : h1;
+                    const int32_t acc = (int32_t)((uint32_t)ha * (uint32_t)ca + (uint32_t)hb * (uint32_t)cb);
+                    const uint32_t pred = half + (uint32_t)wave_sum_i32(acc);
+                    const int32_t res = __builtin_amdgcn_readlane(cur, (int)(t - c0));
+                    const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
+                    if (lane == (t & 63u)) hr = y;
+                }
+                if (odd) h1 = hr; else h0 = hr;
+                if (c0 + lane >= t_begin && c0 + lane < t_end) x[c0 + lane] = hr;
             }
         }
     }
     __syncthreads();
-    /* two-stage de-emphasis (linne_utility.c:215-241): stage-2 inverse then stage-1 inverse, fused */
-    if (lane == 0 && n > 0) {
-        const int32_t c0 = rec[LINNE_AMD_PRM_PCOEF + 0], c1 = rec[LINNE_AMD_PRM_PCOEF + 1];
+    /* two-stage de-emphasis (linne_utility.c:215-241): stage-2 inverse then stage-1 inverse, fused; the recurrence
+     * itself is scalar (wave-uniform), chunks of 64 samples move through a register */
+    if (n > 0) {
+        const int32_t c0e = rec[LINNE_AMD_PRM_PCOEF + 0], c1e = rec[LINNE_AMD_PRM_PCOEF + 1];
         int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
-        for (uint32_t s = 0; s < n; s++) {
-            const int32_t z = (int32_t)((uint32_t)d[s] + (uint32_t)mulshr5(zp, c1));
-            const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0));
-            d[s] = y; zp = z; yp = y;
+        int32_t vin = (lane < n) ? g[lane] : 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const int32_t cur = vin;
+            if (c0 + 64 < n) vin = (c0 + 64 + lane < n) ? g[c0 + 64 + lane] : 0;
+            const uint32_t cnt = (n - c0 < 64) ? (n - c0) : 64;
+            int32_t outv = cur;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const int32_t b = __builtin_amdgcn_readlane(cur, (int)i);
+                const int32_t z = (int32_t)((uint32_t)b + (uint32_t)mulshr5(zp, c1e));
+                const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                zp = z; yp = y;
+                if (lane == i) outv = y;
+            }
+            if (lane < cnt) g[c0 + lane] = outv;
         }
     }
-    __syncthreads();
-    if (use_lds) { for (uint32_t s = lane; s < n; s += 64) g[s] = lds[s]; }
 }
 
 /* MS -> LR (linne_utility.c:135-147) */
@@ -1645,13 +1665,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
     ctx->nspans = 0;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
-    {
-        uint32_t lds_samples = (p.S < SYN_LDS_MAX_SAMPLES) ? p.S : SYN_LDS_MAX_SAMPLES;
-        lds_samples = (lds_samples + 3u) & ~3u;
-        const size_t lds_bytes = sizeof(int32_t) * ((size_t)lds_samples + 128);
-        HIPCHK(ctx, hipFuncSetAttribute((const void *)k_synthesize, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), lds_bytes, ctx->stream, p, lds_samples); span_end(ctx, sp_, ctx->stream); }
-    }
+    { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     if (p.ms)
         { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     HIPCHK(ctx, hipGetLastError());
