@@ -265,15 +265,6 @@ __global__ __launch_bounds__(64) void k_stats(Plan p)
  * ---------------------------------------------------------------------------------------------- */
 __device__ __forceinline__ const DevClass &job_class(const Plan &p, uint32_t job) { return p.cls[p.cls_of_frame[(job / p.R) / p.C]]; }
 
-/* layer-0 input: the pre-emphasised int32 channel scaled to [-1,1) (linne_encoder.c:661-663) */
-__global__ void k_load_layer0(Plan p)
-{
-    const uint32_t job = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
-    const DevClass &c = job_class(p, job);
-    if (s >= c.na) return;
-    p.sig[((size_t)job * 2 + 0) * p.S + s] = (double)p.xint[(size_t)(job / p.R) * p.S + s] * p.scale;
-}
-
 /* ------------------------------------------------------------------------------------------------
  * K_A (v2): Welch window + autocorrelation of every unit-count trial of one layer, fused.
  *
@@ -481,37 +472,21 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
 }
 
 /* ------------------------------------------------------------------------------------------------
- * K_A for the short layers (P <= 16): every lane is an independent (job, trial, 5-lag group) and produces its own
- * padded windowed stream on the fly (one new element per step, prefetched one 5-step group ahead), so there is no
- * tile loop, no barrier and no shared staging; lanes whose lag group does not start at 0 re-read x[q] from a
- * lane-private LDS delay ring.  Same chains, same order as k_autocorr2.
+ * K_A for the short layers (P <= 16): one lane per (job, trial) owns ALL p+1 lags of the trial; a wavefront holds 64
+ * jobs of the SAME trial (grid.y = trial), so every lane issues the same number of multiply-adds.  A lane produces its
+ * own padded windowed stream on the fly -- one new element per step, loads prefetched one 4-step group ahead -- into a
+ * register window w[0..K+3]; step q adds w[q]*w[q+j] to lag j.  No LDS, no barrier.  Same chains, same order as
+ * k_autocorr2.
  * ---------------------------------------------------------------------------------------------- */
-template <int P, bool L0>
-__global__ __launch_bounds__(64) void k_autocorr_small(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+template <int K, bool L0>
+__device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uint32_t cur, uint32_t q_end, uint32_t job, uint32_t t, bool active)
 {
-    using Cfg = AcCfg<P>;
-    constexpr int K = Cfg::K, NT = Cfg::NT;
-    constexpr bool NEED_A = (P + 1 > K);            /* some trial has more than one lag group */
-    constexpr int RL = 32;                          /* delay ring length per lane (>= largest lag0 + 2K) */
-    __shared__ double dring[NEED_A ? RL : 1][64];
-    const uint32_t lane = threadIdx.x;
-    bool active = false;
-    uint32_t job = 0, t = 0, lag0 = 0, u = 1, np = P, n = 1, upl = 8;
-    {
-        const uint32_t jl = lane / Cfg::LPJ;
-        uint32_t rem = lane % Cfg::LPJ;
-        if (jl < (uint32_t)Cfg::JPW) {
-            for (; t < (uint32_t)NT; t++) { if (rem < (uint32_t)Cfg::lanes(t)) break; rem -= Cfg::lanes(t); }
-            job = blockIdx.x * Cfg::JPW + jl;
-            if (job < p.J && t < job_class(p, job).ntrials[layer]) {
-                active = true; lag0 = rem * K; u = 1u << t; np = P >> t;
-                n = job_class(p, job).na / u;
-                upl = n + (np > 4 ? np : 4);
-            }
-        }
-    }
-    if (!active) { job = 0; t = 0; }
+    constexpr int U = 4;
+    constexpr uint32_t np = K - 1;
     const DevClass &c = job_class(p, job);
+    const uint32_t u = 1u << t;
+    const uint32_t n = active ? (c.na / u) : 1u;
+    const uint32_t upl = n + (np > 4 ? np : 4);
     const double *wt = p.wtab + (active ? c.wt_off[layer][t] : 0u);
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
     const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
@@ -521,86 +496,84 @@ __global__ __launch_bounds__(64) void k_autocorr_small(Plan p, uint32_t layer, u
         const double xv = L0 ? ((double)xi[si] * p.scale) : xd[si];
         stale = xv * (c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m));
     }
-    /* generator of the padded stream S[pos]: unit / local index tracked incrementally */
-    uint32_t g_unit = 0, g_loc = 0, g_ubase = 0;
-    auto gen_issue = [&](double &rx, double &rw, uint32_t &rloc) {      /* loads for the element at the current position */
-        const bool in_unit = active && (g_unit < u) && (g_loc < n);
-        const uint32_t si = in_unit ? (g_ubase + g_loc) : 0u;
-        rx = L0 ? ((double)xi[si] * p.scale) : xd[si];
-        rw = wt[in_unit ? g_loc : 0u];
+    const bool odd = (n & 1u) != 0;
+    const uint32_t mid = n >> 1;
+    uint32_t g_loc = 0, g_ubase = 0, g_left = active ? u : 0u;     /* units still to come (incl. the current one) */
+    auto gen_issue = [&](double &rx, double &rw, uint32_t &rloc) {
+        const bool in_unit = (g_loc < n) && (g_left != 0);
+        rx = L0 ? ((double)xi[in_unit ? (g_ubase + g_loc) : 0u] * p.scale) : xd[in_unit ? (g_ubase + g_loc) : 0u];
+        rw = wt[g_loc];                              /* zero inside the zero zone (table covers the padded unit) */
         rloc = in_unit ? g_loc : 0xFFFFFFFFu;
-        g_loc++;
-        if (g_loc >= upl) { g_loc = 0; g_unit++; g_ubase += n; }
+        const bool wrap = (g_loc + 1 >= upl);
+        g_loc = wrap ? 0u : g_loc + 1;
+        g_ubase = (wrap && g_left > 1) ? g_ubase + n : g_ubase;
+        g_left = (wrap && g_left) ? g_left - 1 : g_left;
     };
     auto gen_finish = [&](double rx, double rw, uint32_t rloc) -> double {
         const double v = rx * rw;
-        const double vv = ((n & 1u) && rloc == (n >> 1)) ? stale : v;
+        const double vv = (odd && rloc == mid) ? stale : v;
         return (rloc == 0xFFFFFFFFu) ? 0.0 : vv;
     };
-    double r[K], w[K], fx[K], fw[K]; uint32_t fl[K];
+    double r[K], w[K + U], fx[U], fw[U]; uint32_t fl[U];
 #pragma unroll
-    for (int j = 0; j < K; j++) r[j] = 0.0;
-    /* positions 0 .. lag0+K-1 prime the window (and the delay ring); then prefetch the first group's new elements */
-    for (uint32_t pos = 0; pos < lag0 + K; pos++) {
+    for (int j = 0; j < K; j++) {
+        r[j] = 0.0;
         double rx, rw; uint32_t rl;
         gen_issue(rx, rw, rl);
-        const double v = gen_finish(rx, rw, rl);
-        if (NEED_A) dring[pos % RL][lane] = v;
-        if (pos >= lag0) {
-#pragma unroll
-            for (int j = 0; j < K; j++) if ((int)(pos - lag0) == j) w[j] = v;
-        }
+        w[j] = gen_finish(rx, rw, rl);
     }
 #pragma unroll
-    for (int j = 0; j < K; j++) gen_issue(fx[j], fw[j], fl[j]);
+    for (int j = 0; j < U; j++) gen_issue(fx[j], fw[j], fl[j]);
     uint32_t a_unit = 0, flush_pos = n;
     double *out = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW;
-    const uint32_t q_end = na_max + Cfg::MAXPAD + K;
-    uint32_t slot_a = 0, slot_w = (lag0 + K) % RL;
 #pragma unroll 1
-    for (uint32_t q0 = 0; q0 < q_end; q0 += K) {
-        if (active && q0 >= flush_pos) {
-            double *o = out + (size_t)a_unit * (np + 1) + lag0;
+    for (uint32_t q0 = 0; q0 < q_end; q0 += U) {
+        if (active && q0 >= flush_pos) {           /* in the zero zone after a unit: store its lags, restart */
+            double *o = out + (size_t)a_unit * K;
 #pragma unroll
-            for (int j = 0; j < K; j++) { if (lag0 + j <= np) o[j] = r[j]; r[j] = 0.0; }
+            for (int j = 0; j < K; j++) { o[j] = r[j]; r[j] = 0.0; }
             a_unit++;
             flush_pos = (a_unit < u) ? (flush_pos + upl) : 0xFFFFFFFFu;
         }
-        double nw[K], a[K];
 #pragma unroll
-        for (int j = 0; j < K; j++) nw[j] = gen_finish(fx[j], fw[j], fl[j]);
+        for (int j = 0; j < U; j++) w[K + j] = gen_finish(fx[j], fw[j], fl[j]);
 #pragma unroll
-        for (int j = 0; j < K; j++) gen_issue(fx[j], fw[j], fl[j]);      /* next group's loads fly during this group's MACs */
-        if (NEED_A) {
+        for (int j = 0; j < U; j++) gen_issue(fx[j], fw[j], fl[j]);      /* next group's loads fly during the MACs */
 #pragma unroll
-            for (int j = 0; j < K; j++) {
-                dring[(slot_w + j) % RL][lane] = nw[j];
-                a[j] = dring[(slot_a + j) % RL][lane];
-            }
-            slot_a = (slot_a + K) % RL; slot_w = (slot_w + K) % RL;
-        } else {
+        for (int tt = 0; tt < U; tt++) {
 #pragma unroll
-            for (int j = 0; j < K; j++) a[j] = w[j];
+            for (int j = 0; j < K; j++) r[j] += w[tt] * w[tt + j];
         }
 #pragma unroll
-        for (int tt = 0; tt < K; tt++) {
-#pragma unroll
-            for (int j = 0; j < K; j++) {
-                const double x2 = (tt + j < K) ? w[tt + j] : nw[tt + j - K];
-                r[j] += a[tt] * x2;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < K; j++) w[j] = nw[j];
+        for (int j = 0; j < K; j++) w[j] = w[j + U];
+    }
+}
+
+template <int P, bool L0>
+__global__ __launch_bounds__(64) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    using Cfg = AcCfg<P>;
+    uint32_t job = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t t = blockIdx.y;
+    bool active = (job < p.J);
+    if (!active) job = 0;
+    active = active && (t < job_class(p, job).ntrials[layer]);
+    const uint32_t q_end = na_max + Cfg::MAXPAD + 8;
+    switch (P >> t) {       /* wave-uniform: the trial fixes the number of lags */
+    case 16: if (P >= 16) autocorr_lane<17, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 8:  if (P >= 8)  autocorr_lane<9, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 4:  if (P >= 4)  autocorr_lane<5, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 2:  autocorr_lane<3, L0>(p, layer, cur, q_end, job, t, active); break;
+    default: autocorr_lane<2, L0>(p, layer, cur, q_end, job, t, active); break;
     }
 }
 
 template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     using Cfg = AcCfg<P>;
-    const uint32_t blocks = (p.J + Cfg::JPW - 1) / Cfg::JPW;
-    if (layer == 0) hipLaunchKernelGGL((k_autocorr_small<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
-    else hipLaunchKernelGGL((k_autocorr_small<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
+    const dim3 grid((p.J + 63) / 64, Cfg::NT);
+    if (layer == 0) hipLaunchKernelGGL((k_autocorr_lane<P, true>), grid, dim3(64), 0, st, p, layer, cur, na_max);
+    else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64), 0, st, p, layer, cur, na_max);
 }
 
 template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
@@ -748,7 +721,7 @@ __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
 typedef double lnn_d2 __attribute__((ext_vector_type(2)));
-template <int MODE>
+template <int MODE, bool L0>
 __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
@@ -761,6 +734,7 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
     const uint32_t na = c.na;
     const uint32_t P = p.P[layer];
     const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;          /* layer 0 reads the pre-emphasised int32 channel (linne_encoder.c:661-663) */
     const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
     if (MODE == 0 && tid < LNN_MAXT) chain[tid] = 0.0;
     /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
@@ -768,7 +742,7 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
     __syncthreads();
     for (uint32_t i = tid; i < LNN_MAXP + FIR_TILE + 8; i += FIR_THREADS) {
         const int64_t g = (int64_t)s0 - LNN_MAXP + i;
-        xs[i] = (g >= 0 && g < (int64_t)na) ? x[g] : 0.0;
+        xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
     }
     const uint32_t s = s0 + FIR_SPL * tid;
     const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
@@ -1613,7 +1587,6 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
         const uint32_t sblocks = (S + 255) / 256;
         { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, st, p); span_end(ctx, sp_, st); }
-        { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_load_layer0, dim3(sblocks, (uint32_t)J), dim3(256), 0, st, p); span_end(ctx, sp_, st); }
         uint32_t cur = 0;
         for (uint32_t l = 0; l < hs.L; l++) {
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
@@ -1627,12 +1600,12 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
               if (nbig) hipLaunchKernelGGL(k_levinson_wave, dim3(nbig, (uint32_t)J), dim3(64), 0, st, p, l);
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
             HIPCHK(ctx, hipMemsetAsync(p.tsum, 0, sizeof(double) * J * LNN_MAXT, st));
-            { const int sp_ = span_begin(ctx, 5, st); hipLaunchKernelGGL(k_fir2<2>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
-            { const int sp_ = span_begin(ctx, 6, st); hipLaunchKernelGGL(k_fir2<0>, dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
+            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true>), dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false>), dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, 8, st); hipLaunchKernelGGL(k_fir2<1>, dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 8, st); if (l == 0) hipLaunchKernelGGL((k_fir2<1, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<1, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
         { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
