@@ -59,7 +59,8 @@ struct Plan {
     double *tcoef;                      /* [J][MAXT][MAXP]  filter order (reversed LPC order) */
     double *ptail; uint8_t *ptail_set;  /* [J][MAXT][MAXU]             */
     double *tloss;                      /* [J][MAXT] exact mean |residual| (ordered chain)            */
-    double *tsum;                       /* [J][MAXT] order-free sum of |residual| (certified search)  */
+    double *tsum;                       /* [J][MAXT][npart] per-wave partial sums of |residual| (certified search) */
+    uint32_t npart;                     /* partial sums per (job, trial): tiles x waves per block      */
     uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
     uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
     double *lparams;                    /* [J][MAXL][MAXP]             */
@@ -282,7 +283,7 @@ template <int P> struct AcCfg {
     static constexpr int T = (P >= 32) ? 60 : 20;                       /* tile: padded positions per LDS refill */
     static constexpr int lanes(int t) { return ((P >> t) + 1 + K - 1) / K; }
     static constexpr int halo(int t) { return K * lanes(t) + K; }       /* furthest window read past a group start, +1 */
-    static constexpr int rb(int t) { return T + halo(t); }              /* ring length (multiple of 5) */
+    static constexpr int rb(int t) { return ((T + halo(t) + 2 * K - 1) / (2 * K)) * (2 * K); }   /* ring length, multiple of 2K */
     static constexpr int lpj() { int s = 0; for (int t = 0; t < NT; t++) s += lanes(t); return s; }
     static constexpr int ringsum() { int s = 0; for (int t = 0; t < NT; t++) s += rb(t); return s; }
     static constexpr int maxpad() { int m = 0; for (int t = 0; t < NT; t++) { const int p = P >> t, z = p > 4 ? p : 4, v = (1 << t) * z; if (v > m) m = v; } return m; }
@@ -430,30 +431,39 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
             }
         }
         if (active) {
-#pragma unroll 1
-            for (uint32_t q0 = tile0; q0 < tile0 + T; q0 += K) {
-                if (q0 >= flush_pos) {                  /* inside the zero zone after a unit: store and restart */
+            /* two 5-step groups per trip: the window registers swap roles (w -> nw -> w), so nothing is moved; the ring
+             * length is a multiple of 10, so q0's slot wraps at most once per trip */
+            auto flush = [&](uint32_t q) {
+                if (q >= flush_pos) {                   /* inside the zero zone after a unit: store and restart */
                     double *o = out + (size_t)a_unit * (a_p + 1) + a_lag0;
 #pragma unroll
                     for (int j = 0; j < K; j++) { if (a_lag0 + j <= a_p) o[j] = r[j]; r[j] = 0.0; }
                     a_unit++;
                     flush_pos = (a_unit < a_u) ? (flush_pos + a_upl) : 0xFFFFFFFFu;
                 }
+            };
+#pragma unroll 1
+            for (uint32_t q0 = tile0; q0 < tile0 + T; q0 += 2 * K) {
                 double a[K], nw[K];
+                flush(q0);
 #pragma unroll
                 for (int j = 0; j < K; j++) { a[j] = myring[pa + j]; nw[j] = myring[pw + j]; }
-                pa += K; if (pa >= a_rb) pa -= a_rb;
-                pw += K; if (pw >= a_rb) pw -= a_rb;
+                int32_t pw2 = pw + K; if (pw2 >= a_rb) pw2 -= a_rb;
 #pragma unroll
                 for (int t = 0; t < K; t++) {
 #pragma unroll
-                    for (int j = 0; j < K; j++) {
-                        const double x2 = (t + j < K) ? w[t + j] : nw[t + j - K];
-                        r[j] += a[t] * x2;
-                    }
+                    for (int j = 0; j < K; j++) r[j] += a[t] * ((t + j < K) ? w[t + j] : nw[t + j - K]);
                 }
+                flush(q0 + K);
 #pragma unroll
-                for (int j = 0; j < K; j++) w[j] = nw[j];
+                for (int j = 0; j < K; j++) { a[j] = myring[pa + K + j]; w[j] = myring[pw2 + j]; }
+                pa += 2 * K; if (pa >= a_rb) pa -= a_rb;
+                pw = pw2 + K; if (pw >= a_rb) pw -= a_rb;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) r[j] += a[t] * ((t + j < K) ? nw[t + j] : w[t + j - K]);
+                }
             }
         }
         __syncthreads();
@@ -725,7 +735,7 @@ template <int MODE, bool L0>
 __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
-    __shared__ __attribute__((aligned(16))) double hs[2][LNN_MAXP + 8];   /* +8: the pipelined loop reads one step ahead */
+    __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
     __shared__ __attribute__((aligned(16))) double ob[FIR_THREADS / 64][64 * FIR_SPL];   /* per-wave store transpose */
     __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
     const uint32_t job = blockIdx.y, tid = threadIdx.x;
@@ -737,22 +747,29 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;          /* layer 0 reads the pre-emphasised int32 channel (linne_encoder.c:661-663) */
     const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
     if (MODE == 0 && tid < LNN_MAXT) chain[tid] = 0.0;
+    {
+        const double *hsrc = (MODE != 1) ? (p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
+        for (uint32_t i = tid; i < ntr * LNN_MAXP; i += FIR_THREADS) { const uint32_t tt = i / LNN_MAXP, k = i % LNN_MAXP; if (k < P) hs[tt][k] = hsrc[i]; }
+    }
     /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
     for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.x * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
     __syncthreads();
-    for (uint32_t i = tid; i < LNN_MAXP + FIR_TILE + 8; i += FIR_THREADS) {
-        const int64_t g = (int64_t)s0 - LNN_MAXP + i;
-        xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
+    if (!L0 && s0 >= LNN_MAXP && s0 + FIR_TILE + 8 <= na) {          /* interior tile: 16-byte loads (S, s0, MAXP are even) */
+        for (uint32_t i = 2 * tid; i < LNN_MAXP + FIR_TILE + 8; i += 2 * FIR_THREADS)
+            *(lnn_d2 *)(xs + i) = *(const lnn_d2 *)(x + (s0 - LNN_MAXP + i));
+    } else {
+        for (uint32_t i = tid; i < LNN_MAXP + FIR_TILE + 8; i += FIR_THREADS) {
+            const int64_t g = (int64_t)s0 - LNN_MAXP + i;
+            xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
+        }
     }
     const uint32_t s = s0 + FIR_SPL * tid;
     const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
     for (uint32_t t = 0; t < ntr; t++) {
         const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
         const uint32_t n = na / u, np = P / u;
-        const double *hsrc = (MODE != 1) ? (p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
-        double *hbuf = hs[t & 1u];
-        if (tid < P) hbuf[tid] = hsrc[tid];
-        __syncthreads();                                             /* also covers the xs fill on the first trip */
+        const double *hbuf = hs[t];
+        if (t == 0) __syncthreads();                                 /* tile and coefficients are staged */
         double acc[FIR_SPL];
         if (s < na) {
             /* all FIR_SPL samples in one unit, every tap present */
@@ -822,7 +839,7 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
-            if ((tid & 63u) == 0) atomicAdd(&p.tsum[(size_t)job * LNN_MAXT + t], ps);
+            if ((tid & 63u) == 0) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.x * (FIR_THREADS / 64) + (tid >> 6)] = ps;
         } else if (MODE == 0) {
             /* exact path: the tile's |residual| values go to LDS in sample order and ONE lane adds them to the trial's
              * running sum, continuing the single chain of linne_network.c:326-337 across tiles */
@@ -961,7 +978,11 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
         const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
         int ok = 1;
         for (uint32_t t = 0; t < nt; t++) {
-            m[t] = p.tsum[(size_t)job * LNN_MAXT + t] / (double)c.na;
+            double sm = 0.0;
+            const uint32_t np_used = ((c.na + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64);
+            const double *ps = p.tsum + ((size_t)job * LNN_MAXT + t) * p.npart;
+            for (uint32_t i = 0; i < np_used; i++) sm += ps[i];
+            m[t] = sm / (double)c.na;
             if (!(m[t] >= 0.0) || !(m[t] < (double)FLT_MAX)) ok = 0;
             if (m[t] < min_loss) { min_loss = m[t]; best = t; }
         }
@@ -1500,7 +1521,7 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     b += J * LNN_MAXT * LNN_ACW * sizeof(double);
     b += J * LNN_MAXT * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXT * LNN_MAXU * (sizeof(double) + 1);
-    b += J * LNN_MAXT * sizeof(double) * 2 + J;
+    b += J * LNN_MAXT * sizeof(double) * (1 + (uint64_t)((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64)) + J;
     b += J * LNN_MAXL * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXL * sizeof(uint32_t);
     b += J * 2 * sizeof(double);
@@ -1581,7 +1602,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TAKE(p.sig, double, J * 2 * S);
         TAKE(p.acorr, double, J * LNN_MAXT * LNN_ACW); TAKE(p.tcoef, double, J * LNN_MAXT * LNN_MAXP);
         TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
-        TAKE(p.tloss, double, J * LNN_MAXT); TAKE(p.tsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
+        TAKE(p.tloss, double, J * LNN_MAXT); p.npart = ((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64); TAKE(p.tsum, double, J * LNN_MAXT * p.npart); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
 #undef TAKE
         if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
@@ -1599,7 +1620,6 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
               uint32_t nbig = 0; for (uint32_t u = 1; u <= maxu && hs.P[l] / u >= 16u; u <<= 1) nbig += u;
               if (nbig) hipLaunchKernelGGL(k_levinson_wave, dim3(nbig, (uint32_t)J), dim3(64), 0, st, p, l);
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
-            HIPCHK(ctx, hipMemsetAsync(p.tsum, 0, sizeof(double) * J * LNN_MAXT, st));
             { const int sp_ = span_begin(ctx, 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
