@@ -33,6 +33,7 @@
 #define LNN_MAXCH       8
 #define LNN_ACW         256     /* autocorrelation words per (job, trial): P + u <= 256 */
 #define LNN_MAXSUB      8
+typedef double lnn_d2 __attribute__((ext_vector_type(2)));
 
 /* one distinct frame length of a batch (full frames, the ragged tail, ...) */
 struct DevClass {
@@ -658,7 +659,7 @@ __global__ void k_levinson(Plan p, uint32_t layer)
 #define LEV_WAVE_MIN_ORDER 16u
 __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
 {
-    __shared__ double sa[LNN_MAXP + 2], sr[LNN_MAXP + 2], sp[LNN_MAXP + 2];
+    __shared__ __attribute__((aligned(16))) double sa[LNN_MAXP + 2], sr[LNN_MAXP + 2], sp[LNN_MAXP + 4];
     const uint32_t job = blockIdx.y, lane = threadIdx.x;
     const DevClass &c = job_class(p, job);
     uint32_t pr = blockIdx.x, t = 0;
@@ -693,7 +694,14 @@ __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
             for (uint32_t i = lane; i <= k; i += 64) sp[i] = sa[i] * sr[k + 1 - i];
             __syncthreads();
             double gamma = 0.0;
-            for (uint32_t i = 0; i <= k; i++) gamma += sp[i];
+            {   /* ordered sum, 16-byte LDS reads */
+                uint32_t i = 0;
+                for (; i + 4 <= k + 1; i += 4) {
+                    const lnn_d2 v0 = *(const lnn_d2 *)(sp + i), v1 = *(const lnn_d2 *)(sp + i + 2);
+                    gamma += v0.x; gamma += v0.y; gamma += v1.x; gamma += v1.y;
+                }
+                for (; i <= k; i++) gamma += sp[i];
+            }
             gamma /= -ek;
             ek *= (1.0 - gamma * gamma);
             /* pairwise in-place update from the old vector: read, barrier, write */
@@ -730,13 +738,12 @@ __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
 #define FIR_THREADS 256
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
-typedef double lnn_d2 __attribute__((ext_vector_type(2)));
 template <int MODE, bool L0>
 __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
     __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
-    __shared__ __attribute__((aligned(16))) double ob[FIR_THREADS / 64][64 * FIR_SPL];   /* per-wave store transpose */
+    __shared__ __attribute__((aligned(16))) double ob[(MODE == 2) ? 1 : FIR_THREADS / 64][(MODE == 2) ? 2 : 64 * FIR_SPL];   /* per-wave store transpose (MODE 0/1) */
     __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
     const uint32_t job = blockIdx.y, tid = threadIdx.x;
     if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
@@ -1064,26 +1071,39 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
         for (uint32_t k = 0; k < P; k++) rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + k] = s_coef[l][k];
     }
     __syncthreads();
-    /* FIR cascade (linne_encoder.c:687-696, linne_lpc_predict.c:7-38) on the n valid samples */
+    /* FIR cascade (linne_encoder.c:687-696, linne_lpc_predict.c:7-38) on the n valid samples; each layer streams the
+     * channel through an LDS tile (1024 samples + 128 of history) so the tap loop reads LDS, not global memory */
+    __shared__ int32_t xt[LNN_MAXP + 4 * FIN_THREADS];
     int32_t *src = p.xint + (size_t)cf * S, *dst = p.xtmp + (size_t)cf * S;
     for (uint32_t l = 0; l < p.L; l++) {
         const uint32_t units = s_units[l], np = p.P[l] / units, ns = n / units, rs = s_rshift[l];
         const uint32_t half = 1u << ((rs - 1u) & 31u);
         int32_t *out = (l + 1 == p.L) ? (p.resid + (size_t)cf * S) : dst;
-        for (uint32_t s = tid; s < n; s += FIN_THREADS) {
-            int32_t v = src[s];
-            const uint32_t unit = s / (ns ? ns : 1u);
-            if (ns >= np && unit < units) {
-                const uint32_t loc = s - unit * ns;
-                if (loc >= np) {
-                    uint32_t pred = half;
-                    const int32_t *cc = s_coef[l] + unit * np;
-                    const int32_t *xx = src + (size_t)unit * ns + loc - np;
-                    for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
-                    v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
-                }
+        for (uint32_t s0 = 0; s0 < n; s0 += 4 * FIN_THREADS) {
+            __syncthreads();
+            for (uint32_t i = tid; i < LNN_MAXP + 4 * FIN_THREADS; i += FIN_THREADS) {
+                const int64_t g = (int64_t)s0 - LNN_MAXP + i;
+                xt[i] = (g >= 0 && g < (int64_t)n) ? src[g] : 0;
             }
-            out[s] = v;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < 4; j++) {
+                const uint32_t e = tid + j * FIN_THREADS, s = s0 + e;
+                if (s >= n) continue;
+                int32_t v = xt[LNN_MAXP + e];
+                const uint32_t unit = s / (ns ? ns : 1u);
+                if (ns >= np && unit < units) {
+                    const uint32_t loc = s - unit * ns;
+                    if (loc >= np) {
+                        uint32_t pred = half;
+                        const int32_t *cc = s_coef[l] + unit * np;
+                        const int32_t *xx = xt + LNN_MAXP + e - np;
+                        for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
+                        v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
+                    }
+                }
+                out[s] = v;
+            }
         }
         if (l + 1 == p.L) for (uint32_t s = n + tid; s < S; s += FIN_THREADS) out[s] = 0;
         __syncthreads();
