@@ -112,101 +112,108 @@ __device__ void levinson(const double *r, double r0, uint32_t order, double *a, 
  * K1: per frame -- copy, MS, two pre-emphasis stages, block-type statistics
  * ---------------------------------------------------------------------------------------------- */
 #define PREP_THREADS 256
+/* block-wide integer reductions: shuffle tree inside each wavefront, then one LDS hop (exact: integer add / max) */
 __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sh)
 {
     const uint32_t t = threadIdx.x;
-    sh[t] = v; __syncthreads();
-    for (uint32_t s = PREP_THREADS / 2; s > 0; s >>= 1) { if (t < s) sh[t] += sh[t + s]; __syncthreads(); }
-    const int64_t r = sh[0]; __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();                        /* sh may still be read from a previous reduction */
+    if ((t & 63u) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    int64_t r = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < PREP_THREADS / 64; w++) r += sh[w];
     return r;
 }
 __device__ __forceinline__ int64_t block_max_i64(int64_t v, int64_t *sh)
 {
     const uint32_t t = threadIdx.x;
-    sh[t] = v; __syncthreads();
-    for (uint32_t s = PREP_THREADS / 2; s > 0; s >>= 1) { if (t < s) sh[t] = (sh[t] > sh[t + s]) ? sh[t] : sh[t + s]; __syncthreads(); }
-    const int64_t r = sh[0]; __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int64_t x = __shfl_xor(v, o); v = x > v ? x : v; }
+    __syncthreads();
+    if ((t & 63u) == 0) sh[t >> 6] = v;
+    __syncthreads();
+    int64_t r = sh[0];
+#pragma unroll
+    for (uint32_t w = 1; w < PREP_THREADS / 64; w++) r = sh[w] > r ? sh[w] : r;
     return r;
 }
 
 __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
 {
-    __shared__ int64_t sh[PREP_THREADS];
+    __shared__ int64_t sh[PREP_THREADS / 64];
     __shared__ int32_t sh_coef;
-    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;     /* one block per (frame, channel) */
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
     const int32_t *in = p.pcm + (size_t)f * C * S;
-    int32_t *xa = p.xint + (size_t)f * C * S;
-    int32_t *xb = p.xtmp + (size_t)f * C * S;
+    int32_t *src = p.xint + ((size_t)f * C + ch) * S, *dst = p.xtmp + ((size_t)f * C + ch) * S;
+    int32_t *rec = p.prm + ((size_t)f * C + ch) * LINNE_AMD_PARAM_WORDS;
 
-    /* copy with zero padding (linne_encoder.c:613-621) and LR -> MS on channels 0/1 (linne_utility.c:120-132) */
+    /* copy with zero padding (linne_encoder.c:613-621); LR -> MS on channels 0/1 (linne_utility.c:120-132): each of
+     * the two blocks derives its own channel from L and R */
     for (uint32_t s = tid; s < S; s += PREP_THREADS) {
-        for (uint32_t ch = 0; ch < C; ch++) xa[(size_t)ch * S + s] = (s < n) ? in[(size_t)ch * S + s] : 0;
-        if (p.ms && s < n) {
-            const uint32_t l = (uint32_t)in[s], r = (uint32_t)in[(size_t)S + s];
-            const int32_t side = (int32_t)(r - l);
-            xa[(size_t)S + s] = side;
-            xa[s] = (int32_t)(l + (uint32_t)(side >> 1));
+        int32_t v = 0;
+        if (s < n) {
+            v = in[(size_t)ch * S + s];
+            if (p.ms && ch < 2) {
+                const uint32_t l = (uint32_t)in[s], r = (uint32_t)in[(size_t)S + s];
+                const int32_t side = (int32_t)(r - l);
+                v = (ch == 1) ? side : (int32_t)(l + (uint32_t)(side >> 1));
+            }
         }
+        src[s] = v;
     }
     __syncthreads();
 
-    /* two pre-emphasis stages per channel (linne_encoder.c:634-641) */
-    for (uint32_t ch = 0; ch < C; ch++) {
-        int32_t *src = xa + (size_t)ch * S, *dst = xb + (size_t)ch * S;
-        int32_t *rec = p.prm + ((size_t)f * C + ch) * LINNE_AMD_PARAM_WORDS;
-        for (uint32_t stage = 0; stage < 2; stage++) {
-            /* coefficient: linne_utility.c:158-193.  corr0 = sum x[s]^2, corr1 = sum x[s]x[s+1], s < n-1, are
-             * double chains in the reference; when max|x|^2 * n < 2^53 every partial sum is an exactly
-             * representable integer, so any summation order gives the reference's bits (integer path);
-             * otherwise one thread runs the chains in order. */
-            int64_t mx = 0;
-            for (uint32_t s = tid; s < n; s += PREP_THREADS) { const int64_t v = src[s]; const int64_t av = v < 0 ? -v : v; mx = av > mx ? av : mx; }
-            mx = block_max_i64(mx, sh);
-            const bool exact = ((double)mx * (double)mx * (double)n) < 9.0e15;
-            double c0, c1;
-            if (exact) {
-                int64_t s0 = 0, s1 = 0;
-                for (uint32_t s = tid; s + 1 < n; s += PREP_THREADS) { const int64_t a = src[s], b = src[s + 1]; s0 += a * a; s1 += a * b; }
-                s0 = block_sum_i64(s0, sh);
-                s1 = block_sum_i64(s1, sh);
-                c0 = (double)s0; c1 = (double)s1;
-            } else {
-                c0 = 0.0; c1 = 0.0;
-                if (tid == 0) {
-                    double curr = (double)src[0];
-                    for (uint32_t s = 0; s + 1 < n; s++) {
-                        const double succ = (double)src[s + 1];
-                        c0 += curr * curr;
-                        c1 += curr * succ;
-                        curr = succ;
-                    }
-                }
-            }
-            if (tid == 0) {
-                int32_t coef;
-                c1 /= c0;
-                if ((c0 < 1e-6) || (c1 < 0.0)) coef = 0;
-                else { coef = (int32_t)round_away(c1 * 32.0); if (coef >= 16) coef = 15; }
-                sh_coef = coef;
-                rec[LINNE_AMD_PRM_PREV + stage] = src[0];
-                rec[LINNE_AMD_PRM_PCOEF + stage] = coef;
-            }
-            __syncthreads();
-            const int32_t coef = sh_coef;
-            /* linne_utility.c:196-212 with prev := first sample */
-            for (uint32_t s = tid; s < S; s += PREP_THREADS) {
-                int32_t v = src[s];
-                if (s < n) { const int32_t prev = src[s ? s - 1 : 0]; v = (int32_t)((uint32_t)v - (uint32_t)mulshr5(prev, coef)); }
-                dst[s] = v;
-            }
-            __syncthreads();
-            int32_t *t = src; src = dst; dst = t;
+    /* two pre-emphasis stages (linne_encoder.c:634-641) */
+    for (uint32_t stage = 0; stage < 2; stage++) {
+        /* coefficient: linne_utility.c:158-193.  corr0 = sum x[s]^2, corr1 = sum x[s]x[s+1], s < n-1, are double chains
+         * in the reference; when max|x|^2 * n < 2^53 every partial sum is an exactly representable integer, so any
+         * summation order gives the reference's bits (integer path); otherwise one thread runs the chains in order. */
+        int64_t mx = 0; uint64_t s0 = 0, s1 = 0;
+        for (uint32_t s = tid; s < n; s += PREP_THREADS) {
+            const int64_t a = src[s]; const int64_t av = a < 0 ? -a : a;
+            mx = av > mx ? av : mx;
+            if (s + 1 < n) { const int64_t b = src[s + 1]; s0 += (uint64_t)(a * a); s1 += (uint64_t)(a * b); }
         }
-        /* two stages: xa -> xb -> xa, the pre-emphasised channel is back in xa */
+        mx = block_max_i64(mx, sh);
+        const bool exact = ((double)mx * (double)mx * (double)n) < 9.0e15;
+        double c0 = 0.0, c1 = 0.0;
+        if (exact) {
+            c0 = (double)block_sum_i64((int64_t)s0, sh);
+            c1 = (double)block_sum_i64((int64_t)s1, sh);
+        } else if (tid == 0) {
+            double curr = (double)src[0];
+            for (uint32_t s = 0; s + 1 < n; s++) {
+                const double succ = (double)src[s + 1];
+                c0 += curr * curr;
+                c1 += curr * succ;
+                curr = succ;
+            }
+        }
+        if (tid == 0) {
+            int32_t coef;
+            c1 /= c0;
+            if ((c0 < 1e-6) || (c1 < 0.0)) coef = 0;
+            else { coef = (int32_t)round_away(c1 * 32.0); if (coef >= 16) coef = 15; }
+            sh_coef = coef;
+            rec[LINNE_AMD_PRM_PREV + stage] = src[0];
+            rec[LINNE_AMD_PRM_PCOEF + stage] = coef;
+        }
+        __syncthreads();
+        const int32_t coef = sh_coef;
+        /* linne_utility.c:196-212 with prev := first sample */
+        for (uint32_t s = tid; s < S; s += PREP_THREADS) {
+            int32_t v = src[s];
+            if (s < n) { const int32_t prev = src[s ? s - 1 : 0]; v = (int32_t)((uint32_t)v - (uint32_t)mulshr5(prev, coef)); }
+            dst[s] = v;
+        }
+        __syncthreads();
+        int32_t *t = src; src = dst; dst = t;
     }
-
+    /* two stages: xint -> xtmp -> xint, the pre-emphasised channel is back in xint */
 }
 
 /* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW channel at
@@ -1627,7 +1634,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
 #undef TAKE
         if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
         const uint32_t sblocks = (S + 255) / 256;
-        { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_prep, dim3(Fc), dim3(PREP_THREADS), 0, st, p); span_end(ctx, sp_, st); }
+        { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_prep, dim3(Fc, C), dim3(PREP_THREADS), 0, st, p); span_end(ctx, sp_, st); }
         uint32_t cur = 0;
         for (uint32_t l = 0; l < hs.L; l++) {
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
