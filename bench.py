@@ -33,9 +33,10 @@ MAC_PER_CF_REFERENCE = 46.2e6       # as written in the reference (-m 7, N = 102
 MAC_PER_CF_EXECUTED = 30.7e6        # bit-exact de-duplicated schedule this build runs
 HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it
-ENCODE_KINDS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 13)
-KERNEL_KINDS = {13: "k_stats", 1: "k_prep", 2: "k_window", 3: "k_autocorr", 4: "k_levinson", 5: "k_trial_residual", 6: "k_loss_sum",
-                7: "k_select", 8: "k_forward", 9: "k_final_loss", 10: "k_finalize", 11: "k_synthesize", 12: "k_ms_to_lr"}
+ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16)
+KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson(+_wave)", 5: "k_fir2<2,false>",
+                15: "k_fir2<2,true>", 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false>", 16: "k_fir2<1,true>",
+                9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synthesize", 12: "k_ms_to_lr"}
 
 
 def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):
@@ -151,11 +152,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    ndev = torch.cuda.device_count()
+    local = local % ndev                    # (rehearsals on a one-GPU box put several ranks on the same device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    backend = os.environ.get("BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only for one-GPU rehearsals
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     nch, bits, block, rate, ms = 2, 16, 10240, 44100, True
     ns_total = int(round(args.minutes * 60 * rate))
@@ -220,10 +228,10 @@ def main():
     ctx.enable_timing(False)
 
     if world > 1:
-        tt = torch.tensor([enc_s, dec_s], dtype=torch.float64, device=dev)
+        tt = torch.tensor([enc_s, dec_s], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         enc_s, dec_s = float(tt[0]), float(tt[1])
-        okt = torch.tensor([1 if ok else 0], device=dev)
+        okt = torch.tensor([1 if ok else 0], device=red_dev)
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
@@ -232,14 +240,17 @@ def main():
         enc_fps = total_frames / enc_s
         dec_fps = total_frames / dec_s
         # dominant encode kernel: roofline against HBM with ALGORITHMIC bytes (DESIGN.md "Measurement")
-        dom = max(range(1, 11), key=lambda k: kern_ms[k])      # k_stats (13) runs beside the analysis, never dominant
+        dom = max([k for k in ENCODE_KINDS if k != 13], key=lambda k: kern_ms[k])      # k_stats (13) runs beside the analysis
         launches = max(1, kern_launches[dom])
         avg_ms = kern_ms[dom] / launches
         # one launch of a per-layer kernel serves one chunk of frames for one layer; price it on the channel-frames
         # of its chunk: all steps together processed F*nch*steps channel-frames in launches/(layers) chunk-launches
         nlayers = len(linne_amd.PRESET_LAYERS[args.preset])
-        per_layer = dom in (2, 3, 4, 5, 6, 7, 8)
-        chunk_launches = launches / (nlayers if per_layer else 1)
+        layers = linne_amd.PRESET_LAYERS[args.preset]
+        n_big = sum(1 for P in layers if P >= 32)
+        # timed spans of one kind per frame group: per-layer kernels have one span per layer they serve
+        launches_per_chunk = {3: n_big, 14: nlayers - n_big, 4: nlayers, 5: nlayers - 1, 15: 1, 6: nlayers, 7: nlayers, 8: nlayers - 1, 16: 1}.get(dom, 1)
+        chunk_launches = launches / launches_per_chunk
         cf_per_launch = F * nch * args.steps / chunk_launches
         # a per-layer kernel of one layer carries that layer's share; report the whole-kernel view: bytes of the
         # channel-frames one launch processes / its duration
@@ -248,7 +259,8 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(KERNEL_KINDS[dom], {}).get("hbm_bytes_per_launch")
+                per_cf = json.load(open(pmc)).get(KERNEL_KINDS[dom], {}).get("hbm_bytes_per_channel_frame_per_launch")
+                traffic = per_cf * cf_per_launch if per_cf else None
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

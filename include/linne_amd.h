@@ -124,7 +124,9 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * milliseconds of all launches of one kernel kind (negative if none was recorded), GetLastTimingLaunches their
  * count.  which: 0 whole call, 1 prep, 2 window, 3 autocorrelation, 4 levinson, 5 trial residual, 6 loss sum,
  * 7 select, 8 forward, 9 final loss, 10 finalize (quantise + FIR cascade), 11 synthesis, 12 MS->LR,
- * 13 block-type statistics (runs on a side stream beside the analysis). */
+ * 13 block-type statistics (runs on a side stream beside the analysis), 14 autocorrelation of the short layers
+ * (kind 3 is the long layer's kernel), 15 / 16 trial residual / forward of layer 0 (int32 input; kinds 5 / 8 are the
+ * double-input instantiations used by the other layers). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);

@@ -1641,18 +1641,18 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             uint32_t nt = 0, nprob = 0, nchain = 0;
             for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
             {
-                const int sp_ = span_begin(ctx, 3, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max); span_end(ctx, sp_, st);
+                const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max); span_end(ctx, sp_, st);
             }
             { const int sp_ = span_begin(ctx, 4, st);
               uint32_t nbig = 0; for (uint32_t u = 1; u <= maxu && hs.P[l] / u >= 16u; u <<= 1) nbig += u;
               if (nbig) hipLaunchKernelGGL(k_levinson_wave, dim3(nbig, (uint32_t)J), dim3(64), 0, st, p, l);
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true>), dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false>), dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, 8, st); if (l == 0) hipLaunchKernelGGL((k_fir2<1, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<1, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : 8, st); if (l == 0) hipLaunchKernelGGL((k_fir2<1, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<1, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
         { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
