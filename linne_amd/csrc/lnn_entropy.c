@@ -40,16 +40,20 @@ uint16_t lnn_crc16(const uint8_t *data, uint64_t size)
 }
 
 /* ------------------------------------------------------------------------------------------------ bits */
+/* writer: bits collect in a 64-bit accumulator and leave four bytes at a time; bw_flush pads to a byte and drains */
 struct bitw { uint8_t *p, *base, *end; uint64_t acc; uint32_t n; int overflow; };
 static void bw_open(struct bitw *w, uint8_t *mem, uint64_t size) { w->p = w->base = mem; w->end = mem + size; w->acc = 0; w->n = 0; w->overflow = 0; }
+static inline void bw_byte(struct bitw *w, uint8_t b) { if (w->p < w->end) *w->p++ = b; else w->overflow = 1; }
 static inline void bw_put(struct bitw *w, uint32_t val, uint32_t nbits)
-{   /* nbits <= 32; at most 7 bits pending */
+{   /* nbits <= 32; fewer than 32 bits pending */
     if (nbits == 0) return;
     w->acc = (w->acc << nbits) | (uint64_t)(val & (uint32_t)(0xFFFFFFFFu >> (32u - nbits)));
     w->n += nbits;
-    while (w->n >= 8) {
-        w->n -= 8;
-        if (w->p < w->end) *w->p++ = (uint8_t)(w->acc >> w->n); else w->overflow = 1;
+    if (w->n >= 32) {
+        const uint32_t word = (uint32_t)(w->acc >> (w->n - 32));
+        w->n -= 32;
+        if (w->end - w->p >= 4) { const uint32_t be = __builtin_bswap32(word); memcpy(w->p, &be, 4); w->p += 4; }
+        else { bw_byte(w, (uint8_t)(word >> 24)); bw_byte(w, (uint8_t)(word >> 16)); bw_byte(w, (uint8_t)(word >> 8)); bw_byte(w, (uint8_t)word); }
     }
 }
 static inline void bw_zero_run_then_one(struct bitw *w, uint32_t run)   /* `run` zeros, then a 1 */
@@ -57,40 +61,51 @@ static inline void bw_zero_run_then_one(struct bitw *w, uint32_t run)   /* `run`
     while (run >= 32) { bw_put(w, 0, 32); run -= 32; }
     bw_put(w, 1, run + 1 > 32 ? 32 : run + 1);
 }
-static void bw_flush(struct bitw *w) { if (w->n) bw_put(w, 0, 8 - w->n); }
-static uint64_t bw_bytes(const struct bitw *w) { return (uint64_t)(w->p - w->base); }
+static void bw_flush(struct bitw *w)
+{
+    if (w->n & 7u) bw_put(w, 0, 8 - (w->n & 7u));
+    while (w->n >= 8) { w->n -= 8; bw_byte(w, (uint8_t)(w->acc >> w->n)); }
+}
+static uint64_t bw_bytes(const struct bitw *w) { return (uint64_t)(w->p - w->base); }     /* after bw_flush */
 
-struct bitr { const uint8_t *base; uint64_t nbits, pos; };
-static void br_open(struct bitr *r, const uint8_t *mem, uint64_t size) { r->base = mem; r->nbits = size * 8u; r->pos = 0; }
-static inline uint32_t br_peek32(const struct bitr *r)
-{   /* next 32 bits, zero beyond the end */
-    const uint64_t byte = r->pos >> 3;
-    const uint32_t sh = (uint32_t)(r->pos & 7u);
-    uint64_t v = 0;
-    uint32_t i;
-    const uint64_t nbytes = (r->nbits >> 3);
-    for (i = 0; i < 5; i++) v = (v << 8) | ((byte + i < nbytes) ? r->base[byte + i] : 0u);
-    return (uint32_t)((v << sh) >> 8);
+/* reader: a 64-bit window whose top `have` bits are the next bits of the stream; bytes are pulled in on demand and zeros
+ * are supplied past the end (a corrupt or truncated stream decodes to garbage, never out of bounds) */
+struct bitr { const uint8_t *p, *end, *base; uint64_t win; uint32_t have; uint64_t consumed; uint64_t nbits; };
+static void br_open(struct bitr *r, const uint8_t *mem, uint64_t size) { r->p = r->base = mem; r->end = mem + size; r->win = 0; r->have = 0; r->consumed = 0; r->nbits = size * 8u; }
+static inline void br_refill(struct bitr *r)
+{
+    while (r->have <= 56) {
+        const uint64_t byte = (r->p < r->end) ? *r->p : 0u;
+        r->p++;
+        r->win |= byte << (56 - r->have);
+        r->have += 8;
+    }
 }
 static inline uint32_t br_get(struct bitr *r, uint32_t nbits)
 {
     uint32_t v;
     if (nbits == 0) return 0;
-    v = br_peek32(r) >> (32u - nbits);
-    r->pos += nbits;
+    if (r->have < nbits) br_refill(r);
+    v = (uint32_t)(r->win >> (64 - nbits));
+    r->win <<= nbits; r->have -= nbits; r->consumed += nbits;
     return v;
 }
 static inline uint32_t br_zero_run(struct bitr *r)
 {
     uint32_t run = 0;
     for (;;) {
-        const uint32_t w = br_peek32(r);
-        if (w) { const uint32_t z = (uint32_t)__builtin_clz(w); r->pos += z + 1; return run + z; }
-        if (r->pos >= r->nbits) return run;              /* ran off the data: corrupt stream */
-        run += 32; r->pos += 32;
+        if (r->have < 32) br_refill(r);
+        if (r->win >> 32) {
+            const uint32_t z = (uint32_t)__builtin_clzll(r->win);
+            r->win <<= (z + 1); r->have -= (z + 1); r->consumed += z + 1;
+            return run + z;
+        }
+        if (r->consumed >= r->nbits) return run;             /* ran off the data: corrupt stream */
+        r->win <<= 32; r->have -= 32; r->consumed += 32; run += 32;
     }
 }
-static uint64_t br_bytes(const struct bitr *r) { return (r->pos + 7u) >> 3; }
+static uint64_t br_bytes(const struct bitr *r) { return (r->consumed + 7u) >> 3; }
+#define br_pos_over(r) ((r)->consumed > (r)->nbits)
 
 /* ------------------------------------------------------------------------------------------------ Huffman */
 static struct { uint32_t root; uint16_t child[512][2]; uint32_t code[256]; uint8_t len[256]; } g_huff;
@@ -129,7 +144,8 @@ static inline uint32_t huff_get(struct bitr *r)
 }
 
 static pthread_once_t g_once = PTHREAD_ONCE_INIT;
-static void tables_init(void) { crc_init(); huff_init(); }
+static void rice_k2_init(void);
+static void tables_init(void) { crc_init(); huff_init(); rice_k2_init(); }
 void lnn_tables_init(void) { pthread_once(&g_once, tables_init); }
 
 /* ------------------------------------------------------------------------------------------------ Rice */
@@ -148,9 +164,48 @@ static inline uint32_t rice_k2(double mean)
     const double t = floor((log(log(optx) / log(1.0 - rho))) * 1.4426950408889634);
     return (uint32_t)((0 > t) ? 0 : t);
 }
+/* rice_k2 is a non-decreasing step function of the mean.  Its steps are located once with the same libm expression
+ * (bisection on the double's bit pattern); afterwards the parameter is a table search, and the libm expression is used
+ * again only within a guard band around a step, so the result is the expression's own value everywhere. */
+static double g_k2_step[33]; static uint32_t g_k2_steps = 0;
+static void rice_k2_init(void)
+{
+    uint32_t k;
+    const double top = 8.0e9;                                   /* beyond any mean of zig-zagged 32-bit values */
+    const uint32_t kmax = rice_k2(top);
+    for (k = 1; k <= kmax && k <= 32; k++) {
+        double lo = 0.0, hi = top;                              /* rice_k2(lo) < k <= rice_k2(hi) */
+        int it;
+        for (it = 0; it < 200; it++) {
+            const double mid = lo + (hi - lo) * 0.5;
+            if (mid <= lo || mid >= hi) break;
+            if (rice_k2(mid) >= k) hi = mid; else lo = mid;
+        }
+        g_k2_step[k - 1] = hi;
+    }
+    g_k2_steps = (kmax < 32) ? kmax : 32;
+}
+static inline uint32_t rice_k2_fast(double mean)
+{
+    uint32_t k = 0;
+    while (k < g_k2_steps && mean >= g_k2_step[k]) k++;
+    if (!(mean >= 0.0)) return rice_k2(mean);
+    if (k < g_k2_steps && mean >= g_k2_step[k] * (1.0 - 1e-9)) return rice_k2(mean);      /* just below the next step */
+    if (k > 0 && mean <= g_k2_step[k - 1] * (1.0 + 1e-9)) return rice_k2(mean);            /* just above the last one  */
+    return k;
+}
+/* sum over a partition of the second-stage excess ((v - 2^k1) >> k2 for v >= 2^k1): the only data-dependent part of a
+ * partition's code length (every sample costs k2 + 2 bits before it) */
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static uint32_t rice_excess(const uint32_t *q, uint32_t ns, uint32_t k1pow, uint32_t k2)
+{
+    uint32_t s, b = 0;
+    for (s = 0; s < ns; s++) { const uint32_t v = q[s]; const uint32_t t = (v > k1pow) ? (v - k1pow) : 0u; b += t >> k2; }
+    return b;
+}
 static inline uint32_t gamma_len(uint32_t u) { return u ? (2u * ceil_log2(u + 2u) - 1u) : 1u; }
 
-struct rice_scratch { double mean[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint32_t *u; uint32_t ucap; };
+struct rice_scratch { double mean[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint8_t k2[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint32_t *u; uint32_t ucap; };
 
 static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct rice_scratch *sc)
 {
@@ -166,10 +221,10 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
     {
         const uint32_t ns = n / parts;
         for (part = 0; part < parts; part++) {
-            double sum = 0.0;
+            uint64_t sum = 0;                  /* n < 2^16 values below 2^32: the double sum of the reference is this integer */
             const uint32_t *q = u + (size_t)part * ns;
             for (s = 0; s < ns; s++) sum += q[s];
-            sc->mean[max_order][part] = sum / ns;
+            sc->mean[max_order][part] = (double)sum / ns;
         }
     }
     for (i = (int32_t)max_order - 1; i >= 0; i--)
@@ -179,11 +234,10 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
         const uint32_t ns = n >> order;
         uint32_t prevk2 = 0, bits = 0;
         for (part = 0; part < (1u << order); part++) {
-            const uint32_t k2 = rice_k2(sc->mean[order][part]), k1 = k2 + 1, k1pow = 1u << k1;
+            const uint32_t k2 = rice_k2_fast(sc->mean[order][part]), k1 = k2 + 1, k1pow = 1u << k1;
             const uint32_t *q = u + (size_t)part * ns;
-            uint32_t b = 0;
-            for (s = 0; s < ns; s++) { const uint32_t v = q[s]; b += (v < k1pow) ? (k1 + 1) : (k2 + 2 + ((v - k1pow) >> k2)); }
-            bits += b;
+            sc->k2[order][part] = (uint8_t)k2;
+            bits += ns * (k2 + 2) + rice_excess(q, ns, k1pow, k2);      /* (v < 2^k1) ? k1+1 : k2+2+((v-2^k1)>>k2), k1 = k2+1 */
             bits += part ? gamma_len(zz((int32_t)k2 - (int32_t)prevk2)) : 5u;
             prevk2 = k2;
         }
@@ -194,7 +248,7 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
         uint32_t prevk2 = 0;
         bw_put(w, best, RICE_LOG2_PARTS);
         for (part = 0; part < (1u << best); part++) {
-            const uint32_t k2 = rice_k2(sc->mean[best][part]), k1 = k2 + 1, k1pow = 1u << k1, k2mask = (1u << k2) - 1u;
+            const uint32_t k2 = sc->k2[best][part], k1 = k2 + 1, k1pow = 1u << k1, k2mask = (1u << k2) - 1u;
             const uint32_t *q = u + (size_t)part * ns;
             if (part == 0) bw_put(w, k2, 5);
             else {
@@ -218,7 +272,7 @@ static void rice_decode(struct bitr *r, int32_t *data, uint32_t n)
     const uint32_t order = br_get(r, RICE_LOG2_PARTS), ns = n >> order;
     uint32_t part, s, k2 = 0;
     for (part = 0; part < (1u << order); part++) {
-        if (r->pos > r->nbits) return;
+        if (br_pos_over(r)) return;
         if (part == 0) k2 = br_get(r, 5);
         else {
             const uint32_t nd = br_zero_run(r) + 1;
