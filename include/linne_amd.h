@@ -112,6 +112,26 @@ int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmd
 int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         int32_t *data, const uint32_t *num_samples, uint32_t num_frames, const int32_t *params);
 
+/* Staging slots: what a whole-stream caller (LINNEEncoder_EncodeWhole / LINNEDecoder_DecodeWhole,
+ * linne_encoder.c:865-932, linne_decoder.c:671-742) uses instead of the synchronous host forms.  A slot owns pinned
+ * host buffers and device buffers for up to max_frames frames of one shape.  The caller fills SlotPcm (encode) or
+ * SlotData + SlotParams (decode), submits, and later waits; Submit only enqueues (H2D on a copy stream, the kernels on
+ * the context stream, D2H on a second copy stream, chained by events), so rotating over two or three slots overlaps
+ * the host entropy stage, PCIe and the kernels.  After SlotWait: encode -> SlotData = residual, SlotParams, SlotStats;
+ * decode -> SlotData = PCM.  A slot must be destroyed before its context. */
+struct LINNEAmdSlot;
+struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        uint32_t max_frames, int for_encode);
+void      LINNEAmd_SlotDestroy(struct LINNEAmdSlot *slot);
+int32_t  *LINNEAmd_SlotPcm(struct LINNEAmdSlot *slot);       /* [F][C][S] int32, encode input (NULL for a decode slot) */
+int32_t  *LINNEAmd_SlotData(struct LINNEAmdSlot *slot);      /* [F][C][S] int32, residual (encode out, decode in) / PCM (decode out) */
+int32_t  *LINNEAmd_SlotParams(struct LINNEAmdSlot *slot);    /* [F][C][LINNE_AMD_PARAM_WORDS] */
+double   *LINNEAmd_SlotStats(struct LINNEAmdSlot *slot);     /* [F][C][LINNE_AMD_STAT_WORDS] (NULL for a decode slot) */
+uint32_t  LINNEAmd_SlotCapacity(const struct LINNEAmdSlot *slot);
+int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
+int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
+int LINNEAmd_SlotWait(struct LINNEAmdSlot *slot);
+
 /* Number of (job, layer) unit-count searches of the last EncodeFramesDevice call that the certified order-free
  * search could not decide and that therefore ran the exact ordered sums (synchronises; -1 on error). */
 int64_t LINNEAmd_GetLastFallbackCount(struct LINNEAmdContext *ctx);

@@ -39,6 +39,8 @@ AMD_SYMBOLS = [
     "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
+    "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
+    "LINNEAmd_SlotCapacity", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
 ]
 
 

@@ -7,6 +7,8 @@
  * EncodeBlock / EncodeWhole / DecodeBlock / DecodeWhole of COMPRESS data return LINNE_APIRESULT_NG and say
  * so on stderr.
  */
+#define _GNU_SOURCE
+#include <sched.h>
 #include "linne_encoder.h"
 #include "linne_decoder.h"
 #include "lnn_host.h"
@@ -18,17 +20,61 @@
 #include <unistd.h>
 
 #define LNN_ALIGN 16u
+#define LNN_SLOTS 3u                    /* groups of frames in flight in EncodeWhole / DecodeWhole */
 #define ALIGN_UP(v) (((v) + (LNN_ALIGN - 1u)) & ~(uintptr_t)(LNN_ALIGN - 1u))
 
 extern int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t bytes);
 
+/* host threads of the entropy stage: LINNE_AMD_THREADS, else the CPUs this process may actually use (affinity mask,
+ * capped by the cgroup v2 CPU quota: a container often sees every core of the machine but owns a few) */
 static uint32_t default_threads(void)
 {
     const char *e = getenv("LINNE_AMD_THREADS");
-    long n = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN);
+    long n;
+    if (e) n = atol(e);
+    else {
+        cpu_set_t set;
+        FILE *fp;
+        n = sysconf(_SC_NPROCESSORS_ONLN);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < n) n = CPU_COUNT(&set);
+        if ((fp = fopen("/sys/fs/cgroup/cpu.max", "r")) != NULL) {
+            long long quota = 0, period = 0;
+            if (fscanf(fp, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0) {
+                const long q = (long)((quota + period - 1) / period);
+                if (q < n) n = q;
+            }
+            fclose(fp);
+        }
+    }
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return (uint32_t)n;
+}
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+static int trace_on(void) { static int v = -1; if (v < 0) { const char *e = getenv("LINNE_AMD_TRACE"); v = (e && atoi(e)) ? 1 : 0; } return v; }
+static uint32_t default_group(void)     /* frames per staging slot */
+{
+    const char *e = getenv("LINNE_AMD_GROUP");
+    long n = e ? atol(e) : 256;
+    if (n < 1) n = 1;
+    if (n > 4096) n = 4096;
+    return (uint32_t)n;
+}
+static void drop_slots(struct LINNEAmdSlot **slot)
+{
+    uint32_t i;
+    for (i = 0; i < LNN_SLOTS; i++) { if (slot[i]) LINNEAmd_SlotDestroy(slot[i]); slot[i] = NULL; }
+}
+/* (re)creates the staging slots of a handle for `frames` frames per slot; keeps what already fits */
+static int want_slots(struct LINNEAmdContext *ctx, struct LINNEAmdSlot **slot, struct LINNEAmdShape *have_shape, uint32_t *have_frames,
+        const struct LINNEAmdShape *shape, uint32_t frames, uint32_t count, int for_encode)
+{
+    uint32_t i;
+    if (memcmp(have_shape, shape, sizeof(*shape)) != 0 || *have_frames < frames) { drop_slots(slot); *have_shape = *shape; *have_frames = frames; }
+    for (i = 0; i < count && i < LNN_SLOTS; i++)
+        if (!slot[i] && !(slot[i] = LINNEAmd_SlotCreate(ctx, shape, *have_frames, for_encode))) return LNN_NG;
+    return LNN_OK;
 }
 static int default_device(void)
 {
@@ -70,6 +116,8 @@ struct LINNEEncoder {
     double parcor_state;                /* oracle quirk Q2, carried from block to block */
     int32_t *pcm, *residual, *params;   /* one-frame staging, inside the work area */
     double *stats;
+    struct LINNEAmdSlot *slot[LNN_SLOTS];   /* whole-stream staging (pinned + device), created at the first EncodeWhole */
+    struct LINNEAmdShape slot_shape; uint32_t slot_frames;
 };
 
 LINNEApiResult LINNEEncoder_EncodeHeader(const struct LINNEHeader *header, uint8_t *data, uint32_t data_size)
@@ -144,6 +192,7 @@ struct LINNEEncoder *LINNEEncoder_Create(const struct LINNEEncoderConfig *config
 void LINNEEncoder_Destroy(struct LINNEEncoder *encoder)
 {
     if (encoder == NULL) return;
+    drop_slots(encoder->slot);
     if (encoder->ctx) { LINNEAmd_ContextDestroy(encoder->ctx); encoder->ctx = NULL; }
     if (encoder->alloced_by_own == 1) free(encoder->work);
 }
@@ -214,51 +263,91 @@ LINNEApiResult LINNEEncoder_EncodeBlock(struct LINNEEncoder *encoder, const int3
     return (LINNEApiResult)ret;
 }
 
+/* whole stream (linne_encoder.c:865-932): groups of frames rotate over LNN_SLOTS staging slots -- while the GPU analyses
+ * one group, the host threads pack the previous one into the stream and fill the next */
+struct fill_job { const int32_t *const *input; int32_t *pcm; uint32_t *nsm; uint32_t C, S, num_samples, base; };
+static void fill_frames(void *arg, uint32_t first, uint32_t count)
+{
+    const struct fill_job *j = arg;
+    uint32_t f, ch;
+    for (f = first; f < first + count; f++) {
+        const uint64_t start = (uint64_t)(j->base + f) * j->S;
+        const uint32_t n = (j->num_samples - start < j->S) ? (uint32_t)(j->num_samples - start) : j->S;
+        j->nsm[f] = n;
+        for (ch = 0; ch < j->C; ch++) {
+            int32_t *dst = j->pcm + ((size_t)f * j->C + ch) * j->S;
+            memcpy(dst, j->input[ch] + start, sizeof(int32_t) * n);
+            if (n < j->S) memset(dst + n, 0, sizeof(int32_t) * (j->S - n));
+        }
+    }
+}
+
 LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
         uint8_t *data, uint32_t data_size, uint32_t *output_size)
 {
     LINNEApiResult r;
-    uint32_t S, C, F, f, ch, base;
-    uint64_t off = LINNE_HEADER_SIZE, CS;
-    int32_t *pcm = NULL, *res = NULL, *prm = NULL; double *st = NULL; uint32_t *nsm = NULL, *sizes = NULL;
-    const uint32_t group = 2048;                    /* frames analysed per device batch */
+    uint32_t S, C, F, f, ch, group, ngroups, nslots, submitted = 0, packed = 0;
+    uint64_t off = LINNE_HEADER_SIZE;
+    uint32_t *nsm = NULL, *sizes = NULL;
+    const uint32_t threads = default_threads();
+    double t_begin = 0, t_setup = 0, t_fill = 0, t_submit = 0, t_wait = 0, t_pack = 0, t0;
     int ret = LNN_OK;
     if (encoder == NULL || input == NULL || data == NULL || output_size == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if (encoder->set_parameter != 1) return LINNE_APIRESULT_PARAMETER_NOT_SET;
     encoder->header.num_samples = num_samples;
     if ((r = LINNEEncoder_EncodeHeader(&encoder->header, data, data_size)) != LINNE_APIRESULT_OK) return r;
+    S = encoder->shape.num_samples_per_block; C = encoder->shape.num_channels;
+    for (ch = 0; ch < C; ch++) if (input[ch] == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if (encoder_device(encoder) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
-    S = encoder->shape.num_samples_per_block; C = encoder->shape.num_channels; CS = (uint64_t)C * S;
+    t_begin = now_s();
     F = (uint32_t)(((uint64_t)num_samples + S - 1) / S);
-    {
-        const uint32_t g = (F < group) ? F : group;
-        pcm = malloc(sizeof(int32_t) * CS * g); res = malloc(sizeof(int32_t) * CS * g);
-        prm = malloc(sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (size_t)C * g); st = malloc(sizeof(double) * LINNE_AMD_STAT_WORDS * (size_t)C * g);
-        nsm = malloc(sizeof(uint32_t) * g); sizes = malloc(sizeof(uint32_t) * g);
-        if (!pcm || !res || !prm || !st || !nsm || !sizes) { ret = LNN_NG; goto done; }
-        if (g > 32) (void)LINNEAmd_ReserveScratch(encoder->ctx, 4ull << 30);
+    group = default_group(); if (group > F) group = F;
+    ngroups = (F + group - 1) / group;
+    nslots = (ngroups < LNN_SLOTS) ? ngroups : LNN_SLOTS;
+    if (F > 32) (void)LINNEAmd_ReserveScratch(encoder->ctx, 2ull << 30);
+    if (want_slots(encoder->ctx, encoder->slot, &encoder->slot_shape, &encoder->slot_frames, &encoder->shape, group, nslots, 1) != LNN_OK) {
+        report(encoder->ctx, "SlotCreate", LNN_NG); return LINNE_APIRESULT_NG;
     }
-    for (base = 0; base < F; base += group) {
-        const uint32_t cnt = (F - base < group) ? (F - base) : group;
-        for (f = 0; f < cnt; f++) {
-            const uint64_t start = (uint64_t)(base + f) * S;
-            const uint32_t n = (num_samples - start < S) ? (uint32_t)(num_samples - start) : S;
-            nsm[f] = n;
-            for (ch = 0; ch < C; ch++) {
-                int32_t *dst = pcm + f * CS + (size_t)ch * S;
-                memcpy(dst, input[ch] + start, sizeof(int32_t) * n);
-                if (n < S) memset(dst + n, 0, sizeof(int32_t) * (S - n));
-            }
+    nsm = malloc(sizeof(uint32_t) * (size_t)group * LNN_SLOTS); sizes = malloc(sizeof(uint32_t) * group);
+    if (!nsm || !sizes) { ret = LNN_NG; goto done; }
+    t_setup = now_s() - t_begin;
+    while (packed < ngroups) {
+        while (submitted < ngroups && submitted - packed < nslots) {
+            struct LINNEAmdSlot *sl = encoder->slot[submitted % nslots];
+            struct fill_job fj;
+            const uint32_t base = submitted * group, cnt = (F - base < group) ? (F - base) : group;
+            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.nsm = nsm + (size_t)(submitted % nslots) * group;
+            fj.C = C; fj.S = S; fj.num_samples = num_samples; fj.base = base;
+            t0 = now_s();
+            lnn_parallel_for(cnt, threads, fill_frames, &fj);
+            t_fill += now_s() - t0; t0 = now_s();
+            ret = LINNEAmd_SlotEncodeSubmit(sl, fj.nsm, cnt);
+            t_submit += now_s() - t0;
+            if (ret != LNN_OK) { report(encoder->ctx, "SlotEncodeSubmit", ret); goto done; }
+            submitted++;
         }
-        ret = LINNEAmd_EncodeFramesHost(encoder->ctx, &encoder->shape, pcm, nsm, cnt, res, prm, st);
-        if (ret != LNN_OK) { report(encoder->ctx, "EncodeFramesHost", ret); goto done; }
-        ret = LINNEAmd_PackFrames(&encoder->shape, pcm, nsm, cnt, res, prm, st, data + off, data_size - off, sizes, &encoder->parcor_state, default_threads());
-        if (ret != LNN_OK) goto done;
-        for (f = 0; f < cnt; f++) off += sizes[f];
+        {
+            struct LINNEAmdSlot *sl = encoder->slot[packed % nslots];
+            const uint32_t base = packed * group, cnt = (F - base < group) ? (F - base) : group;
+            t0 = now_s();
+            ret = LINNEAmd_SlotWait(sl);
+            t_wait += now_s() - t0; t0 = now_s();
+            if (ret != LNN_OK) { report(encoder->ctx, "SlotWait", ret); goto done; }
+            ret = LINNEAmd_PackFrames(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % nslots) * group, cnt,
+                    LINNEAmd_SlotData(sl), LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), data + off, data_size - off, sizes,
+                    &encoder->parcor_state, threads);
+            t_pack += now_s() - t0;
+            if (ret != LNN_OK) goto done;
+            for (f = 0; f < cnt; f++) off += sizes[f];
+            packed++;
+        }
     }
     *output_size = (uint32_t)off;
+    if (trace_on()) fprintf(stderr, "liblinne_amd: EncodeWhole %u frames, %u threads: setup %.1f ms, fill %.1f, submit %.1f, wait %.1f, pack %.1f, total %.1f ms\n",
+            F, threads, t_setup * 1e3, t_fill * 1e3, t_submit * 1e3, t_wait * 1e3, t_pack * 1e3, (now_s() - t_begin) * 1e3);
 done:
-    free(pcm); free(res); free(prm); free(st); free(nsm); free(sizes);
+    for (f = 0; f < LNN_SLOTS; f++) if (encoder->slot[f]) (void)LINNEAmd_SlotWait(encoder->slot[f]);
+    free(nsm); free(sizes);
     return (LINNEApiResult)ret;
 }
 
@@ -273,6 +362,8 @@ struct LINNEDecoder {
     struct LINNEAmdContext *ctx;
     int32_t *samples; uint64_t samples_cap;     /* one-frame staging (heap: the block size is unknown at Create) */
     int32_t *params;                            /* inside the work area */
+    struct LINNEAmdSlot *slot[LNN_SLOTS];       /* whole-stream staging, created at the first DecodeWhole */
+    struct LINNEAmdShape slot_shape; uint32_t slot_frames;
 };
 
 LINNEApiResult LINNEDecoder_DecodeHeader(const uint8_t *data, uint32_t data_size, struct LINNEHeader *header)
@@ -333,6 +424,7 @@ struct LINNEDecoder *LINNEDecoder_Create(const struct LINNEDecoderConfig *config
 void LINNEDecoder_Destroy(struct LINNEDecoder *decoder)
 {
     if (decoder == NULL) return;
+    drop_slots(decoder->slot);
     if (decoder->ctx) { LINNEAmd_ContextDestroy(decoder->ctx); decoder->ctx = NULL; }
     free(decoder->samples); decoder->samples = NULL;
     if (decoder->alloced_by_own) free(decoder->work);
@@ -396,21 +488,62 @@ LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint
     return LINNE_APIRESULT_OK;
 }
 
-/* ---- whole stream: scan block boundaries, entropy-decode blocks on a thread pool, synthesise on the GPU ---- */
-struct unpack_job {
-    const struct LINNEDecoder *dec; const uint8_t *data; const uint64_t *offs; const uint64_t *avail; const uint32_t *room;
-    int32_t *samples, *params; uint32_t *types, *ns; int *rets; uint32_t first, count;
+/* ---- whole stream (linne_decoder.c:671-742): scan block boundaries from the size fields, entropy-decode a group of
+ * blocks on the host threads straight into a staging slot, synthesise it on the GPU while the next group is being
+ * entropy-decoded, then scatter the PCM into the caller's planes ---- */
+struct dgroup {
+    uint32_t nblk, ncomp;
+    uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn; int *rets;
 };
-static void *unpack_worker(void *arg)
+struct unpack_job {
+    const struct LINNEDecoder *dec; const uint8_t *data; struct dgroup *g; int32_t *sdata, *sprm; int32_t **buffer;
+};
+static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
 {
     struct unpack_job *j = arg;
+    struct dgroup *g = j->g;
     const struct LINNEAmdShape *sh = &j->dec->shape;
-    const uint64_t CS = (uint64_t)sh->num_channels * sh->num_samples_per_block;
-    uint32_t f, consumed;
-    for (f = j->first; f < j->first + j->count; f++)
-        j->rets[f] = lnn_parse_block(sh, &j->dec->layers, j->data + j->offs[f], j->avail[f], j->dec->check_crc, j->room[f],
-                &j->types[f], &j->ns[f], &consumed, j->samples + f * CS, j->params + (size_t)f * sh->num_channels * LINNE_AMD_PARAM_WORDS);
-    return NULL;
+    const uint32_t C = sh->num_channels, S = sh->num_samples_per_block;
+    const uint64_t CS = (uint64_t)C * S;
+    int32_t *tmp = NULL, tprm[LINNE_MAX_NUM_CHANNELS * LINNE_AMD_PARAM_WORDS];
+    uint32_t f, ch, consumed;
+    for (f = first; f < first + count; f++) {
+        if (g->cidx[f] != 0xFFFFFFFFu) {            /* COMPRESS by its header: residual and parameters go to the slot */
+            g->rets[f] = lnn_parse_block(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
+                    &g->types[f], &g->ns[f], &consumed, j->sdata + g->cidx[f] * CS, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS);
+            continue;
+        }
+        if (!tmp && !(tmp = malloc(sizeof(int32_t) * CS))) { g->rets[f] = LNN_NG; continue; }
+        g->rets[f] = lnn_parse_block(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
+                &g->types[f], &g->ns[f], &consumed, tmp, tprm);
+        if (g->rets[f] == LNN_OK)                   /* RAW / SILENT carry PCM: straight to the caller's planes */
+            for (ch = 0; ch < C; ch++) memcpy(j->buffer[ch] + g->prog[f], tmp + (size_t)ch * S, sizeof(int32_t) * g->ns[f]);
+    }
+    free(tmp);
+}
+static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
+{
+    struct unpack_job *j = arg;
+    struct dgroup *g = j->g;
+    const uint32_t C = j->dec->shape.num_channels, S = j->dec->shape.num_samples_per_block;
+    uint32_t f, ch;
+    for (f = first; f < first + count; f++) {
+        if (g->types[f] != LNN_BLOCK_COMPRESS) continue;
+        for (ch = 0; ch < C; ch++)
+            memcpy(j->buffer[ch] + g->prog[f], j->sdata + ((size_t)g->cidx[f] * C + ch) * S, sizeof(int32_t) * g->ns[f]);
+    }
+}
+static int dgroup_alloc(struct dgroup *g, uint32_t n)
+{
+    memset(g, 0, sizeof(*g));
+    g->offs = malloc(sizeof(*g->offs) * n); g->avail = malloc(sizeof(*g->avail) * n); g->room = malloc(sizeof(uint32_t) * n);
+    g->types = malloc(sizeof(uint32_t) * n); g->ns = malloc(sizeof(uint32_t) * n); g->prog = malloc(sizeof(uint32_t) * n);
+    g->cidx = malloc(sizeof(uint32_t) * n); g->cn = malloc(sizeof(uint32_t) * n); g->rets = malloc(sizeof(int) * n);
+    return (g->offs && g->avail && g->room && g->types && g->ns && g->prog && g->cidx && g->cn && g->rets) ? 0 : -1;
+}
+static void dgroup_free(struct dgroup *g)
+{
+    free(g->offs); free(g->avail); free(g->room); free(g->types); free(g->ns); free(g->prog); free(g->cidx); free(g->cn); free(g->rets);
 }
 
 LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint8_t *data, uint32_t data_size,
@@ -419,70 +552,96 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     LINNEApiResult r;
     struct LINNEHeader h;
     const struct LINNEHeader *hd;
-    uint32_t C, S, group = 2048, nblk = 0, f, ch, progress = 0, t;
-    uint64_t off, CS;
-    uint64_t *offs = NULL, *avail = NULL; uint32_t *room = NULL, *types = NULL, *ns = NULL, *cn = NULL; int *rets = NULL;
-    int32_t *samples = NULL, *params = NULL, *cbuf = NULL, *cprm = NULL;
-    int ret = LNN_OK;
+    struct dgroup grp[LNN_SLOTS];
+    struct unpack_job uj;
+    uint32_t group, f, produced = 0, consumed_groups = 0, progress = 0, i, ngalloc = 0;
+    const uint32_t threads = default_threads();
+    uint64_t off;
+    double t_begin = now_s(), t_parse = 0, t_submit = 0, t_wait = 0, t_scatter = 0, t0;
+    int ret = LNN_OK, scanning = 1;
     if (decoder == NULL || data == NULL || buffer == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if ((r = LINNEDecoder_DecodeHeader(data, data_size, &h)) != LINNE_APIRESULT_OK) return r;
     if ((r = LINNEDecoder_SetHeader(decoder, &h)) != LINNE_APIRESULT_OK) return r;
     hd = &decoder->header;
     if (buffer_num_channels < hd->num_channels || buffer_num_samples < hd->num_samples) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
-    C = decoder->shape.num_channels; S = decoder->shape.num_samples_per_block; CS = (uint64_t)C * S;
-    offs = malloc(sizeof(*offs) * group); avail = malloc(sizeof(*avail) * group); room = malloc(sizeof(*room) * group);
-    types = malloc(sizeof(*types) * group); ns = malloc(sizeof(*ns) * group); cn = malloc(sizeof(*cn) * group); rets = malloc(sizeof(*rets) * group);
-    samples = malloc(sizeof(int32_t) * CS * group); params = malloc(sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (size_t)C * group);
-    cbuf = malloc(sizeof(int32_t) * CS * group); cprm = malloc(sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (size_t)C * group);
-    if (!offs || !avail || !room || !types || !ns || !cn || !rets || !samples || !params || !cbuf || !cprm) { ret = LNN_NG; goto done; }
+    for (i = 0; i < hd->num_channels; i++) if (buffer[i] == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
+    {
+        const uint32_t S = decoder->shape.num_samples_per_block;
+        const uint32_t F = (uint32_t)(((uint64_t)hd->num_samples + S - 1) / S);
+        group = default_group(); if (group > F) group = F ? F : 1;
+    }
+    for (ngalloc = 0; ngalloc < LNN_SLOTS; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
+    uj.dec = decoder; uj.data = data; uj.buffer = buffer;
     off = LINNE_HEADER_SIZE;
-    while (progress < hd->num_samples && off < data_size && ret == LNN_OK) {
-        /* scan up to `group` block boundaries from the size fields (linne_decoder.c:603-615) */
-        uint32_t scan_progress = progress, nthreads = default_threads(), first = 0, ncomp = 0;
-        pthread_t th[64];
-        struct unpack_job jobs[64];
-        nblk = 0;
-        while (nblk < group && scan_progress < hd->num_samples && off < data_size) {
-            const uint64_t rem = data_size - off;
-            uint32_t bsize;
-            offs[nblk] = off; avail[nblk] = rem; room[nblk] = buffer_num_samples - scan_progress;
-            if (rem < 11 || get_be16(data + off) != 0xFFFF) { nblk++; break; }      /* the parser reports the error */
-            bsize = get_be32(data + off + 2);
-            if ((uint64_t)bsize + 6 > rem) { nblk++; break; }
-            scan_progress += get_be16(data + off + 9);
-            off += (uint64_t)bsize + 6;
-            nblk++;
+    while (scanning || consumed_groups < produced) {
+        if (scanning && produced - consumed_groups < LNN_SLOTS && progress < hd->num_samples && off < data_size) {
+            struct dgroup *g = &grp[produced % LNN_SLOTS];
+            struct LINNEAmdSlot *sl;
+            uint32_t scan_progress = progress, ncomp = 0;
+            g->nblk = 0;
+            while (g->nblk < group && scan_progress < hd->num_samples && off < data_size) {
+                const uint64_t rem = data_size - off;
+                const uint32_t k = g->nblk++;
+                uint32_t bsize;
+                g->offs[k] = off; g->avail[k] = rem; g->room[k] = buffer_num_samples - scan_progress; g->prog[k] = scan_progress;
+                g->cidx[k] = 0xFFFFFFFFu; g->types[k] = 0xFFFFFFFFu; g->ns[k] = 0;
+                if (rem < 11 || get_be16(data + off) != 0xFFFF) break;                  /* the parser reports the error */
+                bsize = get_be32(data + off + 2);
+                if ((uint64_t)bsize + 6 > rem) break;
+                if (data[off + 8] == LNN_BLOCK_COMPRESS) g->cidx[k] = ncomp++;
+                scan_progress += get_be16(data + off + 9);
+                off += (uint64_t)bsize + 6;
+            }
+            if (ncomp) {
+                if (decoder_device(decoder) != LINNE_APIRESULT_OK) { ret = LNN_NG; goto done; }
+                if (want_slots(decoder->ctx, decoder->slot, &decoder->slot_shape, &decoder->slot_frames, &decoder->shape, group, LNN_SLOTS, 0) != LNN_OK) {
+                    report(decoder->ctx, "SlotCreate", LNN_NG); ret = LNN_NG; goto done;
+                }
+            }
+            sl = decoder->slot[produced % LNN_SLOTS];
+            uj.g = g; uj.sdata = sl ? LINNEAmd_SlotData(sl) : NULL; uj.sprm = sl ? LINNEAmd_SlotParams(sl) : NULL;
+            t0 = now_s();
+            lnn_parallel_for(g->nblk, threads, unpack_blocks, &uj);
+            t_parse += now_s() - t0;
+            for (f = 0; f < g->nblk; f++) if (g->rets[f] != LNN_OK) { ret = g->rets[f]; g->nblk = f; scanning = 0; break; }    /* first failing block wins */
+            g->ncomp = 0;
+            for (f = 0; f < g->nblk; f++) {
+                if (g->types[f] == LNN_BLOCK_COMPRESS) g->cn[g->ncomp++] = g->ns[f];
+                progress = g->prog[f] + g->ns[f];
+            }
+            if (g->ncomp) {
+                int dret;
+                t0 = now_s();
+                dret = LINNEAmd_SlotDecodeSubmit(sl, g->cn, g->ncomp);
+                t_submit += now_s() - t0;
+                if (dret != LNN_OK) { report(decoder->ctx, "SlotDecodeSubmit", dret); ret = dret; goto done; }
+            }
+            produced++;
+            continue;
         }
-        if (nthreads > nblk) nthreads = nblk ? nblk : 1;
-        for (t = 0; t < nthreads; t++) {
-            const uint32_t c = nblk / nthreads + ((t < nblk % nthreads) ? 1u : 0u);
-            struct unpack_job *j = &jobs[t];
-            j->dec = decoder; j->data = data; j->offs = offs; j->avail = avail; j->room = room; j->samples = samples; j->params = params;
-            j->types = types; j->ns = ns; j->rets = rets; j->first = first; j->count = c; first += c;
-            if (nthreads == 1) unpack_worker(j); else pthread_create(&th[t], NULL, unpack_worker, j);
-        }
-        if (nthreads > 1) for (t = 0; t < nthreads; t++) pthread_join(th[t], NULL);
-        for (f = 0; f < nblk; f++) if (rets[f] != LNN_OK) { ret = rets[f]; nblk = f; break; }    /* first failing block wins */
-        /* gather COMPRESS blocks, synthesise them as one batch */
-        for (f = 0; f < nblk; f++) if (types[f] == LNN_BLOCK_COMPRESS) {
-            memcpy(cbuf + ncomp * CS, samples + f * CS, sizeof(int32_t) * CS);
-            memcpy(cprm + (size_t)ncomp * C * LINNE_AMD_PARAM_WORDS, params + (size_t)f * C * LINNE_AMD_PARAM_WORDS, sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C);
-            cn[ncomp++] = ns[f];
-        }
-        if (ncomp) {
-            int dret;
-            if (decoder_device(decoder) != LINNE_APIRESULT_OK) { ret = LNN_NG; goto done; }
-            dret = LINNEAmd_DecodeFramesHost(decoder->ctx, &decoder->shape, cbuf, cn, ncomp, cprm);
-            if (dret != LNN_OK) { report(decoder->ctx, "DecodeFramesHost", dret); ret = dret; goto done; }
-        }
-        ncomp = 0;
-        for (f = 0; f < nblk; f++) {
-            const int32_t *src = (types[f] == LNN_BLOCK_COMPRESS) ? (cbuf + (ncomp++) * CS) : (samples + f * CS);
-            for (ch = 0; ch < C; ch++) memcpy(buffer[ch] + progress, src + (size_t)ch * S, sizeof(int32_t) * ns[f]);
-            progress += ns[f];
+        scanning = 0;
+        if (consumed_groups < produced) {
+            struct dgroup *g = &grp[consumed_groups % LNN_SLOTS];
+            struct LINNEAmdSlot *sl = decoder->slot[consumed_groups % LNN_SLOTS];
+            if (g->ncomp) {
+                int dret;
+                t0 = now_s();
+                dret = LINNEAmd_SlotWait(sl);
+                t_wait += now_s() - t0;
+                if (dret != LNN_OK) { report(decoder->ctx, "SlotWait", dret); ret = dret; goto done; }
+                uj.g = g; uj.sdata = LINNEAmd_SlotData(sl); uj.sprm = NULL;
+                t0 = now_s();
+                lnn_parallel_for(g->nblk, threads, scatter_blocks, &uj);
+                t_scatter += now_s() - t0;
+            }
+            consumed_groups++;
+            if (ret == LNN_OK && progress < hd->num_samples && off < data_size) scanning = 1;
         }
     }
+    if (trace_on()) fprintf(stderr, "liblinne_amd: DecodeWhole %u threads: parse %.1f ms, submit %.1f, wait %.1f, scatter %.1f, total %.1f ms\n",
+            threads, t_parse * 1e3, t_submit * 1e3, t_wait * 1e3, t_scatter * 1e3, (now_s() - t_begin) * 1e3);
 done:
-    free(offs); free(avail); free(room); free(types); free(ns); free(cn); free(rets); free(samples); free(params); free(cbuf); free(cprm);
+    for (i = 0; i < LNN_SLOTS; i++) if (decoder->slot[i]) (void)LINNEAmd_SlotWait(decoder->slot[i]);
+    for (i = 0; i < ngalloc; i++) dgroup_free(&grp[i]);
     return (LINNEApiResult)ret;
 }

@@ -33,6 +33,7 @@
 #define LNN_MAXCH       8
 #define LNN_ACW         256     /* autocorrelation words per (job, trial): P + u <= 256 */
 #define LNN_MAXSUB      8
+#define LNN_META        8
 typedef double lnn_d2 __attribute__((ext_vector_type(2)));
 
 /* one distinct frame length of a batch (full frames, the ragged tail, ...) */
@@ -1245,6 +1246,12 @@ struct LINNEAmdContext {
     hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub;
     hipStream_t side; hipEvent_t side_done; int has_side;     /* block-type statistics run beside the analysis */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
+    /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
+    DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_for_encode, sig_valid;
+    /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
+    uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
+    /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
+    hipStream_t copy_in, copy_out; int has_copy;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -1324,6 +1331,8 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_wt) hipFree(ctx->d_wt);
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
+    for (int i = 0; i < LNN_META; i++) { if (ctx->meta_h[i]) hipHostFree(ctx->meta_h[i]); if (ctx->meta_ev[i]) hipEventDestroy(ctx->meta_ev[i]); }
+    if (ctx->has_copy) { hipStreamSynchronize(ctx->copy_in); hipStreamSynchronize(ctx->copy_out); hipStreamDestroy(ctx->copy_in); hipStreamDestroy(ctx->copy_out); }
     hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
     for (int i = 0; i < 2 * ctx->span_cap; i++) hipEventDestroy(ctx->span_ev[i]);
     free(ctx->span_ev); free(ctx->span_kind);
@@ -1444,37 +1453,46 @@ static int shape_info(const struct LINNEAmdShape *s, HostShape *h)
     return LNN_OK;
 }
 
-/* Builds the per-length classes of a batch and uploads them (tables are host libm values). */
+/* Builds the per-length classes of a batch (tables are host libm values).  The tables stay resident and
+ * are uploaded again only when the shape or the set of frame lengths changes; the per-frame class index and length go
+ * through a pinned ring, so a call with resident tables enqueues without synchronising the host. */
 static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const HostShape *hs,
-        const uint32_t *h_num_samples, uint32_t F, int for_encode, uint32_t **h_clsidx_out)
+        const uint32_t *h_num_samples, uint32_t F, int for_encode)
 {
     DevClass cls[LNN_MAXCLS];
     uint32_t ncls = 0;
     const uint32_t S = shape->num_samples_per_block;
-    uint32_t *idx = (uint32_t *)malloc(sizeof(uint32_t) * (F ? F : 1));
-    uint32_t *nsm = (uint32_t *)malloc(sizeof(uint32_t) * (F ? F : 1));
-    if (!idx || !nsm) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
+    const int m = ctx->meta_next;
+    ctx->meta_next = (m + 1) % LNN_META;
+    if (ctx->meta_used[m]) { HIPCHK(ctx, hipEventSynchronize(ctx->meta_ev[m])); ctx->meta_used[m] = 0; }
+    if (!ctx->meta_ev[m]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->meta_ev[m], hipEventDisableTiming));
+    if (ctx->meta_cap[m] < 2ull * F) {
+        const uint64_t cap = 2ull * (F < 4096u ? 4096u : F);
+        if (ctx->meta_h[m]) { HIPCHK(ctx, hipHostFree(ctx->meta_h[m])); ctx->meta_h[m] = NULL; ctx->meta_cap[m] = 0; }
+        HIPCHK(ctx, hipHostMalloc((void **)&ctx->meta_h[m], sizeof(uint32_t) * cap, hipHostMallocDefault));
+        ctx->meta_cap[m] = cap;
+    }
+    uint32_t *idx = ctx->meta_h[m], *nsm = ctx->meta_h[m] + F;
     memset(cls, 0, sizeof(cls));
     ctx->na_max = 0;
     uint64_t sin_total = 0, wt_total = 0;
     for (uint32_t f = 0; f < F; f++) {
         const uint32_t n = h_num_samples ? h_num_samples[f] : S;
-        if (n == 0 || n > S) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
+        if (n == 0 || n > S) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
         nsm[f] = n;
         uint32_t k = 0;
         for (; k < ncls; k++) if (cls[k].n == n) break;
         if (k == ncls) {
-            if (ncls == LNN_MAXCLS) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "more than %d distinct frame lengths in one batch", LNN_MAXCLS); return LNN_INVALID_ARGUMENT; }
+            if (ncls == LNN_MAXCLS) { snprintf(ctx->err, sizeof(ctx->err), "more than %d distinct frame lengths in one batch", LNN_MAXCLS); return LNN_INVALID_ARGUMENT; }
             DevClass &c = cls[ncls++];
             c.n = n;
             uint32_t na = ((n + 7u) / 8u) * 8u;             /* linne_encoder.c:652-654 */
             if (na < hs->maxP) na = hs->maxP;
             if (na > S) na = S;
             c.na = na;
-            if (na > ctx->na_max) ctx->na_max = na;
             c.sin_off = (uint32_t)sin_total; sin_total += n;
             if (for_encode) {
-                if (na & 1u) { free(idx); free(nsm); snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
+                if (na & 1u) { snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
                 for (uint32_t l = 0; l < hs->L; l++) {
                     const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
                     uint32_t nt = 0;
@@ -1490,20 +1508,22 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
                 }
             }
         }
+        if (cls[k].na > ctx->na_max) ctx->na_max = cls[k].na;
         idx[f] = k;
     }
     int ret;
-    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) { free(idx); free(nsm); return ret; }
-    if ((ret = ensure_buf(ctx, (void **)&ctx->d_nsmp, &ctx->nsmp_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) { free(idx); free(nsm); return ret; }
-    hipError_t e;
-    e = hipMemcpyAsync(ctx->d_clsidx, idx, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_nsmp, nsm, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && for_encode) {
-        double *tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
-        double *wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
-        if (!tab || !wt) e = hipErrorOutOfMemory;
-        else {
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_nsmp, &ctx->nsmp_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
+    const bool resident = ctx->sig_valid && ctx->sig_for_encode == for_encode && memcmp(&ctx->sig_shape, shape, sizeof(*shape)) == 0
+            && memcmp(ctx->sig_cls, cls, sizeof(cls)) == 0;
+    if (!resident) {
+        hipError_t e = hipSuccess;
+        double *tab = NULL, *wt = NULL;
+        ctx->sig_valid = 0;
+        if (for_encode) {
+            tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
+            wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
+            if (!tab || !wt) { free(tab); free(wt); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
             for (uint32_t k = 0; k < ncls; k++) {
                 const uint32_t n = cls[k].n;
                 for (uint32_t s = 0; s < n; s++) tab[cls[k].sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
@@ -1522,17 +1542,20 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
             }
             ret = ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1));
             if (ret == LNN_OK) ret = ensure_buf(ctx, (void **)&ctx->d_wt, &ctx->wt_cap, sizeof(double) * (wt_total ? wt_total : 1));
-            if (ret == LNN_OK) e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
-            if (ret == LNN_OK && e == hipSuccess) e = hipMemcpyAsync(ctx->d_wt, wt, sizeof(double) * wt_total, hipMemcpyHostToDevice, ctx->stream);
-            if (ret == LNN_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (ret != LNN_OK) { free(tab); free(wt); return ret; }
+            e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_wt, wt, sizeof(double) * wt_total, hipMemcpyHostToDevice, ctx->stream);
         }
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          /* cls is on the stack, tab/wt are freed here */
         free(tab); free(wt);
-        if (ret != LNN_OK) { free(idx); free(nsm); return ret; }
+        if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "class table upload: %s", hipGetErrorString(e)); return LNN_NG; }
+        memcpy(ctx->sig_cls, cls, sizeof(cls)); ctx->sig_shape = *shape; ctx->sig_for_encode = for_encode; ctx->sig_valid = 1;
     }
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);     /* idx/nsm/cls are stack or freed below */
-    free(nsm);
-    if (h_clsidx_out) *h_clsidx_out = idx; else free(idx);
-    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "class table upload: %s", hipGetErrorString(e)); if (h_clsidx_out) { free(idx); *h_clsidx_out = NULL; } return LNN_NG; }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_clsidx, idx, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_nsmp, nsm, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->meta_ev[m], ctx->stream));
+    ctx->meta_used[m] = 1;
     return LNN_OK;
 }
 
@@ -1567,7 +1590,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 1, NULL)) != LNN_OK) return ret;
+    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 1)) != LNN_OK) return ret;
 
     const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
     const uint64_t per_frame = frame_scratch_bytes(shape, &hs);
@@ -1678,7 +1701,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 0, NULL)) != LNN_OK) return ret;
+    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 0)) != LNN_OK) return ret;
     DecPlan p; memset(&p, 0, sizeof(p));
     p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
     for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
@@ -1763,4 +1786,140 @@ done:
     if (d_data) hipFree(d_data);
     if (d_prm) hipFree(d_prm);
     return ret;
+}
+
+/* ================================================================================================
+ * staging slots: pinned host buffers + device buffers for a group of frames.  Submit enqueues H2D (copy-in
+ * stream), the kernels (context stream) and D2H (copy-out stream) chained by events and returns at once, so a
+ * caller that rotates over a few slots overlaps its own host work (entropy stage), PCIe and the kernels.
+ * ============================================================================================== */
+struct LINNEAmdSlot {
+    LINNEAmdContext *ctx; struct LINNEAmdShape shape; uint32_t max_frames; int for_encode;
+    int32_t *h_pcm, *h_data, *h_prm; double *h_st;
+    int32_t *d_pcm, *d_data, *d_prm; double *d_st;
+    hipEvent_t ev_in, ev_k, ev_done; int pending;
+};
+
+static int ctx_copy_streams(LINNEAmdContext *ctx)
+{
+    if (ctx->has_copy) return LNN_OK;
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+    ctx->has_copy = 1;
+    return LNN_OK;
+}
+
+extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
+{
+    if (!s) return;
+    hipSetDevice(s->ctx->device);
+    if (s->pending) hipEventSynchronize(s->ev_done);
+    if (s->h_pcm) hipHostFree(s->h_pcm);
+    if (s->h_data) hipHostFree(s->h_data);
+    if (s->h_prm) hipHostFree(s->h_prm);
+    if (s->h_st) hipHostFree(s->h_st);
+    if (s->d_pcm) hipFree(s->d_pcm);
+    if (s->d_data) hipFree(s->d_data);
+    if (s->d_prm) hipFree(s->d_prm);
+    if (s->d_st) hipFree(s->d_st);
+    if (s->ev_in) hipEventDestroy(s->ev_in);
+    if (s->ev_k) hipEventDestroy(s->ev_k);
+    if (s->ev_done) hipEventDestroy(s->ev_done);
+    free(s);
+}
+
+extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        uint32_t max_frames, int for_encode)
+{
+    HostShape hs;
+    if (!ctx) return NULL;
+    ctx->err[0] = 0;
+    if (!shape || max_frames == 0 || shape_info(shape, &hs) != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "SlotCreate: invalid shape"); return NULL; }
+    if (hipSetDevice(ctx->device) != hipSuccess || ctx_copy_streams(ctx) != LNN_OK) return NULL;
+    LINNEAmdSlot *s = (LINNEAmdSlot *)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    s->ctx = ctx; s->shape = *shape; s->max_frames = max_frames; s->for_encode = for_encode;
+    const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
+    const uint64_t nb = sizeof(int32_t) * CS * max_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * max_frames,
+                   sb = sizeof(double) * LINNE_AMD_STAT_WORDS * (uint64_t)shape->num_channels * max_frames;
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_data, nb, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_prm, pb, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_data, nb);
+    if (e == hipSuccess) e = hipMalloc((void **)&s->d_prm, pb);
+    if (for_encode) {
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pcm, nb, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_st, sb, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_pcm, nb);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_st, sb);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "SlotCreate: %s", hipGetErrorString(e)); LINNEAmd_SlotDestroy(s); return NULL; }
+    return s;
+}
+
+extern "C" int32_t *LINNEAmd_SlotPcm(struct LINNEAmdSlot *s) { return s ? s->h_pcm : NULL; }
+extern "C" int32_t *LINNEAmd_SlotData(struct LINNEAmdSlot *s) { return s ? s->h_data : NULL; }
+extern "C" int32_t *LINNEAmd_SlotParams(struct LINNEAmdSlot *s) { return s ? s->h_prm : NULL; }
+extern "C" double *LINNEAmd_SlotStats(struct LINNEAmdSlot *s) { return s ? s->h_st : NULL; }
+extern "C" uint32_t LINNEAmd_SlotCapacity(const struct LINNEAmdSlot *s) { return s ? s->max_frames : 0; }
+
+extern "C" int LINNEAmd_SlotWait(struct LINNEAmdSlot *s)
+{
+    if (!s) return LNN_INVALID_ARGUMENT;
+    if (!s->pending) return LNN_OK;
+    HIPCHK(s->ctx, hipEventSynchronize(s->ev_done));
+    s->pending = 0;
+    return LNN_OK;
+}
+
+extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t *num_samples, uint32_t num_frames)
+{
+    if (!s || !s->for_encode) return LNN_INVALID_ARGUMENT;
+    LINNEAmdContext *ctx = s->ctx;
+    if (num_frames == 0 || num_frames > s->max_frames) { snprintf(ctx->err, sizeof(ctx->err), "SlotEncodeSubmit: %u frames in a slot of %u", num_frames, s->max_frames); return LNN_INVALID_ARGUMENT; }
+    int ret = LINNEAmd_SlotWait(s);
+    if (ret != LNN_OK) return ret;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
+    const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames, sb = sizeof(double) * LINNE_AMD_STAT_WORDS * C * num_frames;
+    HIPCHK(ctx, hipMemcpyAsync(s->d_pcm, s->h_pcm, nb, hipMemcpyHostToDevice, ctx->copy_in));
+    HIPCHK(ctx, hipEventRecord(s->ev_in, ctx->copy_in));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
+    HIPCHK(ctx, hipMemsetAsync(s->d_prm, 0, pb, ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(s->d_st, 0, sb, ctx->stream));
+    if ((ret = LINNEAmd_EncodeFramesDevice(ctx, &s->shape, s->d_pcm, num_samples, num_frames, s->d_data, s->d_prm, s->d_st)) != LNN_OK) return ret;
+    HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_prm, s->d_prm, pb, hipMemcpyDeviceToHost, ctx->copy_out));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_st, s->d_st, sb, hipMemcpyDeviceToHost, ctx->copy_out));
+    HIPCHK(ctx, hipEventRecord(s->ev_done, ctx->copy_out));
+    s->pending = 1;
+    return LNN_OK;
+}
+
+extern "C" int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *s, const uint32_t *num_samples, uint32_t num_frames)
+{
+    if (!s) return LNN_INVALID_ARGUMENT;
+    LINNEAmdContext *ctx = s->ctx;
+    if (num_frames == 0 || num_frames > s->max_frames) { snprintf(ctx->err, sizeof(ctx->err), "SlotDecodeSubmit: %u frames in a slot of %u", num_frames, s->max_frames); return LNN_INVALID_ARGUMENT; }
+    int ret = LINNEAmd_SlotWait(s);
+    if (ret != LNN_OK) return ret;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
+    const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames;
+    HIPCHK(ctx, hipMemcpyAsync(s->d_data, s->h_data, nb, hipMemcpyHostToDevice, ctx->copy_in));
+    HIPCHK(ctx, hipMemcpyAsync(s->d_prm, s->h_prm, pb, hipMemcpyHostToDevice, ctx->copy_in));
+    HIPCHK(ctx, hipEventRecord(s->ev_in, ctx->copy_in));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
+    if ((ret = LINNEAmd_DecodeFramesDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_prm)) != LNN_OK) return ret;
+    HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
+    HIPCHK(ctx, hipEventRecord(s->ev_done, ctx->copy_out));
+    s->pending = 1;
+    return LNN_OK;
 }

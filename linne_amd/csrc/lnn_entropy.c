@@ -22,20 +22,31 @@
 #include <string.h>
 
 /* ------------------------------------------------------------------------------------------------ CRC16 */
-static uint16_t g_crc_table[256];
+/* CRC-16/ARC (reflected 0xA001), eight bytes per step: g_crc[k][b] is the CRC contribution of byte b followed by k zero bytes */
+static uint16_t g_crc[8][256];
 static void crc_init(void)
 {
-    uint32_t i, b;
+    uint32_t i, b, k;
     for (i = 0; i < 256; i++) {
         uint16_t c = (uint16_t)i;
         for (b = 0; b < 8; b++) c = (uint16_t)((c & 1u) ? ((c >> 1) ^ 0xA001u) : (c >> 1));
-        g_crc_table[i] = c;
+        g_crc[0][i] = c;
     }
+    for (k = 1; k < 8; k++)
+        for (i = 0; i < 256; i++) g_crc[k][i] = (uint16_t)((g_crc[k - 1][i] >> 8) ^ g_crc[0][g_crc[k - 1][i] & 0xFFu]);
 }
 uint16_t lnn_crc16(const uint8_t *data, uint64_t size)
 {
     uint16_t crc = 0;
-    while (size--) crc = (uint16_t)((crc >> 8) ^ g_crc_table[(crc ^ *data++) & 0xFFu]);
+    while (size >= 8) {
+        uint64_t w;
+        memcpy(&w, data, 8);                               /* little-endian host (x86-64) */
+        w ^= crc;
+        crc = (uint16_t)(g_crc[7][w & 0xFFu] ^ g_crc[6][(w >> 8) & 0xFFu] ^ g_crc[5][(w >> 16) & 0xFFu] ^ g_crc[4][(w >> 24) & 0xFFu]
+                ^ g_crc[3][(w >> 32) & 0xFFu] ^ g_crc[2][(w >> 40) & 0xFFu] ^ g_crc[1][(w >> 48) & 0xFFu] ^ g_crc[0][w >> 56]);
+        data += 8; size -= 8;
+    }
+    while (size--) crc = (uint16_t)((crc >> 8) ^ g_crc[0][(crc ^ *data++) & 0xFFu]);
     return crc;
 }
 
@@ -399,6 +410,26 @@ static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers
     put_be16(out + 6, lnn_crc16(out + 8, body + 3));
     *size_out = (uint32_t)(11 + body);
     return LNN_OK;
+}
+
+/* ---- fork/join over a range (frames are independent) -------------------------------------------------- */
+struct pf_job { void (*fn)(void *, uint32_t, uint32_t); void *arg; uint32_t first, count; };
+static void *pf_worker(void *a) { struct pf_job *j = a; j->fn(j->arg, j->first, j->count); return NULL; }
+void lnn_parallel_for(uint32_t count, uint32_t num_threads, void (*fn)(void *arg, uint32_t first, uint32_t count), void *arg)
+{
+    pthread_t th[64]; struct pf_job jobs[64]; int started[64];
+    uint32_t t, first = 0, nt = num_threads ? num_threads : 1;
+    if (count == 0) return;
+    if (nt > 64) nt = 64;
+    if (nt > count) nt = count;
+    if (nt == 1) { fn(arg, 0, count); return; }
+    for (t = 0; t < nt; t++) {
+        const uint32_t c = count / nt + ((t < count % nt) ? 1u : 0u);
+        jobs[t].fn = fn; jobs[t].arg = arg; jobs[t].first = first; jobs[t].count = c; first += c;
+        started[t] = (t + 1 < nt) && pthread_create(&th[t], NULL, pf_worker, &jobs[t]) == 0;
+        if (!started[t]) pf_worker(&jobs[t]);              /* the last share (and any the OS refused a thread for) runs here */
+    }
+    for (t = 0; t < nt; t++) if (started[t]) pthread_join(th[t], NULL);
 }
 
 /* ---- thread pool over frames ------------------------------------------------------------------------- */

@@ -21,6 +21,7 @@ uint16_t lnn_crc16(const uint8_t *data, uint64_t size);
 int lnn_shape_layers(const struct LINNEAmdShape *shape, struct lnn_layers *out);
 uint32_t lnn_decide_block_type(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t n,
         const int32_t *pcm_frame, const double *stats_frame, double *state);
+void lnn_parallel_for(uint32_t count, uint32_t num_threads, void (*fn)(void *arg, uint32_t first, uint32_t count), void *arg);
 int lnn_parse_block(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, const uint8_t *data, uint64_t avail,
         int check_crc, uint32_t max_samples, uint32_t *type_out, uint32_t *n_out, uint32_t *consumed_out,
         int32_t *samples, int32_t *params);

@@ -193,3 +193,28 @@ def test_hotpath_degenerate_signals(ctx, oracle, kind):
         assert np.array_equal(ores, res[f])
     if kind in ("silence", "positive_const", "negative_const"):
         assert ctx.last_fallback_count() > 0, "exact ties must take the ordered-chain fallback"
+
+
+@pytest.mark.parametrize("group", ["2", "5"])
+def test_whole_stream_pipeline_over_staging_slots(product, oracle, monkeypatch, group):
+    """EncodeWhole / DecodeWhole rotate groups of frames over three staging slots (pinned host + device buffers, copy
+    streams beside the kernel stream): with tiny groups a short stream exercises slot reuse, a ragged tail, and
+    SILENT / RAW blocks between COMPRESS ones; the bytes must not depend on the grouping"""
+    monkeypatch.setenv("LINNE_AMD_GROUP", group)
+    block = 2048
+    parts = [music(2, 9 * block, 16, seed=21), np.zeros((2, 2 * block), dtype=np.int32), waveform("white_noise", 2, 3 * block, 16, seed=2),
+             music(2, 5 * block + 777, 16, seed=22)]
+    x = np.concatenate(parts, axis=1)
+    mine = product.encode_whole(x, 16, 44100, block, 7, True)
+    want = oracle.encode_whole(x, 16, 44100, block, 7, True)
+    assert mine == want
+    types, off = set(), 30
+    while off < len(mine):
+        types.add(mine[off + 8]); off += int.from_bytes(mine[off + 2:off + 6], "big") + 6
+    assert types == {0, 1, 2}                                   # compress, silent and raw all occur
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
+    # a stream cut in the middle of a later group: the error is reported and the blocks before it are delivered
+    cut = product.decode_whole(mine[:len(mine) * 2 // 3])
+    assert cut[0] == 4                                          # INSUFFICIENT_DATA
+    assert np.array_equal(cut[1][:, :6 * block], x[:, :6 * block])

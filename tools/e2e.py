@@ -1,17 +1,35 @@
-"""end-to-end timing of the drop-in API (host buffers in, .lnn bytes out): LINNEEncoder_EncodeWhole / LINNEDecoder_DecodeWhole"""
-import os, sys, time
+"""end-to-end timing of the drop-in API (host planes in, .lnn bytes out and back): LINNEEncoder_EncodeWhole /
+LINNEDecoder_DecodeWhole on one handle each, caller buffers touched beforehand; rep 0 pays the one-time set-up of the
+handle's GPU context and pinned staging slots, later reps are the steady state."""
+import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import linne_amd
-from refs import LinneApi
+from refs import LinneApi, _planar_ptrs, _RefDecoderConfig
 from bench import synth_track
 minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 5.0
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ns = int(minutes * 60 * 44100)
-x = synth_track(ns, 2, 16, 3, torch.device("cuda", 0)).cpu().numpy()
+x = np.ascontiguousarray(synth_track(ns, 2, 16, 3, torch.device("cuda", 0)).cpu().numpy(), dtype=np.int32)
 api = LinneApi(linne_amd.LIB_PATH)
-for rep in range(2):
-    t0 = time.perf_counter(); lnn = api.encode_whole(x, 16, 44100, 10240, 7, True); t1 = time.perf_counter()
-    ret, dec = api.decode_whole(lnn); t2 = time.perf_counter()
-    nf = (ns + 10239) // 10240
-    print(f"rep {rep}: {nf} frames; EncodeWhole {t1-t0:.3f} s -> {nf/(t1-t0):.0f} frames/s; DecodeWhole {t2-t1:.3f} s -> {nf/(t2-t1):.0f} frames/s; ratio {len(lnn)/(x.size*2):.3f}; ok={ret == 0 and np.array_equal(dec, x)}")
+L = api.L
+nf = (ns + 10239) // 10240
+enc = api.new_encoder(2, 16, 44100, 10240, 7, True)
+cfg = _RefDecoderConfig(2, 5, 128, 1)
+dec = L.LINNEDecoder_Create(C.byref(cfg), None, 0)
+xp, _k1 = _planar_ptrs(x)
+cap = x.size * 4 + 65536
+out = np.ones(cap, dtype=np.uint8)
+back = np.ones_like(x)
+bp, _k2 = _planar_ptrs(back)
+osz = C.c_uint32(0)
+for rep in range(reps):
+    t0 = time.perf_counter()
+    r1 = L.LINNEEncoder_EncodeWhole(enc, xp, ns, out.ctypes.data, cap, C.byref(osz))
+    t1 = time.perf_counter()
+    r2 = L.LINNEDecoder_DecodeWhole(dec, out.ctypes.data, osz.value, bp, 2, ns)
+    t2 = time.perf_counter()
+    print(f"rep {rep}: {nf} frames; EncodeWhole {t1-t0:.3f} s -> {nf/(t1-t0):.0f} frames/s; DecodeWhole {t2-t1:.3f} s -> {nf/(t2-t1):.0f} frames/s; "
+          f"ratio {osz.value/(x.size*2):.3f}; ok={r1 == 0 and r2 == 0 and np.array_equal(back, x)}", flush=True)
+L.LINNEEncoder_Destroy(enc); L.LINNEDecoder_Destroy(dec)

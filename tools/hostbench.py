@@ -36,7 +36,7 @@ import ctypes as C
 lib = linne_amd.lib
 cap = pcm.size * 8 + 64 * F + 64
 out = np.zeros(cap, np.uint8); sizes = np.zeros(F, np.uint32)
-for threads in (1, 2, 4, 8):
+for threads in (1, 2, 4, 8, 16):
     best = 1e9
     for rep in range(5):
         stt = C.c_double(0.0)
