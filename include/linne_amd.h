@@ -112,6 +112,17 @@ int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmd
 int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         int32_t *data, const uint32_t *num_samples, uint32_t num_frames, const int32_t *params);
 
+/* Rice planning on the device (linne_coder.c:217-279): for every channel-frame of a batch, the
+ * partition means of the zig-zagged residual, the parameter of every partition at every partition order, the code length
+ * of every order and the argmin -- everything of LINNECoder_EncodePartitionedRecursiveRice except writing the bits.
+ * Plan record per channel-frame, LINNE_AMD_RICE_PLAN_BYTES bytes: [0] partition order, [1] 1 if some mean fell inside the
+ * guard band of a parameter step (the host then runs its own search for this channel-frame; the libm expression decides),
+ * [16 ..] the parameter of each partition of the chosen order.  Enqueues on the context's stream. */
+#define LINNE_AMD_RICE_PLAN_BYTES  1040
+#define LINNE_AMD_RICE_PLAN_K2     16
+int LINNEAmd_RicePlanDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *d_residual, const uint32_t *h_num_samples, uint32_t num_frames, uint8_t *d_plan);
+
 /* Staging slots: what a whole-stream caller (LINNEEncoder_EncodeWhole / LINNEDecoder_DecodeWhole,
  * linne_encoder.c:865-932, linne_decoder.c:671-742) uses instead of the synchronous host forms.  A slot owns pinned
  * host buffers and device buffers for up to max_frames frames of one shape.  The caller fills SlotPcm (encode) or
@@ -127,6 +138,7 @@ int32_t  *LINNEAmd_SlotPcm(struct LINNEAmdSlot *slot);       /* [F][C][S] int32,
 int32_t  *LINNEAmd_SlotData(struct LINNEAmdSlot *slot);      /* [F][C][S] int32, residual (encode out, decode in) / PCM (decode out) */
 int32_t  *LINNEAmd_SlotParams(struct LINNEAmdSlot *slot);    /* [F][C][LINNE_AMD_PARAM_WORDS] */
 double   *LINNEAmd_SlotStats(struct LINNEAmdSlot *slot);     /* [F][C][LINNE_AMD_STAT_WORDS] (NULL for a decode slot) */
+uint8_t  *LINNEAmd_SlotRicePlan(struct LINNEAmdSlot *slot);  /* [F][C][LINNE_AMD_RICE_PLAN_BYTES] (NULL for a decode slot) */
 uint32_t  LINNEAmd_SlotCapacity(const struct LINNEAmdSlot *slot);
 int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
 int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
@@ -157,6 +169,11 @@ int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);
  * across calls.  Returns LINNEApiResult. */
 int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
         uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
+        uint32_t num_threads);
+/* The same with the device's Rice plan (LINNEAmd_RicePlanDevice; NULL = search on the host): the host then only writes bits. */
+int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
+        uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
         uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
         uint32_t num_threads);
 

@@ -21,6 +21,7 @@ LIB_PATH = os.path.join(_HERE, "liblinne_amd.so")
 
 PARAM_WORDS = 160
 STAT_WORDS = 8
+RICE_PLAN_BYTES = 1040         # include/linne_amd.h: [0] order, [1] host-search flag, [16..] parameters
 PRM_PREV, PRM_PCOEF, PRM_UNITS, PRM_RSHIFT, PRM_COEF = 0, 2, 4, 7, 10
 ST_R0, ST_K1, ST_ZERO, ST_TAIL, ST_BEST, ST_LOSS = 0, 1, 4, 5, 6, 7
 PRESET_LAYERS = {0: (2, 32), 1: (2, 32), 2: (4, 64, 8), 3: (4, 64, 8), 4: (4, 64, 8),
@@ -40,7 +41,7 @@ AMD_SYMBOLS = [
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
     "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
-    "LINNEAmd_SlotCapacity", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
+    "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
 ]
 
 
@@ -86,6 +87,9 @@ def _load():
     L.LINNEAmd_GetLastTimingLaunches.argtypes = [C.c_void_p, C.c_int]
     L.LINNEAmd_PackFrames.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
+    L.LINNEAmd_PackFramesPlanned.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
+    L.LINNEAmd_RicePlanDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     return L
 
 
@@ -168,6 +172,17 @@ class Context:
                                                     F, res.data_ptr(), prm.data_ptr(), st.data_ptr()), "EncodeFramesDevice")
         return res, prm, st
 
+    def rice_plan(self, shape, residual, num_samples=None):
+        """residual: int32 cuda tensor [F][C][S] -> uint8 cuda tensor [F][C][RICE_PLAN_BYTES] (order, flag, parameters)"""
+        import torch
+        F, Cn, S = residual.shape
+        assert residual.dtype == torch.int32 and residual.is_cuda and residual.is_contiguous()
+        plan = torch.zeros((F, Cn, RICE_PLAN_BYTES), dtype=torch.uint8, device=residual.device)
+        ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+        self._check(lib.LINNEAmd_RicePlanDevice(self.h, C.byref(shape), residual.data_ptr(), ns.ctypes.data if ns is not None else None,
+                                                F, plan.data_ptr()), "RicePlanDevice")
+        return plan
+
     def decode_frames(self, shape, data, params, num_samples=None):
         """in place: data int32 cuda [F][C][S] residual -> PCM"""
         import torch
@@ -201,8 +216,9 @@ class Context:
         return d
 
 
-def pack_frames(shape, pcm, residual, params, stats, num_samples=None, parcor_state=0.0, threads=0):
-    """host entropy stage: numpy arrays of one batch -> (list of block bytes, new parcor_state)"""
+def pack_frames(shape, pcm, residual, params, stats, num_samples=None, parcor_state=0.0, threads=0, plan=None):
+    """host entropy stage: numpy arrays of one batch -> (list of block bytes, new parcor_state); plan = the device's
+    Rice plan (Context.rice_plan, as a numpy uint8 array) or None for the host search"""
     pcm = np.ascontiguousarray(pcm, dtype=np.int32)
     residual = np.ascontiguousarray(residual, dtype=np.int32)
     params = np.ascontiguousarray(params, dtype=np.int32)
@@ -213,9 +229,13 @@ def pack_frames(shape, pcm, residual, params, stats, num_samples=None, parcor_st
     sizes = np.zeros(F, dtype=np.uint32)
     ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
     st = C.c_double(parcor_state)
-    ret = lib.LINNEAmd_PackFrames(C.byref(shape), pcm.ctypes.data, ns.ctypes.data if ns is not None else None, F,
-                                  residual.ctypes.data, params.ctypes.data, stats.ctypes.data, out.ctypes.data, cap,
-                                  sizes.ctypes.data, C.byref(st), threads or (os.cpu_count() or 1))
+    if plan is not None:
+        plan = np.ascontiguousarray(plan, dtype=np.uint8)
+        assert plan.shape == (F, pcm.shape[1], RICE_PLAN_BYTES)
+    ret = lib.LINNEAmd_PackFramesPlanned(C.byref(shape), pcm.ctypes.data, ns.ctypes.data if ns is not None else None, F,
+                                         residual.ctypes.data, params.ctypes.data, stats.ctypes.data,
+                                         plan.ctypes.data if plan is not None else None, out.ctypes.data, cap,
+                                         sizes.ctypes.data, C.byref(st), threads or (os.cpu_count() or 1))
     if ret != 0:
         raise LinneAmdError(f"PackFrames -> {ret}")
     blocks, off = [], 0

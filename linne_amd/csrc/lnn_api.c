@@ -53,10 +53,15 @@ static uint32_t default_threads(void)
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static int trace_on(void) { static int v = -1; if (v < 0) { const char *e = getenv("LINNE_AMD_TRACE"); v = (e && atoi(e)) ? 1 : 0; } return v; }
-static uint32_t default_group(void)     /* frames per staging slot */
+/* frames per staging slot: LINNE_AMD_GROUP, else large enough that a group is throughput- rather than latency-bound on
+ * the GPU (one batch call has a few ms of dependent-kernel latency) while a long stream still splits into several groups
+ * that overlap with the host stage */
+static uint32_t default_group(uint32_t num_frames)
 {
     const char *e = getenv("LINNE_AMD_GROUP");
-    long n = e ? atol(e) : 256;
+    long n = e ? atol(e) : (long)((num_frames + 5u) / 6u);
+    if (!e && n < 256) n = 256;
+    if (!e && n > 1024) n = 1024;
     if (n < 1) n = 1;
     if (n > 4096) n = 4096;
     return (uint32_t)n;
@@ -301,7 +306,7 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
     if (encoder_device(encoder) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
     t_begin = now_s();
     F = (uint32_t)(((uint64_t)num_samples + S - 1) / S);
-    group = default_group(); if (group > F) group = F;
+    group = default_group(F); if (group > F) group = F;
     ngroups = (F + group - 1) / group;
     nslots = (ngroups < LNN_SLOTS) ? ngroups : LNN_SLOTS;
     if (F > 32) (void)LINNEAmd_ReserveScratch(encoder->ctx, 2ull << 30);
@@ -333,9 +338,9 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
             ret = LINNEAmd_SlotWait(sl);
             t_wait += now_s() - t0; t0 = now_s();
             if (ret != LNN_OK) { report(encoder->ctx, "SlotWait", ret); goto done; }
-            ret = LINNEAmd_PackFrames(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % nslots) * group, cnt,
-                    LINNEAmd_SlotData(sl), LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), data + off, data_size - off, sizes,
-                    &encoder->parcor_state, threads);
+            ret = LINNEAmd_PackFramesPlanned(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % nslots) * group, cnt,
+                    LINNEAmd_SlotData(sl), LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), LINNEAmd_SlotRicePlan(sl),
+                    data + off, data_size - off, sizes, &encoder->parcor_state, threads);
             t_pack += now_s() - t0;
             if (ret != LNN_OK) goto done;
             for (f = 0; f < cnt; f++) off += sizes[f];
@@ -568,7 +573,7 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     {
         const uint32_t S = decoder->shape.num_samples_per_block;
         const uint32_t F = (uint32_t)(((uint64_t)hd->num_samples + S - 1) / S);
-        group = default_group(); if (group > F) group = F ? F : 1;
+        group = default_group(F); if (group > F) group = F ? F : 1;
     }
     for (ngalloc = 0; ngalloc < LNN_SLOTS; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;

@@ -21,6 +21,12 @@ extern "C" {
 /* parameter presets (libs/linne_internal/src/linne_internal.c:16-41): layer sizes and ridge regularisers */
 int lnn_preset_info(uint32_t preset, uint32_t *num_layers, uint32_t *layers, uint32_t *num_regs, double *regs);
 
+/* steps of the Rice parameter as a function of the partition mean (lnn_entropy.c: located with the host libm): steps[k] is
+ * the smallest mean whose parameter is k + 1; returns how many there are (at most 32) */
+uint32_t lnn_rice_k2_steps(double *steps);
+/* relative half-width of the band around a step inside which the libm expression itself must be evaluated */
+#define LNN_RICE_GUARD 1e-9
+
 #ifdef __cplusplus
 }
 #endif

@@ -1226,6 +1226,95 @@ __global__ void k_ms_to_lr(DecPlan p)
     sd[s] = (int32_t)((uint32_t)sd[s] + l);
 }
 
+
+/* ================================================================================================
+ * Rice planning (linne_coder.c:217-279): one block per channel-frame.
+ * Integer sums are exact, the means repeat the host's divisions ((double)sum / ns, then pairwise (a + b) / 2.0), the
+ * parameter is a search in the table of steps the host located with its libm (a mean inside a guard band raises the
+ * record's flag and the host searches that channel-frame itself), code lengths are uint32 with wrap-around.
+ * ============================================================================================== */
+#define RICE_THREADS 256
+struct RicePlanArgs {
+    const int32_t *resid; const uint32_t *nsmp; uint8_t *plan; uint32_t C, S, nsteps;
+    double steps[32];
+};
+__device__ __forceinline__ uint32_t rp_zz(int32_t v) { const uint32_t d = (uint32_t)v << 1; return (v < 0) ? ((0u - d) - 1u) : d; }
+__device__ __forceinline__ uint32_t rp_gamma_len(uint32_t u) { return u ? (2u * (32u - (uint32_t)__clz((int)(u + 1u))) - 1u) : 1u; }   /* 2*ceil_log2(u+2)-1 */
+
+__global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(RicePlanArgs a)
+{
+    __shared__ double mean[2048];            /* level o (2^o partitions) at [2^o - 1, 2^(o+1) - 1) */
+    __shared__ uint8_t kk[2048];
+    __shared__ uint32_t tot[12];
+    __shared__ uint32_t flag, best_s;
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x;
+    const uint32_t n = a.nsmp[cf / a.C];
+    const int32_t *x = a.resid + (size_t)cf * a.S;
+    uint8_t *rec = a.plan + (size_t)cf * LINNE_AMD_RICE_PLAN_BYTES;
+    uint32_t max_order = 1;
+    while (max_order <= 11 && (n % (1u << max_order)) == 0) max_order++;
+    max_order = (max_order - 1 < 10u) ? max_order - 1 : 10u;
+    const uint32_t parts = 1u << max_order, nsf = n / parts;
+    if (tid < 12) tot[tid] = 0;
+    if (tid == 0) flag = 0;
+    for (uint32_t p = tid; p < parts; p += RICE_THREADS) {
+        const int32_t *q = x + (size_t)p * nsf;
+        uint64_t sum = 0;
+        for (uint32_t j = 0; j < nsf; j++) sum += rp_zz(q[j]);
+        mean[parts - 1 + p] = (double)sum / (double)nsf;
+    }
+    __syncthreads();
+    for (int o = (int)max_order - 1; o >= 0; o--) {
+        const uint32_t base = (1u << o) - 1u, cbase = (2u << o) - 1u;
+        for (uint32_t p = tid; p < (1u << o); p += RICE_THREADS) mean[base + p] = (mean[cbase + 2 * p] + mean[cbase + 2 * p + 1]) / 2.0;
+        __syncthreads();
+    }
+    const uint32_t nent = 2u * parts - 1u;
+    for (uint32_t e = tid; e < nent; e += RICE_THREADS) {
+        const double m = mean[e];
+        uint32_t k = 0;
+        for (uint32_t i = 0; i < a.nsteps; i++) k += (m >= a.steps[i]) ? 1u : 0u;
+        bool guard = !(m >= 0.0);
+        if (k < a.nsteps && m >= a.steps[k] * (1.0 - LNN_RICE_GUARD)) guard = true;
+        if (k > 0 && m <= a.steps[k - 1] * (1.0 + LNN_RICE_GUARD)) guard = true;
+        if (guard) atomicOr(&flag, 1u);
+        kk[e] = (uint8_t)(k & 31u);
+    }
+    __syncthreads();
+    /* per entry: the samples' fixed part and the parameter's own code */
+    for (uint32_t e = tid; e < nent; e += RICE_THREADS) {
+        const uint32_t o = 31u - (uint32_t)__clz((int)(e + 1u)), p = e - ((1u << o) - 1u);
+        const uint32_t k = kk[e];
+        uint32_t bits = (n >> o) * (k + 2u);
+        bits += p ? rp_gamma_len(rp_zz((int32_t)k - (int32_t)kk[e - 1])) : 5u;
+        atomicAdd(&tot[o], bits);
+    }
+    /* per finest partition: the excess of its samples under the parameter of each order's enclosing partition */
+    for (uint32_t p = tid; p < parts; p += RICE_THREADS) {
+        const int32_t *q = x + (size_t)p * nsf;
+        uint32_t kc[11], acc[11];
+#pragma unroll
+        for (uint32_t o = 0; o < 11; o++) { acc[o] = 0; kc[o] = (o <= max_order) ? kk[((1u << o) - 1u) + (p >> (max_order - o))] : 0u; }
+        for (uint32_t j = 0; j < nsf; j++) {
+            const uint32_t v = rp_zz(q[j]);
+#pragma unroll
+            for (uint32_t o = 0; o < 11; o++) { const uint32_t k1pow = 1u << ((kc[o] + 1u) & 31u); acc[o] += ((v > k1pow) ? (v - k1pow) : 0u) >> kc[o]; }
+        }
+#pragma unroll
+        for (uint32_t o = 0; o < 11; o++) if (o <= max_order) atomicAdd(&tot[o], acc[o]);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t best = 0, min_bits = 0xFFFFFFFFu;
+        for (uint32_t o = 0; o <= max_order; o++) if (min_bits > tot[o]) { min_bits = tot[o]; best = o; }
+        best_s = best;
+        rec[0] = (uint8_t)best; rec[1] = (uint8_t)flag;
+    }
+    __syncthreads();
+    const uint32_t best = best_s;
+    for (uint32_t p = tid; p < (1u << best); p += RICE_THREADS) rec[LINNE_AMD_RICE_PLAN_K2 + p] = kk[((1u << best) - 1u) + p];
+}
+
 /* ================================================================================================
  * host side of this TU: context, scratch arena, launch sequences, C-ABI
  * ============================================================================================== */
@@ -1252,6 +1341,7 @@ struct LINNEAmdContext {
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
     hipStream_t copy_in, copy_out; int has_copy;
+    uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -1331,6 +1421,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_wt) hipFree(ctx->d_wt);
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
+    if (ctx->d_plan_nsmp) hipFree(ctx->d_plan_nsmp);
     for (int i = 0; i < LNN_META; i++) { if (ctx->meta_h[i]) hipHostFree(ctx->meta_h[i]); if (ctx->meta_ev[i]) hipEventDestroy(ctx->meta_ev[i]); }
     if (ctx->has_copy) { hipStreamSynchronize(ctx->copy_in); hipStreamSynchronize(ctx->copy_out); hipStreamDestroy(ctx->copy_in); hipStreamDestroy(ctx->copy_out); }
     hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
@@ -1453,15 +1544,9 @@ static int shape_info(const struct LINNEAmdShape *s, HostShape *h)
     return LNN_OK;
 }
 
-/* Builds the per-length classes of a batch (tables are host libm values, SURVEY 7.3-2).  The tables stay resident and
- * are uploaded again only when the shape or the set of frame lengths changes; the per-frame class index and length go
- * through a pinned ring, so a call with resident tables enqueues without synchronising the host. */
-static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const HostShape *hs,
-        const uint32_t *h_num_samples, uint32_t F, int for_encode)
+/* next buffer of the pinned metadata ring, holding at least 2 * F words; waits for the copy that last read it */
+static int meta_acquire(LINNEAmdContext *ctx, uint32_t F, int *m_out)
 {
-    DevClass cls[LNN_MAXCLS];
-    uint32_t ncls = 0;
-    const uint32_t S = shape->num_samples_per_block;
     const int m = ctx->meta_next;
     ctx->meta_next = (m + 1) % LNN_META;
     if (ctx->meta_used[m]) { HIPCHK(ctx, hipEventSynchronize(ctx->meta_ev[m])); ctx->meta_used[m] = 0; }
@@ -1472,6 +1557,21 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->meta_h[m], sizeof(uint32_t) * cap, hipHostMallocDefault));
         ctx->meta_cap[m] = cap;
     }
+    *m_out = m;
+    return LNN_OK;
+}
+
+/* Builds the per-length classes of a batch (tables are host libm values, SURVEY 7.3-2).  The tables stay resident and
+ * are uploaded again only when the shape or the set of frame lengths changes; the per-frame class index and length go
+ * through a pinned ring, so a call with resident tables enqueues without synchronising the host. */
+static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const HostShape *hs,
+        const uint32_t *h_num_samples, uint32_t F, int for_encode)
+{
+    DevClass cls[LNN_MAXCLS];
+    uint32_t ncls = 0;
+    const uint32_t S = shape->num_samples_per_block;
+    int m;
+    { const int r_ = meta_acquire(ctx, F, &m); if (r_ != LNN_OK) return r_; }
     uint32_t *idx = ctx->meta_h[m], *nsm = ctx->meta_h[m] + F;
     memset(cls, 0, sizeof(cls));
     ctx->na_max = 0;
@@ -1788,6 +1888,51 @@ done:
     return ret;
 }
 
+
+extern "C" int LINNEAmd_RicePlanDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *d_residual, const uint32_t *h_num_samples, uint32_t num_frames, uint8_t *d_plan)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->err[0] = 0;
+    if (!shape || !d_residual || !d_plan) { snprintf(ctx->err, sizeof(ctx->err), "null argument"); return LNN_INVALID_ARGUMENT; }
+    if (num_frames == 0) return LNN_OK;
+    HostShape hs;
+    int ret = shape_info(shape, &hs);
+    if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->rice_nsteps == 0) ctx->rice_nsteps = lnn_rice_k2_steps(ctx->rice_steps);
+    int m;
+    if ((ret = meta_acquire(ctx, num_frames, &m)) != LNN_OK) return ret;
+    uint32_t *nsm = ctx->meta_h[m];
+    for (uint32_t f = 0; f < num_frames; f++) {
+        const uint32_t n = h_num_samples ? h_num_samples[f] : shape->num_samples_per_block;
+        if (n == 0 || n > shape->num_samples_per_block) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
+        nsm[f] = n;
+    }
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_plan_nsmp, &ctx->plan_nsmp_cap, sizeof(uint32_t) * (uint64_t)num_frames)) != LNN_OK) return ret;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_plan_nsmp, nsm, sizeof(uint32_t) * num_frames, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->meta_ev[m], ctx->stream));
+    ctx->meta_used[m] = 1;
+    RicePlanArgs a; memset(&a, 0, sizeof(a));
+    a.resid = d_residual; a.nsmp = ctx->d_plan_nsmp; a.plan = d_plan; a.C = shape->num_channels; a.S = shape->num_samples_per_block;
+    a.nsteps = ctx->rice_nsteps;
+    for (uint32_t i = 0; i < 32; i++) a.steps[i] = ctx->rice_steps[i];
+    const uint64_t CF = (uint64_t)num_frames * shape->num_channels;
+    for (uint64_t c0 = 0; c0 < CF; ) {        /* grid.x limit: split very large batches on frame boundaries */
+        uint64_t cnt = CF - c0;
+        const uint64_t lim = (0x7FFFFFFFull / a.C) * a.C;
+        if (cnt > lim) cnt = lim;
+        RicePlanArgs b = a;
+        b.resid = d_residual + c0 * a.S; b.plan = d_plan + c0 * LINNE_AMD_RICE_PLAN_BYTES; b.nsmp = ctx->d_plan_nsmp + c0 / a.C;
+        const int sp_ = span_begin(ctx, 17, ctx->stream);
+        hipLaunchKernelGGL(k_rice_plan, dim3((uint32_t)cnt), dim3(RICE_THREADS), 0, ctx->stream, b);
+        span_end(ctx, sp_, ctx->stream);
+        c0 += cnt;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return LNN_OK;
+}
+
 /* ================================================================================================
  * staging slots: pinned host buffers + device buffers for a group of frames.  Submit enqueues H2D (copy-in
  * stream), the kernels (context stream) and D2H (copy-out stream) chained by events and returns at once, so a
@@ -1795,8 +1940,8 @@ done:
  * ============================================================================================== */
 struct LINNEAmdSlot {
     LINNEAmdContext *ctx; struct LINNEAmdShape shape; uint32_t max_frames; int for_encode;
-    int32_t *h_pcm, *h_data, *h_prm; double *h_st;
-    int32_t *d_pcm, *d_data, *d_prm; double *d_st;
+    int32_t *h_pcm, *h_data, *h_prm; double *h_st; uint8_t *h_plan;
+    int32_t *d_pcm, *d_data, *d_prm; double *d_st; uint8_t *d_plan;
     hipEvent_t ev_in, ev_k, ev_done; int pending;
 };
 
@@ -1818,6 +1963,8 @@ extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
     if (s->h_data) hipHostFree(s->h_data);
     if (s->h_prm) hipHostFree(s->h_prm);
     if (s->h_st) hipHostFree(s->h_st);
+    if (s->h_plan) hipHostFree(s->h_plan);
+    if (s->d_plan) hipFree(s->d_plan);
     if (s->d_pcm) hipFree(s->d_pcm);
     if (s->d_data) hipFree(s->d_data);
     if (s->d_prm) hipFree(s->d_prm);
@@ -1852,6 +1999,8 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx,
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_st, sb, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_pcm, nb);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_st, sb);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming);
@@ -1864,6 +2013,7 @@ extern "C" int32_t *LINNEAmd_SlotPcm(struct LINNEAmdSlot *s) { return s ? s->h_p
 extern "C" int32_t *LINNEAmd_SlotData(struct LINNEAmdSlot *s) { return s ? s->h_data : NULL; }
 extern "C" int32_t *LINNEAmd_SlotParams(struct LINNEAmdSlot *s) { return s ? s->h_prm : NULL; }
 extern "C" double *LINNEAmd_SlotStats(struct LINNEAmdSlot *s) { return s ? s->h_st : NULL; }
+extern "C" uint8_t *LINNEAmd_SlotRicePlan(struct LINNEAmdSlot *s) { return s ? s->h_plan : NULL; }
 extern "C" uint32_t LINNEAmd_SlotCapacity(const struct LINNEAmdSlot *s) { return s ? s->max_frames : 0; }
 
 extern "C" int LINNEAmd_SlotWait(struct LINNEAmdSlot *s)
@@ -1891,11 +2041,13 @@ extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t 
     HIPCHK(ctx, hipMemsetAsync(s->d_prm, 0, pb, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(s->d_st, 0, sb, ctx->stream));
     if ((ret = LINNEAmd_EncodeFramesDevice(ctx, &s->shape, s->d_pcm, num_samples, num_frames, s->d_data, s->d_prm, s->d_st)) != LNN_OK) return ret;
+    if ((ret = LINNEAmd_RicePlanDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_plan)) != LNN_OK) return ret;
     HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
     HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipMemcpyAsync(s->h_prm, s->d_prm, pb, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipMemcpyAsync(s->h_st, s->d_st, sb, hipMemcpyDeviceToHost, ctx->copy_out));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_plan, s->d_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * C * num_frames, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipEventRecord(s->ev_done, ctx->copy_out));
     s->pending = 1;
     return LNN_OK;

@@ -51,31 +51,39 @@ uint16_t lnn_crc16(const uint8_t *data, uint64_t size)
 }
 
 /* ------------------------------------------------------------------------------------------------ bits */
-/* writer: bits collect in a 64-bit accumulator and leave four bytes at a time; bw_flush pads to a byte and drains */
+/* writer: fewer than 8 bits are pending in the low end of `acc` between calls; a put appends up to 56 bits, stores the
+ * pending bits top-aligned as one big-endian 64-bit word and advances by the whole bytes among them -- no data-dependent
+ * branch (the byte-wise path is taken only within 8 bytes of the end of the buffer) */
 struct bitw { uint8_t *p, *base, *end; uint64_t acc; uint32_t n; int overflow; };
 static void bw_open(struct bitw *w, uint8_t *mem, uint64_t size) { w->p = w->base = mem; w->end = mem + size; w->acc = 0; w->n = 0; w->overflow = 0; }
-static inline void bw_byte(struct bitw *w, uint8_t b) { if (w->p < w->end) *w->p++ = b; else w->overflow = 1; }
-static inline void bw_put(struct bitw *w, uint32_t val, uint32_t nbits)
-{   /* nbits <= 32; fewer than 32 bits pending */
-    if (nbits == 0) return;
-    w->acc = (w->acc << nbits) | (uint64_t)(val & (uint32_t)(0xFFFFFFFFu >> (32u - nbits)));
-    w->n += nbits;
-    if (w->n >= 32) {
-        const uint32_t word = (uint32_t)(w->acc >> (w->n - 32));
-        w->n -= 32;
-        if (w->end - w->p >= 4) { const uint32_t be = __builtin_bswap32(word); memcpy(w->p, &be, 4); w->p += 4; }
-        else { bw_byte(w, (uint8_t)(word >> 24)); bw_byte(w, (uint8_t)(word >> 16)); bw_byte(w, (uint8_t)(word >> 8)); bw_byte(w, (uint8_t)word); }
+static inline void bw_put56(struct bitw *w, uint64_t val, uint32_t nbits)
+{   /* 1 <= nbits <= 56, val < 2^nbits */
+    uint64_t top;
+    uint32_t nbytes;
+    w->acc = (w->acc << nbits) | val;
+    w->n += nbits;                                          /* <= 63 */
+    top = w->acc << (64u - w->n);
+    nbytes = w->n >> 3;
+    if (__builtin_expect(w->end - w->p >= 8, 1)) { const uint64_t be = __builtin_bswap64(top); memcpy(w->p, &be, 8); w->p += nbytes; }
+    else {
+        uint32_t k;
+        for (k = 0; k < nbytes; k++) { if (w->p < w->end) *w->p++ = (uint8_t)(top >> (56u - 8u * k)); else w->overflow = 1; }
     }
+    w->n &= 7u;
+}
+static inline void bw_put(struct bitw *w, uint32_t val, uint32_t nbits)
+{   /* nbits <= 32 */
+    if (nbits == 0) return;
+    bw_put56(w, (uint64_t)(val & (uint32_t)(0xFFFFFFFFu >> (32u - nbits))), nbits);
 }
 static inline void bw_zero_run_then_one(struct bitw *w, uint32_t run)   /* `run` zeros, then a 1 */
 {
-    while (run >= 32) { bw_put(w, 0, 32); run -= 32; }
-    bw_put(w, 1, run + 1 > 32 ? 32 : run + 1);
+    while (run >= 32) { bw_put56(w, 0, 32); run -= 32; }
+    bw_put56(w, 1, run + 1);
 }
-static void bw_flush(struct bitw *w)
+static void bw_flush(struct bitw *w)                        /* pads the last byte with zeros */
 {
-    if (w->n & 7u) bw_put(w, 0, 8 - (w->n & 7u));
-    while (w->n >= 8) { w->n -= 8; bw_byte(w, (uint8_t)(w->acc >> w->n)); }
+    if (w->n) { const uint8_t last = (uint8_t)(w->acc << (8u - w->n)); if (w->p < w->end) *w->p++ = last; else w->overflow = 1; w->n = 0; }
 }
 static uint64_t bw_bytes(const struct bitw *w) { return (uint64_t)(w->p - w->base); }     /* after bw_flush */
 
@@ -85,6 +93,15 @@ struct bitr { const uint8_t *p, *end, *base; uint64_t win; uint32_t have; uint64
 static void br_open(struct bitr *r, const uint8_t *mem, uint64_t size) { r->p = r->base = mem; r->end = mem + size; r->win = 0; r->have = 0; r->consumed = 0; r->nbits = size * 8u; }
 static inline void br_refill(struct bitr *r)
 {
+    if (__builtin_expect(r->end - r->p >= 8, 1)) {          /* top up to at least 57 bits with one load */
+        uint64_t be;
+        uint32_t adv;
+        memcpy(&be, r->p, 8);
+        r->win |= __builtin_bswap64(be) >> r->have;
+        adv = (64u - r->have) >> 3;
+        r->p += adv; r->have += adv * 8u;
+        return;
+    }
     while (r->have <= 56) {
         const uint64_t byte = (r->p < r->end) ? *r->p : 0u;
         r->p++;
@@ -196,13 +213,25 @@ static void rice_k2_init(void)
     }
     g_k2_steps = (kmax < 32) ? kmax : 32;
 }
+uint32_t lnn_rice_k2_steps(double *steps)
+{
+    uint32_t k;
+    lnn_tables_init();
+    for (k = 0; k < g_k2_steps; k++) steps[k] = g_k2_step[k];
+    return g_k2_steps;
+}
 static inline uint32_t rice_k2_fast(double mean)
 {
-    uint32_t k = 0;
-    while (k < g_k2_steps && mean >= g_k2_step[k]) k++;
+    uint32_t k;
+    int e;
     if (!(mean >= 0.0)) return rice_k2(mean);
-    if (k < g_k2_steps && mean >= g_k2_step[k] * (1.0 - 1e-9)) return rice_k2(mean);      /* just below the next step */
-    if (k > 0 && mean <= g_k2_step[k - 1] * (1.0 + 1e-9)) return rice_k2(mean);            /* just above the last one  */
+    { uint64_t b; memcpy(&b, &mean, 8); e = (int)((b >> 52) & 0x7FFu) - 1022; }   /* frexp's exponent; the steps sit near 1.5 * 2^k */
+    k = (e < 1) ? 0u : (uint32_t)(e - 1);
+    if (k > g_k2_steps) k = g_k2_steps;
+    while (k < g_k2_steps && mean >= g_k2_step[k]) k++;
+    while (k > 0 && mean < g_k2_step[k - 1]) k--;
+    if (k < g_k2_steps && mean >= g_k2_step[k] * (1.0 - LNN_RICE_GUARD)) return rice_k2(mean);      /* just below the next step */
+    if (k > 0 && mean <= g_k2_step[k - 1] * (1.0 + LNN_RICE_GUARD)) return rice_k2(mean);            /* just above the last one  */
     return k;
 }
 /* sum over a partition of the second-stage excess ((v - 2^k1) >> k2 for v >= 2^k1): the only data-dependent part of a
@@ -216,8 +245,84 @@ static uint32_t rice_excess(const uint32_t *q, uint32_t ns, uint32_t k1pow, uint
 }
 static inline uint32_t gamma_len(uint32_t u) { return u ? (2u * ceil_log2(u + 2u) - 1u) : 1u; }
 
-struct rice_scratch { double mean[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint8_t k2[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint32_t *u; uint32_t ucap; };
+#define RICE_MAX_DISTINCT 12u
+struct rice_scratch {
+    double mean[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint8_t k2[RICE_LOG2_PARTS + 1][RICE_PARTS];
+    uint32_t prefix[RICE_MAX_DISTINCT][RICE_PARTS + 1];
+    uint32_t *u; uint32_t ucap; uint32_t *t; uint32_t tcap;
+};
+/* prefix[i] = sum over the first i finest partitions (ns samples each) of the excess under parameter k */
+__attribute__((target_clones("avx512f", "avx2", "default")))
+static void rice_excess_prefix(const uint32_t *u, uint32_t parts, uint32_t ns, uint32_t k, uint32_t *t, uint32_t *prefix)
+{
+    const uint32_t k1pow = 1u << (k + 1), n = parts * ns;
+    uint32_t s, part, acc = 0;
+    for (s = 0; s < n; s++) { const uint32_t v = u[s]; const uint32_t x = (v > k1pow) ? (v - k1pow) : 0u; t[s] = x >> k; }
+    prefix[0] = 0;
+    for (part = 0; part < parts; part++) {
+        const uint32_t *q = t + (size_t)part * ns;
+        uint32_t sum = 0;
+        for (s = 0; s < ns; s++) sum += q[s];
+        acc += sum;
+        prefix[part + 1] = acc;
+    }
+}
 
+/* writes one channel's code (linne_coder.c:281-302) for a given partition order and per-partition parameters */
+static void rice_emit(struct bitw *w, const int32_t *data, uint32_t n, uint32_t best, const uint8_t *k2s)
+{
+    uint32_t part, s;
+    {
+        const uint32_t ns = n >> best;
+        uint32_t prevk2 = 0;
+        bw_put(w, best, RICE_LOG2_PARTS);
+        for (part = 0; part < (1u << best); part++) {
+            const uint32_t k2 = k2s[part], k1 = k2 + 1, k1pow = 1u << k1, k2mask = (1u << k2) - 1u;
+            const int32_t *q = data + (size_t)part * ns;
+            if (part == 0) bw_put(w, k2, 5);
+            else {
+                const uint32_t g = zz((int32_t)k2 - (int32_t)prevk2);
+                if (g == 0) bw_put(w, 1, 1);
+                else { const uint32_t nd = ceil_log2(g + 2u); bw_put(w, 0, nd - 1); bw_put(w, g + 1, nd); }
+            }
+            prevk2 = k2;
+            {
+                /* v < 2^k1: '1' then k1 bits.  Otherwise 1 + ((v - 2^k1) >> k2) zeros, a '1', then k2 bits.  Both are one
+                 * (value, length) pair chosen without a branch; only a code longer than 56 bits takes the slow way.  The
+                 * writer's state lives in locals here: its byte stores may alias the struct, which would otherwise be
+                 * re-read after every store */
+                uint8_t *wp = w->p; uint64_t acc = w->acc; uint32_t nb = w->n;
+                uint8_t *const fast_end = (w->end - w->p >= 16) ? w->end - 16 : w->p;
+                for (s = 0; s < ns; s++) {
+                    const uint32_t v = zz(q[s]), d = v - k1pow, quot = d >> k2;
+                    const uint32_t m = 0u - (uint32_t)(v < k1pow);                       /* all ones when v < 2^k1 */
+                    const uint64_t val = (uint64_t)(((k1pow | v) & m) | (((1u << k2) | (d & k2mask)) & ~m));
+                    const uint32_t len = ((k1 + 1) & m) | ((quot + 2 + k2) & ~m);
+                    if (__builtin_expect(len > 56 || wp >= fast_end, 0)) {
+                        w->p = wp; w->acc = acc; w->n = nb;
+                        if (len > 56) { bw_zero_run_then_one(w, 1 + quot); bw_put(w, d & k2mask, k2); } else bw_put56(w, val, len);
+                        wp = w->p; acc = w->acc; nb = w->n;
+                        continue;
+                    }
+                    acc = (acc << len) | val; nb += len;
+                    { const uint64_t be = __builtin_bswap64(acc << (64u - nb)); memcpy(wp, &be, 8); }
+                    wp += nb >> 3; nb &= 7u;
+                }
+                w->p = wp; w->acc = acc; w->n = nb;
+            }
+        }
+    }
+}
+
+#ifdef LNN_PROF
+#include <x86intrin.h>
+static uint64_t g_prof[8];
+#define PROF(i) do { const uint64_t t_ = __rdtsc(); g_prof[i] += t_ - prof_t; prof_t = t_; } while (0)
+#define PROF_BEGIN uint64_t prof_t = __rdtsc()
+#else
+#define PROF(i) do { } while (0)
+#define PROF_BEGIN do { } while (0)
+#endif
 static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct rice_scratch *sc)
 {
     uint32_t max_order = 1, parts, order, part, s, best = 0, min_bits = 0xFFFFFFFFu;
@@ -225,7 +330,9 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
     uint32_t *u;
     if (sc->ucap < n) { free(sc->u); sc->u = malloc(sizeof(uint32_t) * n); sc->ucap = sc->u ? n : 0; if (!sc->u) return -1; }
     u = sc->u;
+    PROF_BEGIN;
     for (s = 0; s < n; s++) u[s] = zz(data[s]);
+    PROF(0);
     while ((n % (1u << max_order)) == 0) max_order++;
     max_order = (max_order - 1 < RICE_LOG2_PARTS) ? max_order - 1 : RICE_LOG2_PARTS;
     parts = 1u << max_order;
@@ -241,40 +348,57 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
     for (i = (int32_t)max_order - 1; i >= 0; i--)
         for (part = 0; part < (1u << i); part++)
             sc->mean[i][part] = (sc->mean[i + 1][2 * part] + sc->mean[i + 1][2 * part + 1]) / 2.0;
-    for (order = 0; order <= max_order; order++) {
-        const uint32_t ns = n >> order;
-        uint32_t prevk2 = 0, bits = 0;
-        for (part = 0; part < (1u << order); part++) {
-            const uint32_t k2 = rice_k2_fast(sc->mean[order][part]), k1 = k2 + 1, k1pow = 1u << k1;
-            const uint32_t *q = u + (size_t)part * ns;
-            sc->k2[order][part] = (uint8_t)k2;
-            bits += ns * (k2 + 2) + rice_excess(q, ns, k1pow, k2);      /* (v < 2^k1) ? k1+1 : k2+2+((v-2^k1)>>k2), k1 = k2+1 */
-            bits += part ? gamma_len(zz((int32_t)k2 - (int32_t)prevk2)) : 5u;
-            prevk2 = k2;
-        }
-        if (min_bits > bits) { min_bits = bits; best = order; }
-    }
+    PROF(1);
+    /* Code length of every partitioning.  A partition with parameter k costs ns * (k + 2) bits plus the sum of its samples'
+     * second-stage excess, and that sum is additive over sub-partitions: so the excess is evaluated once per DISTINCT k that
+     * any (order, partition) selects -- one vectorised pass over the block and a prefix sum over the finest partitions each
+     * -- and every coarser partition is a difference of two prefix entries.  (All sums are uint32 with wrap-around, like the
+     * accumulators of linne_coder.c:256-279; a difference of wrapped prefixes is the wrapped sum.) */
     {
-        const uint32_t ns = n >> best;
-        uint32_t prevk2 = 0;
-        bw_put(w, best, RICE_LOG2_PARTS);
-        for (part = 0; part < (1u << best); part++) {
-            const uint32_t k2 = sc->k2[best][part], k1 = k2 + 1, k1pow = 1u << k1, k2mask = (1u << k2) - 1u;
-            const uint32_t *q = u + (size_t)part * ns;
-            if (part == 0) bw_put(w, k2, 5);
-            else {
-                const uint32_t g = zz((int32_t)k2 - (int32_t)prevk2);
-                if (g == 0) bw_put(w, 1, 1);
-                else { const uint32_t nd = ceil_log2(g + 2u); bw_put(w, 0, nd - 1); bw_put(w, g + 1, nd); }
+        uint32_t used = 0, distinct = 0, k;
+        for (order = 0; order <= max_order; order++)
+            for (part = 0; part < (1u << order); part++) {
+                const uint32_t k2 = rice_k2_fast(sc->mean[order][part]) & 31u;
+                sc->k2[order][part] = (uint8_t)k2;
+                used |= 1u << k2;
             }
-            prevk2 = k2;
-            for (s = 0; s < ns; s++) {
-                uint32_t v = q[s];
-                if (v < k1pow) { bw_put(w, k1pow | v, k1 + 1); }         /* '1' then k1 bits */
-                else { v -= k1pow; bw_zero_run_then_one(w, 1 + (v >> k2)); bw_put(w, v & k2mask, k2); }
+        for (k = 0; k < 32; k++) distinct += (used >> k) & 1u;
+        PROF(4);
+        if (distinct <= RICE_MAX_DISTINCT) {
+            uint32_t slot_of[32], nslot = 0;
+            if (sc->tcap < n) { free(sc->t); sc->t = malloc(sizeof(uint32_t) * n); sc->tcap = sc->t ? n : 0; if (!sc->t) return -1; }
+            for (k = 0; k < 32; k++) if ((used >> k) & 1u) { slot_of[k] = nslot; rice_excess_prefix(u, parts, n / parts, k, sc->t, sc->prefix[nslot]); nslot++; }
+            PROF(5);
+            for (order = 0; order <= max_order; order++) {
+                const uint32_t ns = n >> order, sh = max_order - order;
+                uint32_t prevk2 = 0, bits = 0;
+                for (part = 0; part < (1u << order); part++) {
+                    const uint32_t k2 = sc->k2[order][part];
+                    const uint32_t *pf = sc->prefix[slot_of[k2]];
+                    bits += ns * (k2 + 2) + (pf[(part + 1) << sh] - pf[part << sh]);
+                    bits += part ? gamma_len(zz((int32_t)k2 - (int32_t)prevk2)) : 5u;
+                    prevk2 = k2;
+                }
+                if (min_bits > bits) { min_bits = bits; best = order; }
+            }
+        } else {
+            for (order = 0; order <= max_order; order++) {
+                const uint32_t ns = n >> order;
+                uint32_t prevk2 = 0, bits = 0;
+                for (part = 0; part < (1u << order); part++) {
+                    const uint32_t k2 = sc->k2[order][part], k1 = k2 + 1, k1pow = 1u << k1;
+                    const uint32_t *q = u + (size_t)part * ns;
+                    bits += ns * (k2 + 2) + rice_excess(q, ns, k1pow, k2);      /* (v < 2^k1) ? k1+1 : k2+2+((v-2^k1)>>k2), k1 = k2+1 */
+                    bits += part ? gamma_len(zz((int32_t)k2 - (int32_t)prevk2)) : 5u;
+                    prevk2 = k2;
+                }
+                if (min_bits > bits) { min_bits = bits; best = order; }
             }
         }
     }
+    PROF(2);
+    rice_emit(w, data, n, best, sc->k2[best]);
+    PROF(3);
     return 0;
 }
 
@@ -294,10 +418,28 @@ static void rice_decode(struct bitr *r, int32_t *data, uint32_t n)
         {
             const uint32_t k1 = (k2 + 1) & 31u, k1pow = 1u << k1;
             int32_t *q = data + (size_t)part * ns;
-            for (s = 0; s < ns; s++) {
-                const uint32_t quot = br_zero_run(r);
-                const uint32_t v = (quot == 0) ? br_get(r, k1) : (br_get(r, k2) + k1pow + ((quot - 1) << k2));
-                q[s] = unzz(v);
+            {   /* the reader's state lives in locals in this loop (stores to q[] do not alias it, but it keeps the window,
+                 * the count and the pointer in registers across the general-reader calls' boundaries) */
+                for (s = 0; s < ns; s++) {
+                    uint32_t z, zm, nb, low, v, len;
+                    if (r->have < 57) br_refill(r);
+                    z = (uint32_t)__builtin_clzll(r->win | 1u);
+                    if (__builtin_expect(z > 24, 0)) {      /* long zero run (or the end of the data): the general reader */
+                        const uint32_t quot = br_zero_run(r);
+                        v = (quot == 0) ? br_get(r, k1) : (br_get(r, k2) + k1pow + ((quot - 1) << k2));
+                        q[s] = unzz(v);
+                        continue;
+                    }
+                    /* z zeros and a '1', then k1 bits (z == 0) or k2 bits: at most 25 + 31 bits, all inside the window;
+                     * selected with masks, not branches (z == 0 is a coin toss) */
+                    zm = 0u - (uint32_t)(z == 0);
+                    nb = (k1 & zm) | (k2 & ~zm);
+                    low = (uint32_t)(((r->win << (z + 1)) >> 1) >> (63u - nb));
+                    v = low + ((k1pow + ((z - 1) << k2)) & ~zm);
+                    len = z + 1 + nb;
+                    r->win <<= len; r->have -= len; r->consumed += len;
+                    q[s] = unzz(v);
+                }
             }
         }
     }
@@ -358,7 +500,7 @@ uint32_t lnn_decide_block_type(const struct LINNEAmdShape *shape, const struct l
 
 /* serialises one block (linne_encoder.c:806-855); returns LNN_* and the byte count */
 static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t type, uint32_t n,
-        const int32_t *pcm, const int32_t *residual, const int32_t *params,
+        const int32_t *pcm, const int32_t *residual, const int32_t *params, const uint8_t *plan,
         uint8_t *out, uint64_t cap, uint32_t *size_out, struct rice_scratch *sc)
 {
     const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, S = shape->num_samples_per_block;
@@ -400,7 +542,13 @@ static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers
                 }
             }
         }
-        for (ch = 0; ch < C; ch++) if (rice_encode(&w, residual + (size_t)ch * S, n, sc) != 0) return LNN_NG;
+        for (ch = 0; ch < C; ch++) {
+            /* the device's plan (order + parameters) when there is one and none of its means sat in a guard band */
+            const uint8_t *pl = plan ? plan + (size_t)ch * LINNE_AMD_RICE_PLAN_BYTES : NULL;
+            if (pl && pl[1] == 0 && pl[0] <= RICE_LOG2_PARTS && (n % (1u << pl[0])) == 0)
+                rice_emit(&w, residual + (size_t)ch * S, n, pl[0], pl + LINNE_AMD_RICE_PLAN_K2);
+            else if (rice_encode(&w, residual + (size_t)ch * S, n, sc) != 0) return LNN_NG;
+        }
         bw_flush(&w);
         if (w.overflow) return LNN_INSUFFICIENT_BUFFER;
         body = bw_bytes(&w);
@@ -433,26 +581,41 @@ void lnn_parallel_for(uint32_t count, uint32_t num_threads, void (*fn)(void *arg
 }
 
 /* ---- thread pool over frames ------------------------------------------------------------------------- */
-struct pack_job {
+/* Each worker owns a contiguous range of frames and a region of the pool; it serialises its blocks back to back there.
+ * After the join the regions are copied to their places in the output, again in parallel. */
+struct pack_share {
     const struct LINNEAmdShape *shape; const struct lnn_layers *ly;
-    const int32_t *pcm, *residual, *params; const uint32_t *nsmp; const uint8_t *types;
-    uint8_t **slot; uint64_t *slot_cap; uint32_t *sizes; int *rets;
-    uint32_t first, count;
+    const int32_t *pcm, *residual, *params; const uint32_t *nsmp; const uint8_t *types, *plan;
+    uint8_t *pool, *out; uint64_t per_slot; uint32_t *sizes; int *rets;
+    uint32_t nshare; uint32_t share_first[65]; uint64_t share_dst[65];
 };
-static void *pack_worker(void *arg)
+static void pack_range(void *arg, uint32_t first, uint32_t count)
 {
-    struct pack_job *j = arg;
+    struct pack_share *j = arg;
     struct rice_scratch *sc = calloc(1, sizeof(*sc));
-    const uint64_t CS = (uint64_t)j->shape->num_channels * j->shape->num_samples_per_block;
+    const uint32_t C = j->shape->num_channels;
+    const uint64_t CS = (uint64_t)C * j->shape->num_samples_per_block;
+    uint8_t *cursor = j->pool + j->per_slot * first;
     uint32_t f;
-    for (f = j->first; f < j->first + j->count; f++) {
+    for (f = first; f < first + count; f++) {
         if (!sc) { j->rets[f] = LNN_NG; continue; }
         j->rets[f] = pack_block(j->shape, j->ly, j->types[f], j->nsmp ? j->nsmp[f] : j->shape->num_samples_per_block,
-                j->pcm + f * CS, j->residual + f * CS, j->params + (size_t)f * j->shape->num_channels * LINNE_AMD_PARAM_WORDS,
-                j->slot[f], j->slot_cap[f], &j->sizes[f], sc);
+                j->pcm + f * CS, j->residual + f * CS, j->params + (size_t)f * C * LINNE_AMD_PARAM_WORDS,
+                j->plan ? j->plan + (size_t)f * C * LINNE_AMD_RICE_PLAN_BYTES : NULL,
+                cursor, j->per_slot, &j->sizes[f], sc);
+        if (j->rets[f] == LNN_OK) cursor += j->sizes[f];
     }
-    if (sc) { free(sc->u); free(sc); }
-    return NULL;
+    if (sc) { free(sc->u); free(sc->t); free(sc); }
+}
+static void copy_range(void *arg, uint32_t first, uint32_t count)
+{
+    struct pack_share *j = arg;
+    uint32_t t, f;
+    for (t = first; t < first + count; t++) {
+        uint64_t bytes = 0;
+        for (f = j->share_first[t]; f < j->share_first[t + 1]; f++) bytes += j->sizes[f];
+        memcpy(j->out + j->share_dst[t], j->pool + j->per_slot * j->share_first[t], bytes);
+    }
 }
 
 int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
@@ -460,23 +623,30 @@ int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, c
         uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
         uint32_t num_threads)
 {
+    return LINNEAmd_PackFramesPlanned(shape, pcm, num_samples, num_frames, residual, params, stats, NULL,
+            blocks_out, blocks_capacity, block_sizes, parcor_state, num_threads);
+}
+
+int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
+        uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
+        uint32_t num_threads)
+{
     struct lnn_layers ly;
-    uint8_t *types = NULL, **slot = NULL, *pool = NULL;
-    uint64_t *slot_cap = NULL, CS, per_slot, off;
+    uint8_t *types = NULL, *pool = NULL;
+    uint64_t CS, per_slot;
     int *rets = NULL, ret = LNN_OK;
     double state = parcor_state ? *parcor_state : 0.0;
     uint32_t f, t, C;
-    pthread_t th[64];
-    struct pack_job jobs[64];
     if (!shape || !pcm || !residual || !params || !stats || !blocks_out || !block_sizes) return LNN_INVALID_ARGUMENT;
     if (lnn_shape_layers(shape, &ly) != 0) return LNN_INVALID_FORMAT;
     if (num_frames == 0) return LNN_OK;
     lnn_tables_init();
     C = shape->num_channels;
     CS = (uint64_t)C * shape->num_samples_per_block;
-    types = malloc(num_frames); slot = malloc(sizeof(*slot) * num_frames); slot_cap = malloc(sizeof(*slot_cap) * num_frames);
+    types = malloc(num_frames);
     rets = malloc(sizeof(int) * num_frames);
-    if (!types || !slot || !slot_cap || !rets) { ret = LNN_NG; goto done; }
+    if (!types || !rets) { ret = LNN_NG; goto done; }
     /* sequential pass: block types (the only cross-frame dependency, quirk Q2) */
     for (f = 0; f < num_frames; f++) {
         const uint32_t n = num_samples ? num_samples[f] : shape->num_samples_per_block;
@@ -485,38 +655,35 @@ int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, c
         if (types[f] == LNN_BLOCK_COMPRESS) state = st[(size_t)(C - 1) * LINNE_AMD_STAT_WORDS + LINNE_AMD_ST_TAIL];
     }
     if (parcor_state) *parcor_state = state;
-    /* parallel pass: serialise into private slots, then compact in order */
+    /* parallel pass: serialise into per-worker regions, then copy the regions into place */
     per_slot = 64 + CS * 8;
-    pool = malloc(per_slot * (uint64_t)((num_frames < 4096) ? num_frames : 4096));
+    pool = malloc(per_slot * (uint64_t)num_frames);
     if (!pool) { ret = LNN_NG; goto done; }
-    off = 0;
     {
-        uint32_t base;
+        struct pack_share sh;
+        uint32_t nt, first = 0;
+        uint64_t off = 0;
         if (num_threads == 0) num_threads = 1;
         if (num_threads > 64) num_threads = 64;
-        for (base = 0; base < num_frames && ret == LNN_OK; base += 4096) {
-            const uint32_t cnt = (num_frames - base < 4096) ? (num_frames - base) : 4096;
-            uint32_t first = 0, nt = (num_threads < cnt) ? num_threads : cnt;
-            for (f = 0; f < cnt; f++) { slot[base + f] = pool + per_slot * f; slot_cap[base + f] = per_slot; }
-            for (t = 0; t < nt; t++) {
-                const uint32_t c = cnt / nt + ((t < cnt % nt) ? 1u : 0u);
-                struct pack_job *j = &jobs[t];
-                j->shape = shape; j->ly = &ly; j->pcm = pcm; j->residual = residual; j->params = params; j->nsmp = num_samples;
-                j->types = types; j->slot = slot; j->slot_cap = slot_cap; j->sizes = block_sizes; j->rets = rets;
-                j->first = base + first; j->count = c; first += c;
-                if (nt == 1) pack_worker(j); else pthread_create(&th[t], NULL, pack_worker, j);
-            }
-            if (nt > 1) for (t = 0; t < nt; t++) pthread_join(th[t], NULL);
-            for (f = base; f < base + cnt; f++) {
-                if (rets[f] != LNN_OK) { ret = rets[f]; break; }
-                if (off + block_sizes[f] > blocks_capacity) { ret = LNN_INSUFFICIENT_BUFFER; break; }
-                memcpy(blocks_out + off, slot[f], block_sizes[f]);
-                off += block_sizes[f];
-            }
+        nt = (num_threads < num_frames) ? num_threads : num_frames;
+        sh.shape = shape; sh.ly = &ly; sh.pcm = pcm; sh.residual = residual; sh.params = params; sh.nsmp = num_samples;
+        sh.types = types; sh.plan = rice_plan; sh.pool = pool; sh.out = blocks_out; sh.per_slot = per_slot; sh.sizes = block_sizes; sh.rets = rets;
+        lnn_parallel_for(num_frames, nt, pack_range, &sh);
+        for (f = 0; f < num_frames; f++) if (rets[f] != LNN_OK) { ret = rets[f]; goto done; }
+        /* the shares lnn_parallel_for handed out: count / nt frames each, the first count % nt one more */
+        sh.nshare = nt;
+        for (t = 0; t < nt; t++) {
+            const uint32_t c = num_frames / nt + ((t < num_frames % nt) ? 1u : 0u);
+            sh.share_first[t] = first; sh.share_dst[t] = off;
+            for (f = first; f < first + c; f++) off += block_sizes[f];
+            first += c;
         }
+        sh.share_first[nt] = first;
+        if (off > blocks_capacity) { ret = LNN_INSUFFICIENT_BUFFER; goto done; }
+        lnn_parallel_for(nt, nt, copy_range, &sh);
     }
 done:
-    free(types); free(slot); free(slot_cap); free(rets); free(pool);
+    free(types); free(rets); free(pool);
     return ret;
 }
 

@@ -218,3 +218,33 @@ def test_whole_stream_pipeline_over_staging_slots(product, oracle, monkeypatch, 
     cut = product.decode_whole(mine[:len(mine) * 2 // 3])
     assert cut[0] == 4                                          # INSUFFICIENT_DATA
     assert np.array_equal(cut[1][:, :6 * block], x[:, :6 * block])
+
+
+@pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 24, 4096, 0, 4096), (3, 8, 1024, 2, 1000)])
+def test_device_rice_plan_equals_host_search(ctx, nch, bits, block, preset, tail):
+    """partition means, parameters and the partition-order search of the Rice coder on the device.
+    The plan must reproduce what the host's own search writes: packing with the plan == packing without it, byte for
+    byte, on music, noise and small/large residuals, full and ragged frames."""
+    import torch
+    ms = nch >= 2
+    F = 6
+    frames = music_frames(F, nch, block, bits, seed=31 + nch)
+    frames[2] = waveform("white_noise", nch, block, bits, seed=4)
+    frames[3] //= 64                                             # small residuals: low parameters
+    ns = np.full(F, block, dtype=np.uint32); ns[-1] = tail
+    frames[-1, :, tail:] = 0
+    shape = ctx.shape(nch, bits, block, preset, ms)
+    pcm = torch.from_numpy(frames).cuda()
+    res, prm, st = ctx.encode_frames(shape, pcm, ns)
+    plan = ctx.rice_plan(shape, res, ns)
+    ctx.synchronize()
+    res, prm, st, plan = res.cpu().numpy(), prm.cpu().numpy(), st.cpu().numpy(), plan.cpu().numpy()
+    a, _ = linne_amd.pack_frames(shape, frames, res, prm, st, ns, 0.0, 2)
+    b, _ = linne_amd.pack_frames(shape, frames, res, prm, st, ns, 0.0, 2, plan=plan)
+    assert a == b
+    assert (plan[:, :, 1] == 0).all()                            # no mean of these signals sits on a parameter step
+    assert (plan[:, :, 0] <= 10).all()
+    # a plan whose flag is raised is ignored (the host searches itself): same bytes again
+    plan2 = plan.copy(); plan2[:, :, 1] = 1; plan2[:, :, 16:] = 0
+    c, _ = linne_amd.pack_frames(shape, frames, res, prm, st, ns, 0.0, 2, plan=plan2)
+    assert a == c
