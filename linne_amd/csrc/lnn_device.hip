@@ -568,15 +568,168 @@ __device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uin
     }
 }
 
+/* Fast form for a block whose 64 rows share one length class with every unit length a multiple of 4 (any frame length
+ * that is a multiple of 64: the CLI's 10240-sample blocks and their usual tails): wave t of the block owns trial t of the
+ * same 64 rows.  The samples are read from HBM ONCE for all trials, coalesced (one load instruction covers 16 consecutive
+ * samples of 4 rows), and handed to the lanes through a transposed LDS tile; the stream bookkeeping (unit position, pad
+ * zones, flushes) is wave-uniform.  Same products, same chains, same order as autocorr_lane. */
+#define ACS_T 32
+template <int K, int J0, int JN, bool L0, int NT>
+__device__ __forceinline__ void autocorr_shared(const Plan &p, uint32_t layer, uint32_t cur, uint32_t row0, uint32_t nrows, uint32_t rstride,
+        uint32_t na, uint32_t wt_off, uint32_t t, uint32_t wave, uint32_t lane, double (*tile)[ACS_T][65])
+{
+    constexpr uint32_t np = K - 1, pad = (np > 4 ? np : 4);
+    constexpr int L = ((int)np + 3) / 4 * 4;               /* window lead: elements held ahead of the current step */
+    constexpr int NSLOT = (ACS_T + NT - 1) / NT;           /* load slots (64/ACS_T rows x ACS_T samples) this wave may own; ACS_T slots per tile */
+    const uint32_t u = 1u << t, n = na / u, upl = n + pad, ntiles = na / ACS_T;
+    const double *wt = p.wtab + wt_off;
+    uint32_t myrow = row0 + lane; if (myrow >= nrows) myrow = nrows - 1;
+    const bool store = (row0 + lane) < nrows;
+    double *out = p.acorr + ((size_t)myrow * rstride * LNN_MAXT + t) * LNN_ACW;
+    /* loads run two tiles ahead of the tile being consumed, in two register sets picked by the tile's parity */
+    double preA[NSLOT], preB[NSLOT], wA = 0.0, wB = 0.0, wcur = 0.0;   /* w*: Welch weights of a tile, lane j holds sample j's */
+    const uint32_t ls = lane & (ACS_T - 1u), lr = lane / ACS_T;
+    constexpr uint32_t RPS = 64 / ACS_T;                    /* rows per load slot; a tile has 64 / RPS = ACS_T slots */
+    auto issue = [&](uint32_t tile_idx, double *pre, double &wv) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NT;
+            if (k < 64 / RPS) {
+                uint32_t r = row0 + RPS * k + lr; if (r >= nrows) r = nrows - 1;
+                const uint32_t sidx = tile_idx * ACS_T + ls;
+                if (L0) pre[i] = (double)p.xint[(size_t)r * p.S + sidx] * p.scale;   /* rows are channel-frames */
+                else pre[i] = p.sig[((size_t)r * 2 + cur) * p.S + sidx];
+            }
+        }
+        wv = wt[(tile_idx * ACS_T + ls) % n];               /* the weight depends on the place inside the unit only */
+    };
+    auto commit = [&](uint32_t buf, const double *pre, double wv) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NT;
+            if (k < 64 / RPS) tile[buf][ls][RPS * k + lr] = pre[i];
+        }
+        wcur = wv;
+    };
+    auto lane_bcast = [&](double v, uint32_t src_lane) -> double {     /* wave-uniform src_lane: two v_readlane */
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)src_lane);
+        return __hiloint2double(hi, lo);
+    };
+    issue(0, preA, wA); commit(0, preA, wA);
+    __syncthreads();
+    if (ntiles > 1) issue(1, preB, wB);
+    if (ntiles > 2) issue(2, preA, wA);
+    uint32_t g_loc = 0, g_tile = 0, g_off = 0;              /* generator: place in the padded unit, tile, offset in it */
+    struct D4 { double v0, v1, v2, v3; };
+    auto next4 = [&]() -> D4 {
+        D4 d; d.v0 = 0.0; d.v1 = 0.0; d.v2 = 0.0; d.v3 = 0.0;      /* zero zone after a unit, or past the last unit */
+        if (g_loc < n && g_tile < ntiles) {                 /* four samples of the current unit */
+            const double *src = &tile[g_tile & 1u][g_off][lane];
+            d.v0 = src[0] * lane_bcast(wcur, g_off); d.v1 = src[65] * lane_bcast(wcur, g_off + 1);
+            d.v2 = src[130] * lane_bcast(wcur, g_off + 2); d.v3 = src[195] * lane_bcast(wcur, g_off + 3);
+            g_off += 4;
+            if (g_off == ACS_T) {                           /* tile used up: publish the prefetched one */
+                g_off = 0; g_tile++;
+                if (g_tile < ntiles) {                      /* odd tiles travel in set B, even ones in set A */
+                    if (g_tile & 1u) { commit(1, preB, wB); __syncthreads(); if (g_tile + 2 < ntiles) issue(g_tile + 2, preB, wB); }
+                    else             { commit(0, preA, wA); __syncthreads(); if (g_tile + 2 < ntiles) issue(g_tile + 2, preA, wA); }
+                }
+            }
+        }
+        g_loc += 4; if (g_loc >= upl) g_loc = 0;
+        return d;
+    };
+    /* This wave accumulates lags J0 .. J0+JN-1 of the trial.  The stream window is a register ring of W = L + 4 elements
+     * (w[i % W] = element i): the loop body is unrolled over one turn of the ring, so the window never moves. */
+    constexpr int W = L + 4, NG = W / 4;
+    double r[JN], w[W];
+#pragma unroll
+    for (int j = 0; j < JN; j++) r[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < L / 4; j++) { const D4 d = next4(); w[4 * j] = d.v0; w[4 * j + 1] = d.v1; w[4 * j + 2] = d.v2; w[4 * j + 3] = d.v3; }
+    uint32_t a_unit = 0, flush_pos = n, q0 = 0;
+    bool done = false;
+#pragma unroll 1
+    while (!done) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {                     /* steps q0 .. q0+3 with element q0 + i in w[(4g + i) % W] */
+            if (!done) {
+                if (q0 >= flush_pos) {                     /* in the zero zone after a unit: store its lags, restart */
+                    if (store) {
+                        double *o = out + (size_t)a_unit * K + J0;
+#pragma unroll
+                        for (int j = 0; j < JN; j++) o[j] = r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < JN; j++) r[j] = 0.0;
+                    a_unit++;
+                    flush_pos += upl;
+                    done = (a_unit == u);
+                }
+                if (!done) {
+                    const D4 d = next4();
+                    w[(4 * g + L) % W] = d.v0; w[(4 * g + L + 1) % W] = d.v1; w[(4 * g + L + 2) % W] = d.v2; w[(4 * g + L + 3) % W] = d.v3;
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++) {
+#pragma unroll
+                        for (int j = 0; j < JN; j++) r[j] += w[(4 * g + tt) % W] * w[(4 * g + tt + J0 + j) % W];
+                    }
+                    q0 += 4;
+                }
+            }
+        }
+    }
+}
+
+/* Short layers (P <= 16).  grid.x = groups of 64 rows: a row is a job, or for layer 0 a channel-frame (its input, the
+ * pre-emphasised channel, is the same for every regulariser pass, so the lags are computed once and the Levinson kernels
+ * read pass 0's copy).  A wave of the block owns 2 to 7 lags of one trial of the 64 rows (AcsWaves), ordered so that the
+ * SIMDs of the CU carry about the same number of lags. */
+template <int P> struct AcsWaves;
+template <> struct AcsWaves<16> { static constexpr int NW = 8; };
+template <> struct AcsWaves<8>  { static constexpr int NW = 5; };
+template <> struct AcsWaves<4>  { static constexpr int NW = 3; };
+template <> struct AcsWaves<2>  { static constexpr int NW = 2; };
+
 template <int P, bool L0>
-__global__ __launch_bounds__(64) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+__global__ __launch_bounds__(64 * AcsWaves<P>::NW, 4) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     using Cfg = AcCfg<P>;
-    uint32_t job = blockIdx.x * 64 + threadIdx.x;
-    const uint32_t t = blockIdx.y;
-    bool active = (job < p.J);
-    if (!active) job = 0;
-    active = active && (t < job_class(p, job).ntrials[layer]);
+    constexpr int NT = Cfg::NT, NW = AcsWaves<P>::NW;
+    __shared__ double tile[2][ACS_T][65];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t rstride = L0 ? p.R : 1u, nrows = p.J / rstride, row0 = blockIdx.x * 64;
+    uint32_t row = row0 + lane;
+    const bool inrange = row < nrows;
+    if (!inrange) row = nrows - 1;
+    const uint32_t job = row * rstride;
+    const uint32_t ci = p.cls_of_frame[(job / p.R) / p.C];
+    const uint32_t ci0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
+    const DevClass &c0 = p.cls[ci0];
+    const uint32_t na = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.na);
+    const bool fast = __all(ci == ci0) && c0.ntrials[layer] == (uint32_t)NT && (na % (4u << (NT - 1))) == 0 && (na % ACS_T) == 0;
+#define ACS_RUN(T_, K_, J0_, JN_) autocorr_shared<K_, J0_, JN_, L0, NW>(p, layer, cur, row0, nrows, rstride, na, \
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.wt_off[layer][T_]), T_, wave, lane, tile)
+    if (fast) {                                             /* every wave of the block sees the same rows: same decision */
+        if (P == 16) switch (wave) {                        /* waves w and w+4 share a SIMD: 9 / 9 / 10 / 8 lags per SIMD */
+            case 0: ACS_RUN(0, 17, 10, 7); break; case 1: ACS_RUN(0, 17, 0, 5); break;  case 2: ACS_RUN(0, 17, 5, 5); break;
+            case 3: ACS_RUN(1, 9, 0, 5); break;   case 4: ACS_RUN(4, 2, 0, 2); break;   case 5: ACS_RUN(1, 9, 5, 4); break;
+            case 6: ACS_RUN(2, 5, 0, 5); break;   default: ACS_RUN(3, 3, 0, 3); break;
+        } else if (P == 8) switch (wave) {
+            case 0: ACS_RUN(0, 9, 0, 5); break;   case 1: ACS_RUN(0, 9, 5, 4); break;   case 2: ACS_RUN(1, 5, 0, 5); break;
+            case 3: ACS_RUN(2, 3, 0, 3); break;   default: ACS_RUN(3, 2, 0, 2); break;
+        } else if (P == 4) switch (wave) {
+            case 0: ACS_RUN(0, 5, 0, 5); break;   case 1: ACS_RUN(1, 3, 0, 3); break;   default: ACS_RUN(2, 2, 0, 2); break;
+        } else switch (wave) {
+            case 0: ACS_RUN(0, 3, 0, 3); break;   default: ACS_RUN(1, 2, 0, 2); break;
+        }
+        return;
+    }
+#undef ACS_RUN
+    /* general form: the first NT waves take one whole trial each */
+    if (wave >= (uint32_t)NT) return;
+    const uint32_t t = wave;
+    const bool active = inrange && (t < job_class(p, job).ntrials[layer]);
     const uint32_t q_end = na_max + Cfg::MAXPAD + 8;
     switch (P >> t) {       /* wave-uniform: the trial fixes the number of lags */
     case 16: if (P >= 16) autocorr_lane<17, L0>(p, layer, cur, q_end, job, t, active); break;
@@ -589,10 +742,10 @@ __global__ __launch_bounds__(64) void k_autocorr_lane(Plan p, uint32_t layer, ui
 
 template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
-    using Cfg = AcCfg<P>;
-    const dim3 grid((p.J + 63) / 64, Cfg::NT);
-    if (layer == 0) hipLaunchKernelGGL((k_autocorr_lane<P, true>), grid, dim3(64), 0, st, p, layer, cur, na_max);
-    else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64), 0, st, p, layer, cur, na_max);
+    const uint32_t nrows = (layer == 0) ? p.J / p.R : p.J;
+    const dim3 grid((nrows + 63) / 64);
+    if (layer == 0) hipLaunchKernelGGL((k_autocorr_lane<P, true>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
+    else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
 }
 
 template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
@@ -632,7 +785,8 @@ __global__ void k_levinson(Plan p, uint32_t layer)
     if (np >= 16u) return;                                  /* orders >= 16 are solved by k_levinson_wave */
     const uint32_t P0 = p.P[0];
     const double reg = p.regs[job % p.R];
-    const double *r = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
+    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
     double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
     double a[LNN_MAXP + 2];
     double tail = 0.0; int tail_set = 0;
@@ -679,7 +833,8 @@ __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
     const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u, unit = pr, P0 = p.P[0];
     if (np < LEV_WAVE_MIN_ORDER) return;
     const double reg = p.regs[job % p.R];
-    const double *r = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
+    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
     double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
     const bool last = (layer + 1 == p.L);
     for (uint32_t i = lane; i <= np; i += 64) sr[i] = r[i];
