@@ -902,7 +902,7 @@ __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
 template <int MODE, bool L0>
-__global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
+__global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
     __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
@@ -947,27 +947,32 @@ __global__ __launch_bounds__(FIR_THREADS) void k_fir2(Plan p, uint32_t layer, ui
             if (whole && (np & 3u) == 0) {
                 const double *hb = hbuf + (size_t)(s / n) * np;
                 const double *xw = xc - np;                              /* -> x[s - np] */
-                double w[FIR_SPL + 4];                                   /* sliding window: x[s-np+k .. +FIR_SPL+3] */
+                /* Window x[s-np+k .. +11] in a register ring of 16 (element e lives in w[e % 16]): a step of 4 taps reads
+                 * 11 of them, the LDS reads of the next step's 4 new samples and coefficients land in the free quarter
+                 * while the 32 multiply-adds of this step issue, and nothing is ever moved. */
+                double w[16];
+                static_assert(FIR_SPL == 8, "the ring below is laid out for 8 samples per lane");
 #pragma unroll
-                for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
+                for (int j = 0; j < 12; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
 #pragma unroll
                 for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE != 1) ? xc[j] : 0.0;
-                /* software pipeline: the LDS reads of step k+4 are issued before the 32 MACs of step k */
-                lnn_d2 n0 = *(const lnn_d2 *)(xw + FIR_SPL), n1 = *(const lnn_d2 *)(xw + FIR_SPL + 2);
-                lnn_d2 h01 = *(const lnn_d2 *)(hb), h23 = *(const lnn_d2 *)(hb + 2);
-                for (uint32_t k = 0; k < np; k += 4) {
-                    w[FIR_SPL] = n0.x; w[FIR_SPL + 1] = n0.y; w[FIR_SPL + 2] = n1.x; w[FIR_SPL + 3] = n1.y;
-                    const double hh[4] = { h01.x, h01.y, h23.x, h23.y };
-                    n0 = *(const lnn_d2 *)(xw + k + 4 + FIR_SPL); n1 = *(const lnn_d2 *)(xw + k + 4 + FIR_SPL + 2);   /* in bounds: xs/hs are padded */
-                    h01 = *(const lnn_d2 *)(hb + k + 4); h23 = *(const lnn_d2 *)(hb + k + 6);
-#pragma unroll
-                    for (int kk = 0; kk < 4; kk++) {
-#pragma unroll
-                        for (int j = 0; j < FIR_SPL; j++) acc[j] += hh[kk] * w[kk + j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < FIR_SPL; j++) w[j] = w[j + 4];
+                lnn_d2 ha0 = *(const lnn_d2 *)(hb), ha1 = *(const lnn_d2 *)(hb + 2), hb0, hb1;
+                uint32_t k = 0;
+#define FIR_STEP(G, HC0, HC1, HN0, HN1) { \
+                    const lnn_d2 na_ = *(const lnn_d2 *)(xw + k + 12), nb_ = *(const lnn_d2 *)(xw + k + 14);   /* in bounds: xs/hs are padded */ \
+                    HN0 = *(const lnn_d2 *)(hb + k + 4); HN1 = *(const lnn_d2 *)(hb + k + 6); \
+                    w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y; \
+                    const double hh_[4] = { HC0.x, HC0.y, HC1.x, HC1.y }; \
+                    _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
+                        _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) acc[j] += hh_[kk] * w[(4 * G + kk + j) % 16]; } \
+                    k += 4; }
+                for (;;) {
+                    FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
+                    FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
+                    FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
+                    FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
                 }
+#undef FIR_STEP
             } else if (whole && np <= 2) {
                 const double *hb = hbuf + (size_t)(s / n) * np;
                 const double h0 = hb[0];
