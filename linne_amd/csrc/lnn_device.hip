@@ -292,7 +292,7 @@ template <int P> struct AcCfg {
     static constexpr int T = (P >= 32) ? 60 : 20;                       /* tile: padded positions per LDS refill */
     static constexpr int lanes(int t) { return ((P >> t) + 1 + K - 1) / K; }
     static constexpr int halo(int t) { return K * lanes(t) + K; }       /* furthest window read past a group start, +1 */
-    static constexpr int rb(int t) { return ((T + halo(t) + 2 * K - 1) / (2 * K)) * (2 * K); }   /* ring length, multiple of 2K */
+    static constexpr int rb(int t) { return ((T + halo(t) + 3 + 4 * K - 1) / (4 * K)) * (4 * K); }   /* ring length, multiple of 2K and of 4 */
     static constexpr int lpj() { int s = 0; for (int t = 0; t < NT; t++) s += lanes(t); return s; }
     static constexpr int ringsum() { int s = 0; for (int t = 0; t < NT; t++) s += rb(t); return s; }
     static constexpr int maxpad() { int m = 0; for (int t = 0; t < NT; t++) { const int p = P >> t, z = p > 4 ? p : 4, v = (1 << t) * z; if (v > m) m = v; } return m; }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
 {
     using Cfg = AcCfg<P>;
     constexpr int K = Cfg::K, NT = Cfg::NT, T = Cfg::T;
-    __shared__ double ring[Cfg::JPW * Cfg::RINGSUM];
+    __shared__ __attribute__((aligned(16))) double ring[Cfg::JPW * Cfg::RINGSUM];
     const uint32_t lane = threadIdx.x;
 
     /* ---- accumulate role: (job, trial, lag group) ---- */
@@ -377,6 +377,42 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
         }
     }
 
+    /* Fast generator: when every stream of the wave has unit and padded-unit lengths that are multiples of 4 (always for
+     * frame lengths that are multiples of 4 * 128), a generator lane produces 4 consecutive stream positions at a time --
+     * they never straddle a unit end or the ring end -- with 16-byte loads and stores; the bookkeeping per element drops
+     * to a quarter.  Same products in the same places; the choice is per wave and holds for the whole kernel. */
+    const bool fastgen = __all(!gen || (((g_n | g_upl) & 3u) == 0));
+    if (fastgen && gen) {
+        const uint32_t sub = lane % Cfg::GL;
+        g_halo = (g_halo + 3u) & ~3u;
+        g_q = 4 * sub; g_loc = 4 * sub; g_pos = (int32_t)(4 * sub); g_unit = 0; g_ubase = 0;
+        while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+    }
+    constexpr uint32_t GSTEP4 = 4 * Cfg::GL;
+    constexpr int E4 = (T + 4 * Cfg::GL - 1) / (4 * Cfg::GL);
+    auto gen_advance4 = [&]() {
+        g_q += GSTEP4; g_loc += GSTEP4;
+        while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+    };
+    struct Q4 { double v[4]; };
+    auto gen_fetch4 = [&](uint32_t si) -> Q4 {          /* si is a multiple of 4: 16-byte aligned pieces */
+        Q4 q;
+        if (L0) { const int4 iv = *(const int4 *)(g_xi + si); q.v[0] = (double)iv.x * p.scale; q.v[1] = (double)iv.y * p.scale; q.v[2] = (double)iv.z * p.scale; q.v[3] = (double)iv.w * p.scale; }
+        else { const lnn_d2 a = *(const lnn_d2 *)(g_xd + si), b = *(const lnn_d2 *)(g_xd + si + 2); q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y; }
+        return q;
+    };
+    auto gen_weight4 = [&](uint32_t loc) -> Q4 {
+        Q4 q; const lnn_d2 a = *(const lnn_d2 *)(g_wt + loc), b = *(const lnn_d2 *)(g_wt + loc + 2);
+        q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y; return q;
+    };
+    auto gen_store4 = [&](const Q4 &x, const Q4 &wq, bool in_unit) {
+        lnn_d2 a, b;
+        a.x = in_unit ? x.v[0] * wq.v[0] : 0.0; a.y = in_unit ? x.v[1] * wq.v[1] : 0.0;
+        b.x = in_unit ? x.v[2] * wq.v[2] : 0.0; b.y = in_unit ? x.v[3] * wq.v[3] : 0.0;
+        *(lnn_d2 *)(ring + g_base + g_pos) = a; *(lnn_d2 *)(ring + g_base + g_pos + 2) = b;
+        g_pos += (int32_t)GSTEP4; if (g_pos >= g_rb) g_pos -= g_rb;
+    };
+
     /* per-lane accumulate state */
     double r[K], w[K];
 #pragma unroll
@@ -404,7 +440,15 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
     auto gen_fetch = [&](uint32_t si) -> double { return L0 ? ((double)g_xi[si] * p.scale) : g_xd[si]; };
 
     /* initial fill: padded positions [0, T + halo) */
-    if (gen) {
+    if (gen && fastgen) {
+        const uint32_t lim = T + g_halo;
+        while (g_q < lim) {
+            const bool in_unit = (g_unit < g_u) && (g_loc < g_n);
+            const Q4 x = gen_fetch4(in_unit ? (g_ubase + g_loc) : 0u), wq = gen_weight4(in_unit ? g_loc : 0u);
+            gen_store4(x, wq, in_unit);
+            gen_advance4();
+        }
+    } else if (gen) {
         const uint32_t lim = T + g_halo;
         while (g_q < lim) {
             double v = 0.0;
@@ -426,7 +470,19 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
         /* prefetch the samples of the NEXT refill (positions [tile0 + T + halo, tile0 + 2T + halo)) into registers;
          * their latency hides behind this tile's accumulation */
         double fx[E], fw[E]; uint32_t floc[E];
-        {
+        Q4 qx[E4], qw[E4]; uint32_t qin[E4];                /* fast generator: 0 = not mine, 1 = zero zone, 2 = samples */
+        if (fastgen) {
+            const uint32_t lim = tile0 + 2 * T + g_halo;
+#pragma unroll
+            for (int e = 0; e < E4; e++) {
+                const bool in_range = gen && (g_q < lim);
+                const bool in_unit = in_range && (g_unit < g_u) && (g_loc < g_n);
+                qin[e] = in_unit ? 2u : (in_range ? 1u : 0u);
+                qx[e] = gen_fetch4(in_unit ? (g_ubase + g_loc) : 0u);
+                qw[e] = gen_weight4(in_unit ? g_loc : 0u);
+                if (in_range) gen_advance4();
+            }
+        } else {
             const uint32_t lim = tile0 + 2 * T + g_halo;
 #pragma unroll
             for (int e = 0; e < E; e++) {           /* straight-line: E independent loads in flight */
@@ -476,7 +532,10 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
             }
         }
         __syncthreads();
-        if (gen) {
+        if (fastgen) {
+#pragma unroll
+            for (int e = 0; e < E4; e++) if (qin[e]) gen_store4(qx[e], qw[e], qin[e] == 2u);
+        } else if (gen) {
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 if (floc[e] != 0xFFFFFFFFu) {
@@ -882,6 +941,81 @@ __global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
         for (uint32_t k = lane; k < np; k += 64) h[k] = sa[np - k];
     }
     if (last && lane == 0) {
+        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
+        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
+    }
+}
+
+/* Levinson-Durbin for the large problems (order >= 16), lanes = jobs: a wavefront solves the SAME (trial, unit) problem of 64
+ * consecutive jobs, each lane running the scalar recursion of `levinson` above on its own column of two LDS arrays
+ * (a[i][lane], r[i][lane]: conflict-free 8-byte accesses).  Every wave instruction therefore advances 64 problems; the
+ * ordered sum a[0]r[k+1] + ... + a[k]r[1] (lpc.c:295-297) is one chain per lane.  grid = (job groups, units of the trial). */
+__global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uint32_t t)
+{
+    extern __shared__ __attribute__((aligned(16))) double lev_lds[];
+    const uint32_t lane = threadIdx.x, unit = blockIdx.y;
+    uint32_t job = blockIdx.x * 64 + lane;
+    const bool inrange = job < p.J;
+    if (!inrange) job = p.J - 1;
+    const DevClass &c = job_class(p, job);
+    const uint32_t P = p.P[layer], u = 1u << t, np = P >> t, P0 = p.P[0];
+    const bool have = inrange && t < c.ntrials[layer];
+    const uint32_t n = c.na / u;
+    double *sa = lev_lds + lane, *sr = lev_lds + (size_t)(np + 2) * 64 + lane;      /* element i at [i * 64] */
+    const double reg = p.regs[job % p.R];
+    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
+    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    const bool last = (layer + 1 == p.L);
+    for (uint32_t i = 0; i <= np; i++) sr[(size_t)i * 64] = have ? r[i] : 0.0;
+    for (uint32_t i = 0; i < np + 2; i++) sa[(size_t)i * 64] = 0.0;
+    double tail = 0.0; int tail_set = 0;
+    const double r0 = sr[0] * (1.0 + reg);                    /* lpc.c:358 */
+    const bool zero = (n < np) || (fabs(r0) < (double)FLT_EPSILON);      /* lpc.c:349-355, 271-276 */
+    {   /* lanes with a zero problem (or none) run along on values nobody reads */
+        const double r1 = sr[64];
+        double ek = r0;
+        const double a1 = -r1 / r0;
+        ek += r1 * a1;
+        sa[0] = 1.0; sa[64] = a1;
+        for (uint32_t k = 1; k < np; k++) {
+            double gamma = 0.0;
+            {
+                const double *pa = sa, *pr = sr + (size_t)(k + 1) * 64;
+                uint32_t i = 0;
+                for (; i + 4 <= k + 1; i += 4) {                /* four terms per trip, reads ahead of the adds */
+                    const double a0 = pa[0], a1_ = pa[64], a2 = pa[128], a3 = pa[192];
+                    const double q0 = pr[0], q1 = *(pr - 64), q2 = *(pr - 128), q3 = *(pr - 192);
+                    gamma += a0 * q0; gamma += a1_ * q1; gamma += a2 * q2; gamma += a3 * q3;
+                    pa += 256; pr -= 256;
+                }
+                for (; i <= k; i++) { gamma += pa[0] * pr[0]; pa += 64; pr -= 64; }
+            }
+            gamma /= -ek;
+            ek *= (1.0 - gamma * gamma);
+            const double a0n = 1.0 + gamma * 0.0;              /* u[0]   + gamma*v[0]   */
+            const double ak1 = 0.0 + gamma * 1.0;              /* u[k+1] + gamma*v[k+1] */
+            uint32_t i = 1, j = k;
+            while (i < j) {
+                const double ai = sa[(size_t)i * 64], aj = sa[(size_t)j * 64];
+                sa[(size_t)i * 64] = ai + gamma * aj;
+                sa[(size_t)j * 64] = aj + gamma * ai;
+                i++; j--;
+            }
+            if (i == j) { const double ai = sa[(size_t)i * 64]; sa[(size_t)i * 64] = ai + gamma * ai; }
+            sa[0] = a0n; sa[(size_t)(k + 1) * 64] = ak1;
+            if (last && k == P0) { tail = -gamma; tail_set = 1; }
+        }
+    }
+    if (!have) return;
+    if (zero) {
+        for (uint32_t k = 0; k < np; k++) h[k] = 0.0;
+        tail = 0.0; tail_set = (np >= P0) ? 1 : 0;             /* zero branches write parcor[0..order] */
+    } else {
+        for (uint32_t k = 0; k < np; k++) h[k] = sa[(size_t)(np - k) * 64];
+        if (!(last && np > P0)) { tail = 0.0; tail_set = 0; }
+    }
+    if (last) {
         p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
         p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
     }
@@ -1561,6 +1695,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
         ctx->has_side = (ctx->nsub > 0) && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
     }
+    (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * (2 * LNN_MAXP + 3)));
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
     return ctx;
@@ -1761,7 +1896,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
                         c.trial_u[l][nt] = u;
                         c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
                         c.wt_off[l][nt] = (uint32_t)wt_total;
-                        { const uint32_t pu = hs->P[l] / u; wt_total += na / u + (pu > 4 ? pu : 4); }
+                        { const uint32_t pu = hs->P[l] / u; wt_total += na / u + (pu > 4 ? pu : 4); wt_total = (wt_total + 3u) & ~(uint64_t)3u; }   /* tables start 32-byte aligned */
                         nt++;
                     }
                     c.ntrials[l] = nt;
@@ -1928,7 +2063,12 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             }
             { const int sp_ = span_begin(ctx, 4, st);
               uint32_t nbig = 0; for (uint32_t u = 1; u <= maxu && hs.P[l] / u >= 16u; u <<= 1) nbig += u;
-              if (nbig) hipLaunchKernelGGL(k_levinson_wave, dim3(nbig, (uint32_t)J), dim3(64), 0, st, p, l);
+              (void)nbig;
+              for (uint32_t t = 0, u = 1; u <= maxu && hs.P[l] / u >= LEV_WAVE_MIN_ORDER; u <<= 1, t++) {
+                  const uint32_t np = hs.P[l] / u;
+                  const size_t lds = sizeof(double) * 64 * (size_t)(2 * np + 3);
+                  hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
+              }
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
