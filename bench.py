@@ -32,7 +32,8 @@ ALGO_BYTES_PER_CF = 82552           # 40960 in + 40960 out + 632 pa
 MAC_PER_CF_REFERENCE = 46.2e6       # as written in the reference (-m 7, N = 10240)
 MAC_PER_CF_EXECUTED = 30.7e6        # bit-exact de-duplicated schedule this build runs
 HBM_PEAK_GBS = 8000.0
-FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it
+FP64_PEAK_TFLOPS = 78.6
+FP64_UNFUSED_MEASURED_TFLOPS = 32.4     # profiles/r01_dp_rate.txt             # vector FMA peak; unfused mul+add tops out at half of it
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson(+_wave)", 5: "k_fir2<2,false>",
                 15: "k_fir2<2,true>", 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false>", 16: "k_fir2<1,true>",
@@ -269,7 +270,11 @@ def main():
                     "note": "algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64"}
         cf_per_s = enc_fps * nch / world        # per GPU
         valu = {"executed_tflops": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12, "reference_equiv_tflops": 2 * MAC_PER_CF_REFERENCE * cf_per_s / 1e12,
-                "peak_fma_tflops": FP64_PEAK_TFLOPS, "frac_of_unfused_peak": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / (FP64_PEAK_TFLOPS / 2)}
+                "peak_fma_tflops": FP64_PEAK_TFLOPS, "frac_of_unfused_peak": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / (FP64_PEAK_TFLOPS / 2),
+                "measured_unfused_mul_add_tflops": FP64_UNFUSED_MEASURED_TFLOPS,
+                "frac_of_measured_unfused": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / FP64_UNFUSED_MEASURED_TFLOPS,
+                "note": "the bit-exact path may not fuse multiply and add; tools/ubench/dp_rate.hip sustains 32.4 TFLOP/s of unfused "
+                        "FP64 mul+add on this GPU (profiles/r01_dp_rate.txt), 63 with FMA"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))

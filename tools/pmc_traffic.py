@@ -1,0 +1,36 @@
+"""HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md
+prescribes) of tools/kbench.py --frames F: writes profiles/pmc_latest.json.  Counters are KiB; FETCH_SIZE is doubled
+(gfx950 reports half of the bytes of wide coalesced reads); WRITE_SIZE is used as is.
+usage: pmc_traffic.py fetch.csv write.csv frames channels"""
+import csv, json, sys, collections
+fetch_csv, write_csv, frames, channels = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
+KIND = [("k_fir2<2, false>", "k_fir2<2,false>"), ("k_fir2<2, true>", "k_fir2<2,true>"), ("k_fir2<1, false>", "k_fir2<1,false>"), ("k_fir2<1, true>", "k_fir2<1,true>"),
+        ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson(+_wave)"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"),
+        ("k_synthesize", "k_synthesize"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan")]
+def load(path, counter):
+    per = collections.defaultdict(dict)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            per[int(r["Dispatch_Id"])] = (r["Kernel_Name"], float(r["Counter_Value"]))
+    return per
+f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+out = {"_source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on tools/kbench.py --frames {frames} "
+       f"({frames * channels} channel-frames); counters are KiB; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; "
+       "per kernel kind: all launches of one encode call summed, then divided by the launches and by the channel-frames of a launch"}
+def collect(per):
+    agg = collections.defaultdict(list)
+    for _, (name, val) in sorted(per.items()):
+        for sub, kind in KIND:
+            if sub in name:
+                agg[kind].append(val); break
+    return agg
+fa, wa = collect(f), collect(w)
+for kind in fa:
+    fk, wk = fa[kind], wa.get(kind, [0.0] * len(fa[kind]))
+    n = len(fk)
+    bytes_total = (2.0 * sum(fk) + sum(wk)) * 1024.0
+    out[kind] = {"launches_sampled": n, "fetch_kib_raw": [int(v) for v in fk], "write_kib": [int(v) for v in wk],
+                 "hbm_bytes_per_channel_frame_per_launch": int(bytes_total / n / (frames * channels))}
+json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
+for k, v in out.items():
+    if not k.startswith("_"): print(k, v["launches_sampled"], v["hbm_bytes_per_channel_frame_per_launch"])
