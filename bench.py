@@ -32,8 +32,8 @@ ALGO_BYTES_PER_CF = 82552           # 40960 in + 40960 out + 632 pa
 MAC_PER_CF_REFERENCE = 46.2e6       # as written in the reference (-m 7, N = 10240)
 MAC_PER_CF_EXECUTED = 30.7e6        # bit-exact de-duplicated schedule this build runs
 HBM_PEAK_GBS = 8000.0
-FP64_PEAK_TFLOPS = 78.6
-FP64_UNFUSED_MEASURED_TFLOPS = 32.4     # profiles/r01_dp_rate.txt             # vector FMA peak; unfused mul+add tops out at half of it
+FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
+FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson(+_wave)", 5: "k_fir2<2,false>",
                 15: "k_fir2<2,true>", 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false>", 16: "k_fir2<1,true>",
