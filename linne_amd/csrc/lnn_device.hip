@@ -1042,7 +1042,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
     __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
     __shared__ __attribute__((aligned(16))) double ob[(MODE == 2) ? 1 : FIR_THREADS / 64][(MODE == 2) ? 2 : 64 * FIR_SPL];   /* per-wave store transpose (MODE 0/1) */
     __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
-    const uint32_t job = blockIdx.y, tid = threadIdx.x;
+    const uint32_t job = blockIdx.x, tid = threadIdx.x;          /* grid = (jobs, tiles): the job count is not bound by 65535 */
     if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
         for (uint32_t i = tid; i < ntr * LNN_MAXP; i += FIR_THREADS) { const uint32_t tt = i / LNN_MAXP, k = i % LNN_MAXP; if (k < P) hs[tt][k] = hsrc[i]; }
     }
     /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
-    for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.x * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
+    for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.y * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
     __syncthreads();
     if (!L0 && s0 >= LNN_MAXP && s0 + FIR_TILE + 8 <= na) {          /* interior tile: 16-byte loads (S, s0, MAXP are even) */
         for (uint32_t i = 2 * tid; i < LNN_MAXP + FIR_TILE + 8; i += 2 * FIR_THREADS)
@@ -1148,7 +1148,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
             }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
-            if ((tid & 63u) == 0) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.x * (FIR_THREADS / 64) + (tid >> 6)] = ps;
+            if ((tid & 63u) == 0) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
         } else if (MODE == 0) {
             /* exact path: the tile's |residual| values go to LDS in sample order and ONE lane adds them to the trial's
              * running sum, continuing the single chain of linne_network.c:326-337 across tiles */
@@ -1512,7 +1512,7 @@ __global__ __launch_bounds__(64) void k_synthesize(DecPlan p)
 /* MS -> LR (linne_utility.c:135-147) */
 __global__ void k_ms_to_lr(DecPlan p)
 {
-    const uint32_t f = blockIdx.y, s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t f = blockIdx.x, s = blockIdx.y * blockDim.x + threadIdx.x;      /* grid = (frames, sample tiles) */
     if (s >= p.nsmp[f]) return;
     int32_t *m = p.data + (size_t)f * p.C * p.S, *sd = m + p.S;
     const uint32_t l = (uint32_t)m[s] - (uint32_t)(sd[s] >> 1);
@@ -1683,7 +1683,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     if ((e = hipMalloc((void **)&ctx->d_ucount, sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
     {
         const char *env = getenv("LINNE_AMD_STREAMS");
-        int ns = env ? atoi(env) : 1;
+        int ns = env ? atoi(env) : 2;
         if (ns < 1) ns = 1;
         if (ns > LNN_MAXSUB) ns = LNN_MAXSUB;
         ctx->nsub = 0;
@@ -1997,14 +1997,14 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     }
     /* frame groups ("chunks") rotate over nsub streams, each with its own slice of the arena */
     uint32_t nsub = ctx->nsub > 0 ? (uint32_t)ctx->nsub : 1u;
-    while (nsub > 1 && ((ctx->arena_bytes - 65536) / nsub < per_frame * 2 || num_frames < nsub * 64u)) nsub--;
+    while (nsub > 1 && ((ctx->arena_bytes - 65536) / nsub < per_frame * 2 || num_frames < nsub * 512u)) nsub--;
     const uint64_t part_bytes = ((ctx->arena_bytes - 65536) / nsub) & ~(uint64_t)255;
     uint64_t chunk = part_bytes / per_frame;
     if (chunk == 0) chunk = 1;
-    {   /* even split over the streams; grid.y / grid.z carry the job index: J = chunk * C * R must stay below 65536 */
+    {   /* even split over the streams; every kernel carries the job index in grid.x: J = chunk * C * R is kept below 2^22 */
         const uint64_t even = (num_frames + nsub - 1) / nsub;
         if (chunk > even) chunk = even;
-        const uint64_t lim = 65535u / ((uint64_t)C * hs.R);
+        const uint64_t lim = 4194304u / ((uint64_t)C * hs.R);
         if (chunk > lim) chunk = lim;
     }
     ctx->nspans = 0;
@@ -2070,12 +2070,12 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
               }
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
-            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true>), dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false>), dim3(1, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur);
+            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : 8, st); if (l == 0) hipLaunchKernelGGL((k_fir2<1, true>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<1, false>), dim3((S + FIR_TILE - 1) / FIR_TILE, (uint32_t)J), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : 8, st); if (l == 0) hipLaunchKernelGGL((k_fir2<1, true>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<1, false>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
         { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
@@ -2110,7 +2110,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     if (p.ms)
-        { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3((p.S + 255) / 256, num_frames), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
+        { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3(num_frames, (p.S + 255) / 256), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }
     return LNN_OK;
