@@ -248,3 +248,42 @@ def test_device_rice_plan_equals_host_search(ctx, nch, bits, block, preset, tail
     plan2 = plan.copy(); plan2[:, :, 1] = 1; plan2[:, :, 16:] = 0
     c, _ = linne_amd.pack_frames(shape, frames, res, prm, st, ns, 0.0, 2, plan=plan2)
     assert a == c
+
+
+def test_own_cli_matches_the_reference_cli(tmp_path):
+    """tools/cli (own WAV reader/writer, own option parsing) on liblinne_amd.so: the .lnn it writes -- whole-stream and
+    block-at-a-time -- equals the reference CLI's byte for byte, decoding gives the reference's WAV, and --batch runs
+    several files through one handle (BASELINE config 4's many-track use)"""
+    import os
+    import shutil
+    import subprocess
+    from refs import ROOT
+    cli, refcli = os.path.join(ROOT, "linne_amd", "linne_amd_cli"), os.path.join(ROOT, "oracle", "_ref", "linne_ref")
+    if not (os.path.exists(cli) and os.path.exists(refcli)):
+        pytest.skip("CLI binaries not built")
+    wav = os.path.join(ROOT, "tests", "golden", "ref_16bit_2ch.wav")
+    wav2 = os.path.join(ROOT, "tests", "golden", "ref_a.wav")
+    ref_lnn, mine, mine_b = str(tmp_path / "ref.lnn"), str(tmp_path / "mine.lnn"), str(tmp_path / "mine_b.lnn")
+    subprocess.run([refcli, "-e", "-m", "7", wav, ref_lnn], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([cli, "-e", "-m", "7", wav, mine], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([cli, "-e", "--mode=7", "-B", "-q", wav, mine_b], check=True, stdout=subprocess.DEVNULL)
+    want = open(ref_lnn, "rb").read()
+    assert open(mine, "rb").read() == want and open(mine_b, "rb").read() == want
+    ref_wav, my_wav = str(tmp_path / "ref.wav"), str(tmp_path / "mine.wav")
+    subprocess.run([refcli, "-d", ref_lnn, ref_wav], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run([cli, "-d", mine, my_wav], check=True, stdout=subprocess.DEVNULL)
+    assert open(my_wav, "rb").read() == open(ref_wav, "rb").read()
+    # batch: two different files (different formats) through one encoder handle, then one decoder handle
+    out = tmp_path / "batch"; out.mkdir()
+    shutil.copy(wav, tmp_path / "one.wav"); shutil.copy(wav2, tmp_path / "two.wav")
+    subprocess.run([cli, "-e", "-m", "5", "-q", "--batch", str(out), str(tmp_path / "one.wav"), str(tmp_path / "two.wav")], check=True)
+    for name, src in (("one", wav), ("two", wav2)):
+        r = str(tmp_path / (name + "_ref.lnn"))
+        subprocess.run([refcli, "-e", "-m", "5", src, r], check=True, stdout=subprocess.DEVNULL)
+        assert (out / (name + ".lnn")).read_bytes() == open(r, "rb").read(), name
+    back = tmp_path / "back"; back.mkdir()
+    subprocess.run([cli, "-d", "-q", "--batch", str(back), str(out / "one.lnn"), str(out / "two.lnn")], check=True)
+    for name in ("one", "two"):
+        r = str(tmp_path / (name + "_ref.wav"))
+        subprocess.run([refcli, "-d", str(out / (name + ".lnn")), r], check=True, stdout=subprocess.DEVNULL)
+        assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
