@@ -1032,6 +1032,24 @@ __global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uin
  * chain in increasing tap order.  Lanes whose 4 samples touch the start of the frame (taps are skipped there),
  * a unit boundary of a ragged tail frame, or p < 4 take the sample-at-a-time path.
  * ---------------------------------------------------------------------------------------------- */
+/* order-free sum of one double per lane over the wavefront, result in lane 63 (DPP row shifts / broadcasts on the two
+ * halves of the value: no LDS round trip, unlike __shfl_xor).  Only for sums whose order is free (the certified search). */
+__device__ __forceinline__ double wave_sum_f64_lane63(double v)
+{
+#define LNN_DPP_ADD(CTRL, ROWMASK) { \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true); \
+        v += __hiloint2double(hi_, lo_); }
+    LNN_DPP_ADD(0x111, 0xf)   /* row_shr:1 */
+    LNN_DPP_ADD(0x112, 0xf)   /* row_shr:2 */
+    LNN_DPP_ADD(0x114, 0xf)   /* row_shr:4 */
+    LNN_DPP_ADD(0x118, 0xf)   /* row_shr:8 */
+    LNN_DPP_ADD(0x142, 0xa)   /* row_bcast:15 -> rows 1, 3 */
+    LNN_DPP_ADD(0x143, 0xc)   /* row_bcast:31 -> rows 2, 3 */
+#undef LNN_DPP_ADD
+    return v;
+}
+
 #define FIR_THREADS 256
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
@@ -1146,9 +1164,8 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
 #pragma unroll
                 for (int j = 0; j < FIR_SPL; j++) if (s + j < na) ps += acc[j];
             }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) ps += __shfl_xor(ps, o);
-            if ((tid & 63u) == 0) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
+            ps = wave_sum_f64_lane63(ps);
+            if ((tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
         } else if (MODE == 0) {
             /* exact path: the tile's |residual| values go to LDS in sample order and ONE lane adds them to the trial's
              * running sum, continuing the single chain of linne_network.c:326-337 across tiles */
@@ -1683,7 +1700,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     if ((e = hipMalloc((void **)&ctx->d_ucount, sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
     {
         const char *env = getenv("LINNE_AMD_STREAMS");
-        int ns = env ? atoi(env) : 2;
+        int ns = env ? atoi(env) : 1;
         if (ns < 1) ns = 1;
         if (ns > LNN_MAXSUB) ns = LNN_MAXSUB;
         ctx->nsub = 0;
