@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames-per-thread", type=int, default=128)
     ap.add_argument("--scratch-gib", type=float, default=24.0)
+    ap.add_argument("--channels", type=int, default=2, help="other BASELINE configs, e.g. configs[4]: --channels 8 --bits 24 --rate 96000")
+    ap.add_argument("--bits", type=int, default=16)
+    ap.add_argument("--rate", type=int, default=44100)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -166,7 +169,7 @@ def main():
             dist.init_process_group(backend=backend)
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    nch, bits, block, rate, ms = 2, 16, 10240, 44100, True
+    nch, bits, block, rate, ms = args.channels, args.bits, 10240, args.rate, args.channels >= 2
     ns_total = int(round(args.minutes * 60 * rate))
     track = synth_track(ns_total, nch, bits, seed=rank, device=dev)
     frames, nsm = frames_from_track(track, block)
@@ -285,8 +288,8 @@ def main():
             "value": enc_fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": enc_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"encode -m {args.preset}: {args.minutes:g} min 44.1 kHz int16 stereo per GPU = {F} frames of {block} samples "
-                                   f"(tail {int(nsm[-1])}), MS on, PCM resident in HBM; decode = inverse hot path on the encode output",
+            "config": {"workload": f"encode -m {args.preset}: {args.minutes:g} min {rate / 1000:g} kHz int{bits} {nch}-channel per GPU = {F} frames of {block} samples "
+                                   f"(tail {int(nsm[-1])}), MS {'on' if ms else 'off'}, PCM resident in HBM; decode = inverse hot path on the encode output",
                        "frames_per_gpu": F, "channels": nch, "preset": args.preset, "sharding": f"{world} independent track(s), one per GPU"},
             "decode_frames_per_s": dec_fps, "decode_ms_per_step": dec_s / args.steps * 1e3, "decode_bit_exact": ok,
             "encode_channel_frames_per_s": enc_fps * nch,

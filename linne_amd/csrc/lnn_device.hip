@@ -113,6 +113,7 @@ __device__ void levinson(const double *r, double r0, uint32_t order, double *a, 
  * K1: per frame -- copy, MS, two pre-emphasis stages, block-type statistics
  * ---------------------------------------------------------------------------------------------- */
 #define PREP_THREADS 256
+#define PREP_CHUNK   1024           /* products staged per round of the ordered pre-emphasis chains */
 /* block-wide integer reductions: shuffle tree inside each wavefront, then one LDS hop (exact: integer add / max) */
 __device__ __forceinline__ int64_t block_sum_i64(int64_t v, int64_t *sh)
 {
@@ -145,6 +146,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
 {
     __shared__ int64_t sh[PREP_THREADS / 64];
     __shared__ int32_t sh_coef;
+    __shared__ double sh_prod[2][PREP_CHUNK];
     const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;     /* one block per (frame, channel) */
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
@@ -173,26 +175,49 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
         /* coefficient: linne_utility.c:158-193.  corr0 = sum x[s]^2, corr1 = sum x[s]x[s+1], s < n-1, are double chains
          * in the reference; when max|x|^2 * n < 2^53 every partial sum is an exactly representable integer, so any
          * summation order gives the reference's bits (integer path); otherwise one thread runs the chains in order. */
-        int64_t mx = 0; uint64_t s0 = 0, s1 = 0;
+        int64_t mx = 0; uint64_t s0 = 0, s1 = 0, sq = 0;
         for (uint32_t s = tid; s < n; s += PREP_THREADS) {
             const int64_t a = src[s]; const int64_t av = a < 0 ? -a : a;
             mx = av > mx ? av : mx;
+            sq += (uint64_t)(a * a);
             if (s + 1 < n) { const int64_t b = src[s + 1]; s0 += (uint64_t)(a * a); s1 += (uint64_t)(a * b); }
         }
         mx = block_max_i64(mx, sh);
-        const bool exact = ((double)mx * (double)mx * (double)n) < 9.0e15;
+        /* every partial sum of either chain is bounded by sum x^2 (|ab| <= (a^2 + b^2) / 2): below 2^53 they are all
+         * exactly representable integers.  (mx^2 * n < 2^62 first: then the 64-bit sums themselves cannot wrap.) */
+        bool exact = ((double)mx * (double)mx * (double)n) < 4.0e18;
+        if (exact) exact = (uint64_t)block_sum_i64((int64_t)sq, sh) < (1ull << 53);
         double c0 = 0.0, c1 = 0.0;
         if (exact) {
             c0 = (double)block_sum_i64((int64_t)s0, sh);
             c1 = (double)block_sum_i64((int64_t)s1, sh);
-        } else if (tid == 0) {
-            double curr = (double)src[0];
-            for (uint32_t s = 0; s + 1 < n; s++) {
-                const double succ = (double)src[s + 1];
-                c0 += curr * curr;
-                c1 += curr * succ;
-                curr = succ;
+        } else {
+            /* ordered chains: the products (exact: |x| < 2^31 squares may round, as in the reference's double multiply) are
+             * formed by all threads, chunk by chunk, into LDS; lane 0 adds the squares and lane 1 the cross products in
+             * sample order */
+            double acc = 0.0;
+            for (uint32_t base = 0; base + 1 < n; base += PREP_CHUNK) {
+                const uint32_t cnt = (n - 1 - base < PREP_CHUNK) ? (n - 1 - base) : PREP_CHUNK;
+                __syncthreads();
+                for (uint32_t i = tid; i < cnt; i += PREP_THREADS) {
+                    const double curr = (double)src[base + i], succ = (double)src[base + i + 1];
+                    sh_prod[0][i] = curr * curr; sh_prod[1][i] = curr * succ;
+                }
+                __syncthreads();
+                if (tid < 2) {
+                    const double *q = sh_prod[tid];
+                    uint32_t i = 0;
+                    for (; i + 8 <= cnt; i += 8) {
+                        const double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3], q4 = q[i + 4], q5 = q[i + 5], q6 = q[i + 6], q7 = q[i + 7];
+                        acc += q0; acc += q1; acc += q2; acc += q3; acc += q4; acc += q5; acc += q6; acc += q7;
+                    }
+                    for (; i < cnt; i++) acc += q[i];
+                }
             }
+            __syncthreads();
+            if (tid == 1) sh_prod[1][0] = acc;
+            __syncthreads();
+            if (tid == 0) { c0 = acc; c1 = sh_prod[1][0]; }
         }
         if (tid == 0) {
             int32_t coef;
