@@ -1485,7 +1485,7 @@ __device__ __forceinline__ int32_t wave_sum_i32(int32_t v)
  *   - the residual of the step is picked from the loaded chunk with a scalar readlane; the next chunk's load is in
  *     flight meanwhile.
  * No per-channel LDS staging, so occupancy is limited by registers only. */
-__global__ __launch_bounds__(64) void k_synthesize(DecPlan p)
+__global__ __launch_bounds__(64) void k_synthesize(DecPlan p, uint32_t only_layer, uint32_t deemph)
 {
     __shared__ int32_t cpad[128];
     const uint32_t cf = blockIdx.x, lane = threadIdx.x;
@@ -1494,6 +1494,7 @@ __global__ __launch_bounds__(64) void k_synthesize(DecPlan p)
     int32_t *g = p.data + (size_t)cf * S;
     /* linne_decoder.c:503-509: layers in reverse order; linne_lpc_synthesize.c:8-83: units are independent */
     for (int32_t l = (int32_t)p.L - 1; l >= 0; l--) {
+        if (only_layer != 0xFFFFFFFFu && (uint32_t)l != only_layer) continue;
         const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
         const uint32_t np = p.P[l] / (units ? units : 1u), ns = n / (units ? units : 1u);
         const uint32_t half = 1u << ((rs - 1u) & 31u);
@@ -1530,7 +1531,7 @@ __global__ __launch_bounds__(64) void k_synthesize(DecPlan p)
     __syncthreads();
     /* two-stage de-emphasis (linne_utility.c:215-241): stage-2 inverse then stage-1 inverse, fused; the recurrence
      * itself is scalar (wave-uniform), chunks of 64 samples move through a register */
-    if (n > 0) {
+    if (n > 0 && deemph) {
         const int32_t c0e = rec[LINNE_AMD_PRM_PCOEF + 0], c1e = rec[LINNE_AMD_PRM_PCOEF + 1];
         int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
         int32_t vin = (lane < n) ? g[lane] : 0;
@@ -1548,6 +1549,106 @@ __global__ __launch_bounds__(64) void k_synthesize(DecPlan p)
             }
             if (lane < cnt) g[c0 + lane] = outv;
         }
+    }
+}
+
+/* Synthesis of a SHORT layer (order <= 16), lanes = channel-frames: a wavefront reconstructs the same layer of 64
+ * channel-frames, each lane running its own recurrence (linne_lpc_synthesize.c:8-83) with its unit's coefficients
+ * (zero-extended to PL taps) and the last PL outputs in registers -- the time loop is unrolled over one turn of that
+ * history ring, so no register moves.  The int32 dot product is evaluated in FP64: coefficients are 8-bit, so
+ * |sum c*y| < 2^45 and every FMA is exact; the sum is then reduced modulo 2^32, which is what the reference's wrap-around
+ * int32 accumulation holds.  Samples travel in 64 x 64 tiles transposed through LDS (coalesced loads and stores, next
+ * tile prefetched into registers).  DEEMPH fuses the two de-emphasis stages (linne_utility.c:215-241), a scalar
+ * recurrence per lane, behind layer 0. */
+#define SYN_T 64
+template <int PL, bool DEEMPH>
+__global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
+{
+    __shared__ int32_t tile[SYN_T][65];
+    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64, S = p.S;
+    const uint32_t nrows = p.F * p.C;
+    uint32_t cf = row0 + lane;
+    const bool have = cf < nrows;
+    if (!have) cf = nrows - 1;
+    const uint32_t n = p.nsmp[cf / p.C];
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + layer], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + layer];
+    const uint32_t np = (units ? PL / units : 0u), ns = (units ? n / units : 0u);
+    const bool skip = (units == 0 || np == 0 || ns < np);         /* linne_decoder.c: such a layer leaves the data unchanged */
+    const uint32_t half = 1u << ((rs - 1u) & 31u);
+    const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
+    double c[PL], h[PL];
+#pragma unroll
+    for (int k = 0; k < PL; k++) { c[k] = 0.0; h[k] = 0.0; }
+    uint32_t tl = 0, unit = 0;                                   /* place inside the current unit; its index */
+    bool fresh = true;                                           /* the unit's coefficients are not loaded yet */
+    int32_t zp = 0, yp = 0, c0e = 0, c1e = 0;
+    if (DEEMPH) { c0e = rec[LINNE_AMD_PRM_PCOEF + 0]; c1e = rec[LINNE_AMD_PRM_PCOEF + 1]; zp = rec[LINNE_AMD_PRM_PREV + 1]; yp = rec[LINNE_AMD_PRM_PREV + 0]; }
+    /* wave-uniform number of tiles: the longest frame of the block */
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    const uint32_t ntiles = (nmax + SYN_T - 1) / SYN_T;
+    int32_t pre[64];
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const uint32_t row = (row0 + r < nrows) ? row0 + r : nrows - 1, sidx = t * SYN_T + lane;
+            pre[r] = (sidx < S) ? p.data[(size_t)row * S + sidx] : 0;
+        }
+    };
+    if (ntiles) issue(0);
+    for (uint32_t t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) tile[lane][r] = pre[r];      /* transposed: tile[sample][row] */
+        if (t + 1 < ntiles) issue(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t s0 = 0; s0 < SYN_T; s0 += PL) {
+#pragma unroll
+            for (int tt = 0; tt < PL; tt++) {                    /* sample index = tt (mod PL): ring slot tt is the oldest */
+                const uint32_t sidx = t * SYN_T + s0 + tt;
+                if (fresh && !skip && unit < units) {            /* first sample of a unit: its zero-extended coefficients */
+#pragma unroll
+                    for (int k = 0; k < PL; k++) c[k] = ((uint32_t)k >= PL - np) ? (double)crec[unit * np + ((uint32_t)k - (PL - np))] : 0.0;
+                }
+                fresh = false;
+                const int32_t res = tile[s0 + tt][lane];
+                /* four partial sums (exact integers: any order) keep the FMA chain short */
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int k = 0; k < PL; k++) {
+                    const double prod_h = h[(tt + k) % PL];
+                    if ((k & 3) == 0) a0 = __builtin_fma(c[k], prod_h, a0);
+                    else if ((k & 3) == 1) a1 = __builtin_fma(c[k], prod_h, a1);
+                    else if ((k & 3) == 2) a2 = __builtin_fma(c[k], prod_h, a2);
+                    else a3 = __builtin_fma(c[k], prod_h, a3);
+                }
+                const double acc = (a0 + a1) + (a2 + a3);
+                const double q = __builtin_floor(acc * 2.3283064365386963e-10);            /* 2^-32 */
+                const uint32_t sum32 = (uint32_t)__builtin_fma(q, -4294967296.0, acc);    /* acc mod 2^32 */
+                const uint32_t pred = half + sum32;
+                int32_t y = res;
+                if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
+                h[tt] = (double)y;
+                tl++;
+                if (tl == ns) { tl = 0; unit++; fresh = true; }
+                if (DEEMPH) {
+                    const int32_t z = (int32_t)((uint32_t)y + (uint32_t)mulshr5(zp, c1e));
+                    const int32_t yy = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                    if (sidx < n) { zp = z; yp = yy; }
+                    y = yy;
+                }
+                tile[s0 + tt][lane] = y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const uint32_t row = row0 + r, sidx = t * SYN_T + lane;
+            if (row < nrows && sidx < p.nsmp[row / p.C]) p.data[(size_t)row * S + sidx] = tile[lane][r];
+        }
+        __syncthreads();
     }
 }
 
@@ -2150,7 +2251,22 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
     ctx->nspans = 0;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
-    { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(num_frames * p.C), dim3(64), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
+    {   /* layers in reverse order (linne_decoder.c:503-509): long layers one wave per channel-frame, short ones (order <= 16)
+         * with lanes = channel-frames; the de-emphasis rides on layer 0's pass */
+        const int sp_ = span_begin(ctx, 11, ctx->stream);
+        const uint32_t CF = num_frames * p.C, gsmall = (CF + 63) / 64;
+        for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
+            const bool de = (l == 0);
+            switch (hs.P[l]) {
+            case 2:  if (de) hipLaunchKernelGGL((k_synth_small<2, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<2, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            case 4:  if (de) hipLaunchKernelGGL((k_synth_small<4, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<4, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            case 8:  if (de) hipLaunchKernelGGL((k_synth_small<8, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<8, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            case 16: if (de) hipLaunchKernelGGL((k_synth_small<16, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<16, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            default: hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, (uint32_t)l, de ? 1u : 0u); break;
+            }
+        }
+        span_end(ctx, sp_, ctx->stream);
+    }
     if (p.ms)
         { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3(num_frames, (p.S + 255) / 256), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     HIPCHK(ctx, hipGetLastError());
