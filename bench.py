@@ -37,7 +37,7 @@ FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains wit
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson(+_wave)", 5: "k_fir2<2,false>",
                 15: "k_fir2<2,true>", 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false>", 16: "k_fir2<1,true>",
-                9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synthesize", 12: "k_ms_to_lr"}
+                9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synth_small+k_synth_big (all layers, de-emphasis)", 12: "k_ms_to_lr"}
 
 
 def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):

@@ -1652,6 +1652,118 @@ __global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
     }
 }
 
+/* Synthesis of a LONG layer (order 32..128), four lanes per channel-frame: a wavefront reconstructs the same layer of 16
+ * channel-frames; lane g of a channel-frame owns the taps k = g (mod 4) of the zero-extended coefficient vector, in
+ * registers as doubles.  The last PL outputs live in LDS as doubles in a ring stored twice (slot i and i + PL), so a
+ * lane's taps are a strided run without wrap-around, read with immediate offsets; the row stride and the tap
+ * interleaving put the 32 lanes of each LDS access group on 32 different banks.  The int32 dot product is evaluated in
+ * FP64 (exact, see k_synth_small), the four partial sums of a channel-frame meet through two DPP quad permutes, and
+ * every lane of the quad finishes the step redundantly.  The newest output is forwarded in a register (its tap belongs
+ * to lane 3), so the LDS write -> read round trip is off the critical path. */
+#define SYB_T 64
+template <int PL>
+__global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
+{
+    constexpr int TP = PL / 4;                                   /* taps per lane */
+    constexpr int RSTR = 2 * PL + 4;                             /* ring row stride in doubles: = 4 (mod 32) */
+    __shared__ __attribute__((aligned(16))) double ring[16 * RSTR];
+    __shared__ int32_t tile[16][SYB_T];
+    const uint32_t lane = threadIdx.x, cfl = lane >> 2, g = lane & 3u, S = p.S;
+    const uint32_t nrows = p.F * p.C, row0 = blockIdx.x * 16;
+    uint32_t cf = row0 + cfl;
+    if (cf >= nrows) cf = nrows - 1;
+    const uint32_t n = p.nsmp[cf / p.C];
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + layer], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + layer];
+    const uint32_t np = (units ? PL / units : 0u), ns = (units ? n / units : 0u);
+    const bool skip = (units == 0 || np == 0 || ns < np);
+    const uint32_t half = 1u << ((rs - 1u) & 31u);
+    const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
+    double c[TP];
+#pragma unroll
+    for (int j = 0; j < TP; j++) c[j] = 0.0;
+    double *myring = ring + cfl * RSTR;
+    for (uint32_t i = g; i < 2 * PL; i += 4) myring[i] = 0.0;
+    uint32_t tl = 0, unit = 0;
+    bool fresh = true;
+    double ynew = 0.0, part = 0.0;                               /* the previous step's output, forwarded; the partial sum made ahead */
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    const uint32_t ntiles = (nmax + SYB_T - 1) / SYB_T;
+    int32_t pre[16];
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t row = (row0 + r < nrows) ? row0 + r : nrows - 1, sidx = t * SYB_T + lane;
+            pre[r] = (sidx < S) ? p.data[(size_t)row * S + sidx] : 0;
+        }
+    };
+    if (ntiles) issue(0);
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) tile[r][lane] = pre[r];
+        if (t + 1 < ntiles) issue(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t s = 0; s < SYB_T; s++) {
+            const uint32_t sidx = t * SYB_T + s, tm = sidx & (PL - 1);
+            if (fresh && !skip && unit < units) {                /* first sample of a unit: my taps of its zero-extended coefficients */
+#pragma unroll
+                for (int j = 0; j < TP; j++) {
+                    const uint32_t k = 4u * (uint32_t)j + g;
+                    c[j] = (k >= PL - np) ? (double)crec[unit * np + (k - (PL - np))] : 0.0;
+                }
+            }
+            fresh = false;
+            const int32_t res = tile[cfl][s];
+            /* tap k = 4j + g multiplies y[sidx - PL + k] (ring position tm + k).  Everything but the newest tap (k = PL - 1,
+             * lane 3) was summed during the previous step (`part`); only that one product is on this step's critical path */
+            double acc = (g == 3u) ? __builtin_fma(c[TP - 1], ynew, part) : part;
+            {   /* quad sum: lanes 4q .. 4q+3 */
+                int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0xB1, 0xf, 0xf, true);     /* quad_perm: 1,0,3,2 */
+                int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0xB1, 0xf, 0xf, true);
+                acc += __hiloint2double(hi, lo);
+                lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0x4E, 0xf, 0xf, true);         /* quad_perm: 2,3,0,1 */
+                hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0x4E, 0xf, 0xf, true);
+                acc += __hiloint2double(hi, lo);
+            }
+            {   /* next step's partial sum: positions tm + 1 + k, k <= PL - 2 -- none of them is written by this step */
+                const double *hp = myring + ((tm + 1u) & (PL - 1)) + g;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int j = 0; j < TP - 1; j++) {
+                    const double hv = hp[4 * j];
+                    if ((j & 3) == 0) a0 = __builtin_fma(c[j], hv, a0);
+                    else if ((j & 3) == 1) a1 = __builtin_fma(c[j], hv, a1);
+                    else if ((j & 3) == 2) a2 = __builtin_fma(c[j], hv, a2);
+                    else a3 = __builtin_fma(c[j], hv, a3);
+                }
+                const double hl = (g == 3u) ? 0.0 : hp[4 * (TP - 1)];
+                a3 = __builtin_fma(c[TP - 1], hl, a3);
+                part = (a0 + a1) + (a2 + a3);
+            }
+            const double q = __builtin_floor(acc * 2.3283064365386963e-10);               /* 2^-32 */
+            const uint32_t sum32 = (uint32_t)__builtin_fma(q, -4294967296.0, acc);       /* acc mod 2^32 */
+            const uint32_t pred = half + sum32;
+            int32_t y = res;
+            if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
+            ynew = (double)y;
+            if (g == 0) { myring[tm] = ynew; myring[tm + PL] = ynew; tile[cfl][s] = y; }
+            tl++;
+            if (tl == ns) { tl = 0; unit++; fresh = true; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t row = row0 + r, sidx = t * SYB_T + lane;
+            if (row < nrows && sidx < p.nsmp[row / p.C]) p.data[(size_t)row * S + sidx] = tile[r][lane];
+        }
+        __syncthreads();
+    }
+}
+
 /* MS -> LR (linne_utility.c:135-147) */
 __global__ void k_ms_to_lr(DecPlan p)
 {
@@ -2255,6 +2367,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
          * with lanes = channel-frames; the de-emphasis rides on layer 0's pass */
         const int sp_ = span_begin(ctx, 11, ctx->stream);
         const uint32_t CF = num_frames * p.C, gsmall = (CF + 63) / 64;
+        if (hs.P[0] > 16) { snprintf(ctx->err, sizeof(ctx->err), "internal: layer 0 of order %u", hs.P[0]); return LNN_NG; }
         for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
             const bool de = (l == 0);
             switch (hs.P[l]) {
@@ -2262,7 +2375,10 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
             case 4:  if (de) hipLaunchKernelGGL((k_synth_small<4, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<4, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
             case 8:  if (de) hipLaunchKernelGGL((k_synth_small<8, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<8, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
             case 16: if (de) hipLaunchKernelGGL((k_synth_small<16, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<16, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
-            default: hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, (uint32_t)l, de ? 1u : 0u); break;
+            case 32:  hipLaunchKernelGGL((k_synth_big<32>), dim3((CF + 15) / 16), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            case 64:  hipLaunchKernelGGL((k_synth_big<64>), dim3((CF + 15) / 16), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            case 128: hipLaunchKernelGGL((k_synth_big<128>), dim3((CF + 15) / 16), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+            default: hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, (uint32_t)l, 0u); break;      /* not a preset size */
             }
         }
         span_end(ctx, sp_, ctx->stream);
