@@ -1625,8 +1625,7 @@ __global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
                     else a3 = __builtin_fma(c[k], prod_h, a3);
                 }
                 const double acc = (a0 + a1) + (a2 + a3);
-                const double q = __builtin_floor(acc * 2.3283064365386963e-10);            /* 2^-32 */
-                const uint32_t sum32 = (uint32_t)__builtin_fma(q, -4294967296.0, acc);    /* acc mod 2^32 */
+                const uint32_t sum32 = (uint32_t)__double2loint(acc + 6755399441055744.0);   /* acc mod 2^32: |acc| < 2^45, so adding 1.5 * 2^52 leaves the integer in the low mantissa bits, two's complement */
                 const uint32_t pred = half + sum32;
                 int32_t y = res;
                 if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
@@ -1744,8 +1743,7 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
                 a3 = __builtin_fma(c[TP - 1], hl, a3);
                 part = (a0 + a1) + (a2 + a3);
             }
-            const double q = __builtin_floor(acc * 2.3283064365386963e-10);               /* 2^-32 */
-            const uint32_t sum32 = (uint32_t)__builtin_fma(q, -4294967296.0, acc);       /* acc mod 2^32 */
+            const uint32_t sum32 = (uint32_t)__double2loint(acc + 6755399441055744.0);      /* acc mod 2^32 (see k_synth_small) */
             const uint32_t pred = half + sum32;
             int32_t y = res;
             if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
