@@ -133,8 +133,54 @@ def cpu_baseline(frames_host, bits, block, preset, ms, budget_frames_per_thread)
         sub = np.ascontiguousarray(frames_host[:total])
         nbytes = C.c_uint64(0)
         dt = o.L.oracle_bench_encode(C.byref(p), sub.ctypes.data, total, cores, C.byref(nbytes))
+    single = None
+    if kind == "reference":                          # one core, a few frames: the per-core rate the speed-up is usually quoted against
+        n1 = min(per, 24)
+        enc = api.new_encoder(nch, bits, 44100, block, preset, ms)
+        out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
+        osz = C.c_uint32(0)
+        t1 = time.perf_counter()
+        for f in range(n1):
+            ptrs = (C.POINTER(C.c_int32) * nch)(*[frames_host[f, ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
+            assert api.L.LINNEEncoder_EncodeBlock(enc, ptrs, block, out.ctypes.data, out.size, C.byref(osz)) == 0
+        single = n1 / (time.perf_counter() - t1)
+        api.L.LINNEEncoder_Destroy(enc)
     return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": f"{total} full stereo frames of the same track ({per} per thread, {dt:.1f} s wall), EncodeBlock incl. entropy stage"}
+            "sample": f"{total} full {nch}-channel frames of the same track ({per} per thread, {dt:.1f} s wall), EncodeBlock incl. entropy stage",
+            "single_core_frames_per_s": single}
+
+
+def end_to_end(x_host, bits, rate, block, preset, ms):
+    """the drop-in API on host buffers (host planes -> .lnn bytes -> host planes): LINNEEncoder_EncodeWhole /
+    LINNEDecoder_DecodeWhole of liblinne_amd.so, PCIe and the host entropy stage included; second of two runs on the
+    same handles (the first pays the one-time set-up of the GPU context and the pinned staging slots)"""
+    import ctypes as C
+    from refs import LinneApi, _planar_ptrs, _RefDecoderConfig
+    api = LinneApi(linne_amd.LIB_PATH)
+    L = api.L
+    nch, ns = x_host.shape
+    nf = (ns + block - 1) // block
+    enc = api.new_encoder(nch, bits, rate, block, preset, ms)
+    cfg = _RefDecoderConfig(nch, 5, 128, 1)
+    dec = L.LINNEDecoder_Create(C.byref(cfg), None, 0)
+    xp, _k1 = _planar_ptrs(x_host)
+    cap = min(x_host.size * 4 + 65536, 0xFFFFFFFF)
+    out = np.ones(cap, dtype=np.uint8)
+    back = np.ones_like(x_host)
+    bp, _k2 = _planar_ptrs(back)
+    osz = C.c_uint32(0)
+    res = {}
+    for rep in range(2):
+        t0 = time.perf_counter()
+        r1 = L.LINNEEncoder_EncodeWhole(enc, xp, ns, out.ctypes.data, cap, C.byref(osz))
+        t1 = time.perf_counter()
+        r2 = L.LINNEDecoder_DecodeWhole(dec, out.ctypes.data, osz.value, bp, nch, ns)
+        t2 = time.perf_counter()
+        res = {"encode_whole_frames_per_s": nf / (t1 - t0), "decode_whole_frames_per_s": nf / (t2 - t1),
+               "compression_ratio": osz.value / (x_host.size * (bits // 8)), "round_trip_bit_exact": bool(r1 == 0 and r2 == 0 and np.array_equal(back, x_host)),
+               "host_threads": host_cores(), "note": "host planes -> .lnn -> host planes through the 13-symbol API; includes PCIe and the host entropy stage"}
+    L.LINNEEncoder_Destroy(enc); L.LINNEDecoder_Destroy(dec)
+    return res
 
 
 def main():
@@ -282,6 +328,14 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))
             cpu = cpu_baseline(frames[:nf].cpu().numpy(), bits, block, args.preset, ms, args.cpu_frames_per_thread)
+        e2e = None
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                x_host = np.ascontiguousarray(frames.permute(1, 0, 2).reshape(nch, -1)[:, :ns_total].cpu().numpy())
+                e2e = end_to_end(x_host, bits, rate, block, args.preset, ms)
+                del x_host
+            except Exception as exc:                 # the hot-path numbers above do not depend on it
+                e2e = {"error": repr(exc)}
         breakdown = {KERNEL_KINDS[k]: round(kern_ms[k] / args.steps, 3) for k in KERNEL_KINDS if kern_ms[k] > 0}
         line = {
             "metric": "frames/sec encode (-m 7) + decode, 44.1 kHz stereo, bit-exact; 1/2/4/8 GPU",
@@ -294,7 +348,7 @@ def main():
             "decode_frames_per_s": dec_fps, "decode_ms_per_step": dec_s / args.steps * 1e3, "decode_bit_exact": ok,
             "encode_channel_frames_per_s": enc_fps * nch,
             "kernel_ms_per_step": breakdown,
-            "roofline": roofline, "valu_f64": valu, "cpu_baseline": cpu,
+            "roofline": roofline, "valu_f64": valu, "cpu_baseline": cpu, "end_to_end_api": e2e,
         }
         if cpu:
             line["speedup_vs_cpu_baseline"] = enc_fps / cpu["value"]
