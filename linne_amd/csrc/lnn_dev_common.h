@@ -1,0 +1,93 @@
+/* lnn_dev_common.h -- shared device-side types, the launch plan and small device helpers.
+ * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
+#ifndef LNN_DEV_COMMON_H_INCLUDED
+#define LNN_DEV_COMMON_H_INCLUDED
+
+
+#define LNN_MAXT        8       /* unit-count trials per layer: u = 1,2,...,128 */
+#define LNN_MAXU        128
+#define LNN_MAXP        128
+#define LNN_MAXL        3
+#define LNN_MAXR        4
+#define LNN_MAXCLS      16
+#define LNN_MAXCH       8
+#define LNN_ACW         256     /* autocorrelation words per (job, trial): P + u <= 256 */
+#define LNN_MAXSUB      8
+#define LNN_META        8
+typedef double lnn_d2 __attribute__((ext_vector_type(2)));
+
+/* one distinct frame length of a batch (full frames, the ragged tail, ...) */
+struct DevClass {
+    uint32_t n;                         /* valid samples                                             */
+    uint32_t na;                        /* analysis length (linne_encoder.c:644-655)                 */
+    uint32_t sin_off;                   /* offset of this class's SIN window table                   */
+    uint32_t pad;
+    uint32_t ntrials[LNN_MAXL];
+    uint32_t trial_u[LNN_MAXL][LNN_MAXT];
+    double   trial_div[LNN_MAXL][LNN_MAXT];   /* 4*pow(na/u - 1, -2) from the host libm (lpc.c:199)  */
+    uint32_t wt_off[LNN_MAXL][LNN_MAXT];      /* offset of the trial's Welch weight table (padded unit: n + max(p,4) entries) */
+};
+
+struct Plan {
+    uint32_t C, S, bits, L, R, ms, F, J;
+    uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
+    double regs[LNN_MAXR];
+    double scale;                       /* 2^-(bits-1), exact */
+    const int32_t *pcm; int32_t *resid; int32_t *prm; double *stats;
+    const uint32_t *cls_of_frame; const DevClass *cls; const double *sintab; const double *wtab;
+    int32_t *xint, *xtmp;               /* [F*C][S]                    */
+    double *sig;                        /* [J][2][S]                   */
+    double *acorr;                      /* [J][MAXT][ACW]              */
+    double *tcoef;                      /* [J][MAXT][MAXP]  filter order (reversed LPC order) */
+    double *ptail; uint8_t *ptail_set;  /* [J][MAXT][MAXU]             */
+    double *tloss;                      /* [J][MAXT] exact mean |residual| (ordered chain)            */
+    double *tsum;                       /* [J][MAXT][npart] per-wave partial sums of |residual| (certified search) */
+    uint32_t npart;                     /* partial sums per (job, trial): tiles x waves per block      */
+    uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
+    uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
+    double *lparams;                    /* [J][MAXL][MAXP]             */
+    uint32_t *lunits;                   /* [J][MAXL]                   */
+    double *jloss, *jtail;              /* [J]                         */
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * small device helpers
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ double round_away(double d) { return (d >= 0.0) ? floor(d + 0.5) : -floor(-d + 0.5); }   /* lpc.c:49-52 */
+__device__ __forceinline__ int32_t mulshr5(int32_t x, int32_t c) { return (int32_t)((uint32_t)x * (uint32_t)c) >> 5; }
+
+/* Levinson-Durbin, lpc.c:252-324, on a private array a[0..order+1]; r[1..order] are the lags, r0 the
+ * ridge-scaled lag 0 (lpc.c:358).  The reference's u/v vectors are the old a and its mirror:
+ * a_new[i] = u[i] + gamma*v[i] with u = (1,a1..ak,0), v = (0,ak..a1,1), so the update is done in place on
+ * pairs (i, k+1-i).  On return a[1..order] are the LPC coefficients.  parcor_out (optional) gets
+ * parcor[0..order-1] exactly as the reference writes them. */
+__device__ void levinson(const double *r, double r0, uint32_t order, double *a, double *parcor_out)
+{
+    for (uint32_t i = 0; i < order + 2; i++) a[i] = 0.0;
+    a[0] = 1.0;
+    double ek = r0;
+    a[1] = -r[1] / r0;
+    if (parcor_out) parcor_out[0] = r[1] / ek;
+    ek += r[1] * a[1];
+    for (uint32_t k = 1; k < order; k++) {
+        double gamma = 0.0;
+        for (uint32_t i = 0; i < k + 1; i++) gamma += a[i] * r[k + 1 - i];
+        gamma /= -ek;
+        ek *= (1.0 - gamma * gamma);
+        const double a0 = 1.0 + gamma * 0.0;              /* u[0]   + gamma*v[0]   */
+        const double ak1 = 0.0 + gamma * 1.0;             /* u[k+1] + gamma*v[k+1] */
+        uint32_t i = 1, j = k;
+        while (i < j) {
+            const double ai = a[i], aj = a[j];
+            a[i] = ai + gamma * aj;
+            a[j] = aj + gamma * ai;
+            i++; j--;
+        }
+        if (i == j) { const double ai = a[i]; a[i] = ai + gamma * ai; }
+        a[0] = a0; a[k + 1] = ak1;
+        if (parcor_out) parcor_out[k] = -gamma;
+    }
+}
+
+
+#endif

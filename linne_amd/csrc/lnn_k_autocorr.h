@@ -1,0 +1,564 @@
+/* lnn_k_autocorr.h -- Welch window + autocorrelation kernels (k_autocorr2, k_autocorr_lane) and their launchers.
+ * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
+#ifndef LNN_K_AUTOCORR_H_INCLUDED
+#define LNN_K_AUTOCORR_H_INCLUDED
+
+/* ------------------------------------------------------------------------------------------------
+ * analysis, one layer at a time over every job = (channel-frame, regulariser pass)
+ * ---------------------------------------------------------------------------------------------- */
+__device__ __forceinline__ const DevClass &job_class(const Plan &p, uint32_t job) { return p.cls[p.cls_of_frame[(job / p.R) / p.C]]; }
+
+/* ------------------------------------------------------------------------------------------------
+ * K_A (v2): Welch window + autocorrelation of every unit-count trial of one layer, fused.
+ *
+ * Work decomposition (DESIGN.md "autocorrelation kernel"): one wavefront per JPW jobs.  A LANE owns K = 5
+ * consecutive lags of one trial of one job and walks ALL units of that trial in order, so every lane runs the
+ * same number of steps (~ na + P) and each lag's sum stays one chain in increasing sample order.  The windowed
+ * signal of a trial is produced on the fly into a small LDS ring ("padded stream": each unit is followed by
+ * z = max(p,4) zeros, so a lane's 5-lag register window can slide across unit ends without masking and the
+ * accumulators can be flushed at a group boundary inside the zero zone).  Per 5 steps a lane issues 25 unfused
+ * mul+add pairs against 10 LDS reads.
+ * ---------------------------------------------------------------------------------------------- */
+template <int P> struct AcCfg {
+    static constexpr int K = 5;
+    static constexpr int NT = (P >= 128) ? 8 : ((P >= 64) ? 7 : (P >= 32) ? 6 : (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2);
+    static constexpr int T = (P >= 32) ? 60 : 20;                       /* tile: padded positions per LDS refill */
+    static constexpr int lanes(int t) { return ((P >> t) + 1 + K - 1) / K; }
+    static constexpr int halo(int t) { return K * lanes(t) + K; }       /* furthest window read past a group start, +1 */
+    static constexpr int rb(int t) { return ((T + halo(t) + 3 + 4 * K - 1) / (4 * K)) * (4 * K); }   /* ring length, multiple of 2K and of 4 */
+    static constexpr int lpj() { int s = 0; for (int t = 0; t < NT; t++) s += lanes(t); return s; }
+    static constexpr int ringsum() { int s = 0; for (int t = 0; t < NT; t++) s += rb(t); return s; }
+    static constexpr int maxpad() { int m = 0; for (int t = 0; t < NT; t++) { const int p = P >> t, z = p > 4 ? p : 4, v = (1 << t) * z; if (v > m) m = v; } return m; }
+    static constexpr int LPJ = lpj();
+    static constexpr int JPW = 64 / LPJ;
+    static constexpr int NS = JPW * NT;
+    static constexpr int GL = (64 / NS) >= 1 ? (64 / NS) : 1;
+    static constexpr int RINGSUM = ringsum();
+    static constexpr int MAXPAD = maxpad();
+};
+
+template <int P, bool L0>
+__global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    using Cfg = AcCfg<P>;
+    constexpr int K = Cfg::K, NT = Cfg::NT, T = Cfg::T;
+    __shared__ __attribute__((aligned(16))) double ring[Cfg::JPW * Cfg::RINGSUM];
+    const uint32_t lane = threadIdx.x;
+
+    /* ---- accumulate role: (job, trial, lag group) ---- */
+    bool active = false;
+    uint32_t a_job = 0, a_t = 0, a_lag0 = 0, a_u = 1, a_p = P, a_upl = 1;
+    int32_t a_base = 0, a_rb = 5;          /* ring base (doubles) and ring length of my stream */
+    {
+        const uint32_t jl = lane / Cfg::LPJ;
+        uint32_t rem = lane % Cfg::LPJ;
+        if (jl < (uint32_t)Cfg::JPW) {
+            uint32_t t = 0; int32_t off = 0;
+            for (; t < (uint32_t)NT; t++) { if (rem < (uint32_t)Cfg::lanes(t)) break; rem -= Cfg::lanes(t); off += Cfg::rb(t); }
+            a_job = blockIdx.x * Cfg::JPW + jl;
+            if (a_job < p.J) {
+                const DevClass &c = job_class(p, a_job);
+                if (t < c.ntrials[layer]) {
+                    active = true;
+                    a_t = t; a_lag0 = rem * K; a_u = 1u << t; a_p = P >> t;
+                    const uint32_t n = c.na / a_u;
+                    a_upl = n + (a_p > 4 ? a_p : 4);
+                    a_base = (int32_t)(jl * Cfg::RINGSUM) + off; a_rb = Cfg::rb(t);
+                }
+            }
+        }
+    }
+    uint32_t a_n = 1;
+    if (active) a_n = job_class(p, a_job).na / a_u;
+
+    /* ---- generate role: (stream, sub-lane) ---- */
+    bool gen = false;
+    uint32_t g_n = 1, g_u = 1, g_upl = 5, g_halo = 0;
+    int32_t g_base = 0, g_rb = 5, g_pos = 0;       /* ring slot of g_q */
+    uint32_t g_q = 0, g_unit = 0, g_loc = 0, g_ubase = 0;
+    double g_stale = 0.0;
+    const double *g_wt = p.wtab;                    /* Welch weights of my trial, one padded unit */
+    const double *g_xd = p.sig; const int32_t *g_xi = p.xint;      /* always dereferenceable */
+    {
+        const uint32_t gs = lane / Cfg::GL, sub = lane % Cfg::GL;
+        if (gs < (uint32_t)Cfg::NS) {
+            const uint32_t jl = gs / NT, t = gs % NT;
+            const uint32_t job = blockIdx.x * Cfg::JPW + jl;
+            if (job < p.J) {
+                const DevClass &c = job_class(p, job);
+                if (t < c.ntrials[layer]) {
+                    gen = true;
+                    g_u = 1u << t; g_n = c.na / g_u;
+                    const uint32_t pp = P >> t;
+                    g_upl = g_n + (pp > 4 ? pp : 4);
+                    g_halo = Cfg::halo(t);
+                    int32_t off = 0;
+                    for (uint32_t i = 0; i < t; i++) off += Cfg::rb(i);
+                    g_base = (int32_t)(jl * Cfg::RINGSUM) + off; g_rb = Cfg::rb(t);
+                    g_wt = p.wtab + c.wt_off[layer][t];
+                    if (L0) g_xi = p.xint + (size_t)(job / p.R) * p.S; else g_xd = p.sig + ((size_t)job * 2 + cur) * p.S;
+                    g_q = sub; g_loc = sub; g_pos = (int32_t)sub;
+                    while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+                    if (g_n & 1u) {     /* Q1: stale middle sample = previous trial's last unit at local index m */
+                        const uint32_t m = g_n >> 1, n2 = 2 * g_n, si = (g_u / 2 - 1) * n2 + m;
+                        const double xv = L0 ? ((double)g_xi[si] * p.scale) : g_xd[si];
+                        const double wgt = c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m);
+                        g_stale = xv * wgt;
+                    }
+                }
+            }
+        }
+    }
+
+    /* Fast generator: when every stream of the wave has unit and padded-unit lengths that are multiples of 4 (always for
+     * frame lengths that are multiples of 4 * 128), a generator lane produces 4 consecutive stream positions at a time --
+     * they never straddle a unit end or the ring end -- with 16-byte loads and stores; the bookkeeping per element drops
+     * to a quarter.  Same products in the same places; the choice is per wave and holds for the whole kernel. */
+    const bool fastgen = __all(!gen || (((g_n | g_upl) & 3u) == 0));
+    if (fastgen && gen) {
+        const uint32_t sub = lane % Cfg::GL;
+        g_halo = (g_halo + 3u) & ~3u;
+        g_q = 4 * sub; g_loc = 4 * sub; g_pos = (int32_t)(4 * sub); g_unit = 0; g_ubase = 0;
+        while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+    }
+    constexpr uint32_t GSTEP4 = 4 * Cfg::GL;
+    constexpr int E4 = (T + 4 * Cfg::GL - 1) / (4 * Cfg::GL);
+    auto gen_advance4 = [&]() {
+        g_q += GSTEP4; g_loc += GSTEP4;
+        while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+    };
+    struct Q4 { double v[4]; };
+    auto gen_fetch4 = [&](uint32_t si) -> Q4 {          /* si is a multiple of 4: 16-byte aligned pieces */
+        Q4 q;
+        if (L0) { const int4 iv = *(const int4 *)(g_xi + si); q.v[0] = (double)iv.x * p.scale; q.v[1] = (double)iv.y * p.scale; q.v[2] = (double)iv.z * p.scale; q.v[3] = (double)iv.w * p.scale; }
+        else { const lnn_d2 a = *(const lnn_d2 *)(g_xd + si), b = *(const lnn_d2 *)(g_xd + si + 2); q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y; }
+        return q;
+    };
+    auto gen_weight4 = [&](uint32_t loc) -> Q4 {
+        Q4 q; const lnn_d2 a = *(const lnn_d2 *)(g_wt + loc), b = *(const lnn_d2 *)(g_wt + loc + 2);
+        q.v[0] = a.x; q.v[1] = a.y; q.v[2] = b.x; q.v[3] = b.y; return q;
+    };
+    auto gen_store4 = [&](const Q4 &x, const Q4 &wq, bool in_unit) {
+        lnn_d2 a, b;
+        a.x = in_unit ? x.v[0] * wq.v[0] : 0.0; a.y = in_unit ? x.v[1] * wq.v[1] : 0.0;
+        b.x = in_unit ? x.v[2] * wq.v[2] : 0.0; b.y = in_unit ? x.v[3] * wq.v[3] : 0.0;
+        *(lnn_d2 *)(ring + g_base + g_pos) = a; *(lnn_d2 *)(ring + g_base + g_pos + 2) = b;
+        g_pos += (int32_t)GSTEP4; if (g_pos >= g_rb) g_pos -= g_rb;
+    };
+
+    /* per-lane accumulate state */
+    double r[K], w[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) { r[j] = 0.0; w[j] = 0.0; }
+    uint32_t a_unit = 0, flush_pos = a_n;           /* first padded position after unit 0's samples */
+    int32_t pa = 0, pw = (int32_t)a_lag0;           /* ring slots of q0 and of q0 + lag0 */
+    double *out = nullptr;
+    if (active) out = p.acorr + ((size_t)a_job * LNN_MAXT + a_t) * LNN_ACW;
+    /* volatile LDS pointer: keeps the 8-byte reads unmerged (ds_read2_b64 runs at half the rate of two ds_read_b64) */
+    typedef const volatile __attribute__((address_space(3))) double *lds_ro_ptr;
+    lds_ro_ptr myring = (lds_ro_ptr)(ring + a_base);
+    double *gring = ring + g_base;
+
+    /* generator step: classify padded position g_q -> sample index (or zero / stale), then advance */
+    constexpr int E = (T + Cfg::GL - 1) / Cfg::GL;  /* elements one generator lane adds per tile (at most) */
+    auto gen_advance = [&]() {
+        g_q += Cfg::GL; g_loc += Cfg::GL;
+        while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
+    };
+    /* element of the padded stream: x[unit*n + loc] * w(loc); w is 0 in the zero zone; Q1 replaces an odd unit's middle */
+    auto gen_value = [&](double xv, double wv, uint32_t loc) -> double {
+        const double v = xv * wv;
+        return ((g_n & 1u) && loc == (g_n >> 1)) ? g_stale : v;
+    };
+    auto gen_fetch = [&](uint32_t si) -> double { return L0 ? ((double)g_xi[si] * p.scale) : g_xd[si]; };
+
+    /* initial fill: padded positions [0, T + halo) */
+    if (gen && fastgen) {
+        const uint32_t lim = T + g_halo;
+        while (g_q < lim) {
+            const bool in_unit = (g_unit < g_u) && (g_loc < g_n);
+            const Q4 x = gen_fetch4(in_unit ? (g_ubase + g_loc) : 0u), wq = gen_weight4(in_unit ? g_loc : 0u);
+            gen_store4(x, wq, in_unit);
+            gen_advance4();
+        }
+    } else if (gen) {
+        const uint32_t lim = T + g_halo;
+        while (g_q < lim) {
+            double v = 0.0;
+            if (g_unit < g_u && g_loc < g_n) v = gen_value(gen_fetch(g_ubase + g_loc), g_wt[g_loc], g_loc);
+            gring[g_pos] = v;
+            g_pos += Cfg::GL; if (g_pos >= g_rb) g_pos -= g_rb;
+            gen_advance();
+        }
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < K; j++) w[j] = myring[pw + j];
+        pw += K; if (pw >= a_rb) pw -= a_rb;
+    }
+
+    const uint32_t q_end = na_max + Cfg::MAXPAD + K;       /* uniform bound: past every lane's last flush */
+    for (uint32_t tile0 = 0; tile0 < q_end; tile0 += T) {
+        /* prefetch the samples of the NEXT refill (positions [tile0 + T + halo, tile0 + 2T + halo)) into registers;
+         * their latency hides behind this tile's accumulation */
+        double fx[E], fw[E]; uint32_t floc[E];
+        Q4 qx[E4], qw[E4]; uint32_t qin[E4];                /* fast generator: 0 = not mine, 1 = zero zone, 2 = samples */
+        if (fastgen) {
+            const uint32_t lim = tile0 + 2 * T + g_halo;
+#pragma unroll
+            for (int e = 0; e < E4; e++) {
+                const bool in_range = gen && (g_q < lim);
+                const bool in_unit = in_range && (g_unit < g_u) && (g_loc < g_n);
+                qin[e] = in_unit ? 2u : (in_range ? 1u : 0u);
+                qx[e] = gen_fetch4(in_unit ? (g_ubase + g_loc) : 0u);
+                qw[e] = gen_weight4(in_unit ? g_loc : 0u);
+                if (in_range) gen_advance4();
+            }
+        } else {
+            const uint32_t lim = tile0 + 2 * T + g_halo;
+#pragma unroll
+            for (int e = 0; e < E; e++) {           /* straight-line: E independent loads in flight */
+                const bool in_range = gen && (g_q < lim);
+                const bool in_unit = in_range && (g_unit < g_u) && (g_loc < g_n);
+                const uint32_t si = in_unit ? (g_ubase + g_loc) : 0u;
+                floc[e] = in_unit ? g_loc : (in_range ? 0xFFFFFFFEu : 0xFFFFFFFFu);
+                fx[e] = gen_fetch(si);
+                fw[e] = g_wt[in_unit ? g_loc : 0u];
+                if (in_range) gen_advance();
+            }
+        }
+        if (active) {
+            /* two 5-step groups per trip: the window registers swap roles (w -> nw -> w), so nothing is moved; the ring
+             * length is a multiple of 10, so q0's slot wraps at most once per trip */
+            auto flush = [&](uint32_t q) {
+                if (q >= flush_pos) {                   /* inside the zero zone after a unit: store and restart */
+                    double *o = out + (size_t)a_unit * (a_p + 1) + a_lag0;
+#pragma unroll
+                    for (int j = 0; j < K; j++) { if (a_lag0 + j <= a_p) o[j] = r[j]; r[j] = 0.0; }
+                    a_unit++;
+                    flush_pos = (a_unit < a_u) ? (flush_pos + a_upl) : 0xFFFFFFFFu;
+                }
+            };
+#pragma unroll 1
+            for (uint32_t q0 = tile0; q0 < tile0 + T; q0 += 2 * K) {
+                double a[K], nw[K];
+                flush(q0);
+#pragma unroll
+                for (int j = 0; j < K; j++) { a[j] = myring[pa + j]; nw[j] = myring[pw + j]; }
+                int32_t pw2 = pw + K; if (pw2 >= a_rb) pw2 -= a_rb;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) r[j] += a[t] * ((t + j < K) ? w[t + j] : nw[t + j - K]);
+                }
+                flush(q0 + K);
+#pragma unroll
+                for (int j = 0; j < K; j++) { a[j] = myring[pa + K + j]; w[j] = myring[pw2 + j]; }
+                pa += 2 * K; if (pa >= a_rb) pa -= a_rb;
+                pw = pw2 + K; if (pw >= a_rb) pw -= a_rb;
+#pragma unroll
+                for (int t = 0; t < K; t++) {
+#pragma unroll
+                    for (int j = 0; j < K; j++) r[j] += a[t] * ((t + j < K) ? nw[t + j] : w[t + j - K]);
+                }
+            }
+        }
+        __syncthreads();
+        if (fastgen) {
+#pragma unroll
+            for (int e = 0; e < E4; e++) if (qin[e]) gen_store4(qx[e], qw[e], qin[e] == 2u);
+        } else if (gen) {
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                if (floc[e] != 0xFFFFFFFFu) {
+                    const double gv = gen_value(fx[e], fw[e], floc[e]);
+                    gring[g_pos] = (floc[e] == 0xFFFFFFFEu) ? 0.0 : gv;
+                    g_pos += Cfg::GL; if (g_pos >= g_rb) g_pos -= g_rb;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * K_A for the short layers (P <= 16): one lane per (job, trial) owns ALL p+1 lags of the trial; a wavefront holds 64
+ * jobs of the SAME trial (grid.y = trial), so every lane issues the same number of multiply-adds.  A lane produces its
+ * own padded windowed stream on the fly -- one new element per step, loads prefetched one 4-step group ahead -- into a
+ * register window w[0..K+3]; step q adds w[q]*w[q+j] to lag j.  No LDS, no barrier.  Same chains, same order as
+ * k_autocorr2.
+ * ---------------------------------------------------------------------------------------------- */
+template <int K, bool L0>
+__device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uint32_t cur, uint32_t q_end, uint32_t job, uint32_t t, bool active)
+{
+    constexpr int U = 4;
+    constexpr uint32_t np = K - 1;
+    const DevClass &c = job_class(p, job);
+    const uint32_t u = 1u << t;
+    const uint32_t n = active ? (c.na / u) : 1u;
+    const uint32_t upl = n + (np > 4 ? np : 4);
+    const double *wt = p.wtab + (active ? c.wt_off[layer][t] : 0u);
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
+    const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
+    double stale = 0.0;
+    if (active && (n & 1u)) {                       /* Q1, as in k_autocorr2 */
+        const uint32_t m = n >> 1, n2 = 2 * n, si = (u / 2 - 1) * n2 + m;
+        const double xv = L0 ? ((double)xi[si] * p.scale) : xd[si];
+        stale = xv * (c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m));
+    }
+    const bool odd = (n & 1u) != 0;
+    const uint32_t mid = n >> 1;
+    uint32_t g_loc = 0, g_ubase = 0, g_left = active ? u : 0u;     /* units still to come (incl. the current one) */
+    auto gen_issue = [&](double &rx, double &rw, uint32_t &rloc) {
+        const bool in_unit = (g_loc < n) && (g_left != 0);
+        rx = L0 ? ((double)xi[in_unit ? (g_ubase + g_loc) : 0u] * p.scale) : xd[in_unit ? (g_ubase + g_loc) : 0u];
+        rw = wt[g_loc];                              /* zero inside the zero zone (table covers the padded unit) */
+        rloc = in_unit ? g_loc : 0xFFFFFFFFu;
+        const bool wrap = (g_loc + 1 >= upl);
+        g_loc = wrap ? 0u : g_loc + 1;
+        g_ubase = (wrap && g_left > 1) ? g_ubase + n : g_ubase;
+        g_left = (wrap && g_left) ? g_left - 1 : g_left;
+    };
+    auto gen_finish = [&](double rx, double rw, uint32_t rloc) -> double {
+        const double v = rx * rw;
+        const double vv = (odd && rloc == mid) ? stale : v;
+        return (rloc == 0xFFFFFFFFu) ? 0.0 : vv;
+    };
+    double r[K], w[K + U], fx[U], fw[U]; uint32_t fl[U];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        r[j] = 0.0;
+        double rx, rw; uint32_t rl;
+        gen_issue(rx, rw, rl);
+        w[j] = gen_finish(rx, rw, rl);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++) gen_issue(fx[j], fw[j], fl[j]);
+    uint32_t a_unit = 0, flush_pos = n;
+    double *out = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW;
+#pragma unroll 1
+    for (uint32_t q0 = 0; q0 < q_end; q0 += U) {
+        if (active && q0 >= flush_pos) {           /* in the zero zone after a unit: store its lags, restart */
+            double *o = out + (size_t)a_unit * K;
+#pragma unroll
+            for (int j = 0; j < K; j++) { o[j] = r[j]; r[j] = 0.0; }
+            a_unit++;
+            flush_pos = (a_unit < u) ? (flush_pos + upl) : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < U; j++) w[K + j] = gen_finish(fx[j], fw[j], fl[j]);
+#pragma unroll
+        for (int j = 0; j < U; j++) gen_issue(fx[j], fw[j], fl[j]);      /* next group's loads fly during the MACs */
+#pragma unroll
+        for (int tt = 0; tt < U; tt++) {
+#pragma unroll
+            for (int j = 0; j < K; j++) r[j] += w[tt] * w[tt + j];
+        }
+#pragma unroll
+        for (int j = 0; j < K; j++) w[j] = w[j + U];
+    }
+}
+
+/* Fast form for a block whose 64 rows share one length class with every unit length a multiple of 4 (any frame length
+ * that is a multiple of 64: the CLI's 10240-sample blocks and their usual tails): wave t of the block owns trial t of the
+ * same 64 rows.  The samples are read from HBM ONCE for all trials, coalesced (one load instruction covers 16 consecutive
+ * samples of 4 rows), and handed to the lanes through a transposed LDS tile; the stream bookkeeping (unit position, pad
+ * zones, flushes) is wave-uniform.  Same products, same chains, same order as autocorr_lane. */
+#define ACS_T 32
+template <int K, int J0, int JN, bool L0, int NT>
+__device__ __forceinline__ void autocorr_shared(const Plan &p, uint32_t layer, uint32_t cur, uint32_t row0, uint32_t nrows, uint32_t rstride,
+        uint32_t na, uint32_t wt_off, uint32_t t, uint32_t wave, uint32_t lane, double (*tile)[ACS_T][65])
+{
+    constexpr uint32_t np = K - 1, pad = (np > 4 ? np : 4);
+    constexpr int L = ((int)np + 3) / 4 * 4;               /* window lead: elements held ahead of the current step */
+    constexpr int NSLOT = (ACS_T + NT - 1) / NT;           /* load slots (64/ACS_T rows x ACS_T samples) this wave may own; ACS_T slots per tile */
+    const uint32_t u = 1u << t, n = na / u, upl = n + pad, ntiles = na / ACS_T;
+    const double *wt = p.wtab + wt_off;
+    uint32_t myrow = row0 + lane; if (myrow >= nrows) myrow = nrows - 1;
+    const bool store = (row0 + lane) < nrows;
+    double *out = p.acorr + ((size_t)myrow * rstride * LNN_MAXT + t) * LNN_ACW;
+    /* loads run two tiles ahead of the tile being consumed, in two register sets picked by the tile's parity */
+    double preA[NSLOT], preB[NSLOT], wA = 0.0, wB = 0.0, wcur = 0.0;   /* w*: Welch weights of a tile, lane j holds sample j's */
+    const uint32_t ls = lane & (ACS_T - 1u), lr = lane / ACS_T;
+    constexpr uint32_t RPS = 64 / ACS_T;                    /* rows per load slot; a tile has 64 / RPS = ACS_T slots */
+    auto issue = [&](uint32_t tile_idx, double *pre, double &wv) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NT;
+            if (k < 64 / RPS) {
+                uint32_t r = row0 + RPS * k + lr; if (r >= nrows) r = nrows - 1;
+                const uint32_t sidx = tile_idx * ACS_T + ls;
+                if (L0) pre[i] = (double)p.xint[(size_t)r * p.S + sidx] * p.scale;   /* rows are channel-frames */
+                else pre[i] = p.sig[((size_t)r * 2 + cur) * p.S + sidx];
+            }
+        }
+        wv = wt[(tile_idx * ACS_T + ls) % n];               /* the weight depends on the place inside the unit only */
+    };
+    auto commit = [&](uint32_t buf, const double *pre, double wv) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NT;
+            if (k < 64 / RPS) tile[buf][ls][RPS * k + lr] = pre[i];
+        }
+        wcur = wv;
+    };
+    auto lane_bcast = [&](double v, uint32_t src_lane) -> double {     /* wave-uniform src_lane: two v_readlane */
+        const int lo = __builtin_amdgcn_readlane(__double2loint(v), (int)src_lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), (int)src_lane);
+        return __hiloint2double(hi, lo);
+    };
+    issue(0, preA, wA); commit(0, preA, wA);
+    __syncthreads();
+    if (ntiles > 1) issue(1, preB, wB);
+    if (ntiles > 2) issue(2, preA, wA);
+    uint32_t g_loc = 0, g_tile = 0, g_off = 0;              /* generator: place in the padded unit, tile, offset in it */
+    struct D4 { double v0, v1, v2, v3; };
+    auto next4 = [&]() -> D4 {
+        D4 d; d.v0 = 0.0; d.v1 = 0.0; d.v2 = 0.0; d.v3 = 0.0;      /* zero zone after a unit, or past the last unit */
+        if (g_loc < n && g_tile < ntiles) {                 /* four samples of the current unit */
+            const double *src = &tile[g_tile & 1u][g_off][lane];
+            d.v0 = src[0] * lane_bcast(wcur, g_off); d.v1 = src[65] * lane_bcast(wcur, g_off + 1);
+            d.v2 = src[130] * lane_bcast(wcur, g_off + 2); d.v3 = src[195] * lane_bcast(wcur, g_off + 3);
+            g_off += 4;
+            if (g_off == ACS_T) {                           /* tile used up: publish the prefetched one */
+                g_off = 0; g_tile++;
+                if (g_tile < ntiles) {                      /* odd tiles travel in set B, even ones in set A */
+                    if (g_tile & 1u) { commit(1, preB, wB); __syncthreads(); if (g_tile + 2 < ntiles) issue(g_tile + 2, preB, wB); }
+                    else             { commit(0, preA, wA); __syncthreads(); if (g_tile + 2 < ntiles) issue(g_tile + 2, preA, wA); }
+                }
+            }
+        }
+        g_loc += 4; if (g_loc >= upl) g_loc = 0;
+        return d;
+    };
+    /* This wave accumulates lags J0 .. J0+JN-1 of the trial.  The stream window is a register ring of W = L + 4 elements
+     * (w[i % W] = element i): the loop body is unrolled over one turn of the ring, so the window never moves. */
+    constexpr int W = L + 4, NG = W / 4;
+    double r[JN], w[W];
+#pragma unroll
+    for (int j = 0; j < JN; j++) r[j] = 0.0;
+#pragma unroll
+    for (int j = 0; j < L / 4; j++) { const D4 d = next4(); w[4 * j] = d.v0; w[4 * j + 1] = d.v1; w[4 * j + 2] = d.v2; w[4 * j + 3] = d.v3; }
+    uint32_t a_unit = 0, flush_pos = n, q0 = 0;
+    bool done = false;
+#pragma unroll 1
+    while (!done) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {                     /* steps q0 .. q0+3 with element q0 + i in w[(4g + i) % W] */
+            if (!done) {
+                if (q0 >= flush_pos) {                     /* in the zero zone after a unit: store its lags, restart */
+                    if (store) {
+                        double *o = out + (size_t)a_unit * K + J0;
+#pragma unroll
+                        for (int j = 0; j < JN; j++) o[j] = r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < JN; j++) r[j] = 0.0;
+                    a_unit++;
+                    flush_pos += upl;
+                    done = (a_unit == u);
+                }
+                if (!done) {
+                    const D4 d = next4();
+                    w[(4 * g + L) % W] = d.v0; w[(4 * g + L + 1) % W] = d.v1; w[(4 * g + L + 2) % W] = d.v2; w[(4 * g + L + 3) % W] = d.v3;
+#pragma unroll
+                    for (int tt = 0; tt < 4; tt++) {
+#pragma unroll
+                        for (int j = 0; j < JN; j++) r[j] += w[(4 * g + tt) % W] * w[(4 * g + tt + J0 + j) % W];
+                    }
+                    q0 += 4;
+                }
+            }
+        }
+    }
+}
+
+/* Short layers (P <= 16).  grid.x = groups of 64 rows: a row is a job, or for layer 0 a channel-frame (its input, the
+ * pre-emphasised channel, is the same for every regulariser pass, so the lags are computed once and the Levinson kernels
+ * read pass 0's copy).  A wave of the block owns 2 to 7 lags of one trial of the 64 rows (AcsWaves), ordered so that the
+ * SIMDs of the CU carry about the same number of lags. */
+template <int P> struct AcsWaves;
+template <> struct AcsWaves<16> { static constexpr int NW = 8; };
+template <> struct AcsWaves<8>  { static constexpr int NW = 5; };
+template <> struct AcsWaves<4>  { static constexpr int NW = 3; };
+template <> struct AcsWaves<2>  { static constexpr int NW = 2; };
+
+template <int P, bool L0>
+__global__ __launch_bounds__(64 * AcsWaves<P>::NW, 4) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    using Cfg = AcCfg<P>;
+    constexpr int NT = Cfg::NT, NW = AcsWaves<P>::NW;
+    __shared__ double tile[2][ACS_T][65];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t rstride = L0 ? p.R : 1u, nrows = p.J / rstride, row0 = blockIdx.x * 64;
+    uint32_t row = row0 + lane;
+    const bool inrange = row < nrows;
+    if (!inrange) row = nrows - 1;
+    const uint32_t job = row * rstride;
+    const uint32_t ci = p.cls_of_frame[(job / p.R) / p.C];
+    const uint32_t ci0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)ci);
+    const DevClass &c0 = p.cls[ci0];
+    const uint32_t na = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.na);
+    const bool fast = __all(ci == ci0) && c0.ntrials[layer] == (uint32_t)NT && (na % (4u << (NT - 1))) == 0 && (na % ACS_T) == 0;
+#define ACS_RUN(T_, K_, J0_, JN_) autocorr_shared<K_, J0_, JN_, L0, NW>(p, layer, cur, row0, nrows, rstride, na, \
+        (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.wt_off[layer][T_]), T_, wave, lane, tile)
+    if (fast) {                                             /* every wave of the block sees the same rows: same decision */
+        if (P == 16) switch (wave) {                        /* waves w and w+4 share a SIMD: 9 / 9 / 10 / 8 lags per SIMD */
+            case 0: ACS_RUN(0, 17, 10, 7); break; case 1: ACS_RUN(0, 17, 0, 5); break;  case 2: ACS_RUN(0, 17, 5, 5); break;
+            case 3: ACS_RUN(1, 9, 0, 5); break;   case 4: ACS_RUN(4, 2, 0, 2); break;   case 5: ACS_RUN(1, 9, 5, 4); break;
+            case 6: ACS_RUN(2, 5, 0, 5); break;   default: ACS_RUN(3, 3, 0, 3); break;
+        } else if (P == 8) switch (wave) {
+            case 0: ACS_RUN(0, 9, 0, 5); break;   case 1: ACS_RUN(0, 9, 5, 4); break;   case 2: ACS_RUN(1, 5, 0, 5); break;
+            case 3: ACS_RUN(2, 3, 0, 3); break;   default: ACS_RUN(3, 2, 0, 2); break;
+        } else if (P == 4) switch (wave) {
+            case 0: ACS_RUN(0, 5, 0, 5); break;   case 1: ACS_RUN(1, 3, 0, 3); break;   default: ACS_RUN(2, 2, 0, 2); break;
+        } else switch (wave) {
+            case 0: ACS_RUN(0, 3, 0, 3); break;   default: ACS_RUN(1, 2, 0, 2); break;
+        }
+        return;
+    }
+#undef ACS_RUN
+    /* general form: the first NT waves take one whole trial each */
+    if (wave >= (uint32_t)NT) return;
+    const uint32_t t = wave;
+    const bool active = inrange && (t < job_class(p, job).ntrials[layer]);
+    const uint32_t q_end = na_max + Cfg::MAXPAD + 8;
+    switch (P >> t) {       /* wave-uniform: the trial fixes the number of lags */
+    case 16: if (P >= 16) autocorr_lane<17, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 8:  if (P >= 8)  autocorr_lane<9, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 4:  if (P >= 4)  autocorr_lane<5, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 2:  autocorr_lane<3, L0>(p, layer, cur, q_end, job, t, active); break;
+    default: autocorr_lane<2, L0>(p, layer, cur, q_end, job, t, active); break;
+    }
+}
+
+template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    const uint32_t nrows = (layer == 0) ? p.J / p.R : p.J;
+    const dim3 grid((nrows + 63) / 64);
+    if (layer == 0) hipLaunchKernelGGL((k_autocorr_lane<P, true>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
+    else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
+}
+
+template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    using Cfg = AcCfg<P>;
+    const uint32_t blocks = (p.J + Cfg::JPW - 1) / Cfg::JPW;
+    if (layer == 0) hipLaunchKernelGGL((k_autocorr2<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
+    else hipLaunchKernelGGL((k_autocorr2<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
+}
+static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
+{
+    switch (p.P[layer]) {
+    case 2: launch_autocorr_small<2>(st, p, layer, cur, na_max); break;
+    case 4: launch_autocorr_small<4>(st, p, layer, cur, na_max); break;
+    case 8: launch_autocorr_small<8>(st, p, layer, cur, na_max); break;
+    case 16: launch_autocorr_small<16>(st, p, layer, cur, na_max); break;
+    case 32: launch_autocorr2<32>(st, p, layer, cur, na_max); break;
+    case 64: launch_autocorr2<64>(st, p, layer, cur, na_max); break;
+    default: launch_autocorr2<128>(st, p, layer, cur, na_max); break;
+    }
+}
+
+
+#endif

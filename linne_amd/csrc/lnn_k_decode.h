@@ -1,0 +1,326 @@
+/* lnn_k_decode.h -- decode kernels: k_synth_small, k_synth_big, k_synthesize, k_ms_to_lr.
+ * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
+#ifndef LNN_K_DECODE_H_INCLUDED
+#define LNN_K_DECODE_H_INCLUDED
+
+/* ------------------------------------------------------------------------------------------------
+ * decode: synthesis cascade + de-emphasis per channel-frame (one wavefront), MS->LR per frame
+ * ---------------------------------------------------------------------------------------------- */
+struct DecPlan {
+    uint32_t C, S, L, ms, F;
+    uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
+    int32_t *data; const int32_t *prm; const uint32_t *nsmp;
+};
+
+/* wrap-around sum of one int per lane over the 64-lane wavefront (associative, so a DPP tree is exact) */
+__device__ __forceinline__ int32_t wave_sum_i32(int32_t v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   /* row_bcast:15 -> rows 1,3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   /* row_bcast:31 -> rows 2,3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+/* One wavefront per channel-frame, data streamed through registers in 64-sample chunks (coalesced loads/stores):
+ *   - the 128-slot history ring of the recurrence lives in two registers per lane (slot = sample index mod 128);
+ *     the chunk being reconstructed IS one of them, so finished samples are already where the next steps need them
+ *     and the chunk is stored from that register;
+ *   - taps are spread over the lanes, the rotating zero-extended coefficient ring sits in 512 B of LDS, the int32
+ *     dot product is reduced with the DPP tree (wrap-around addition is associative);
+ *   - the residual of the step is picked from the loaded chunk with a scalar readlane; the next chunk's load is in
+ *     flight meanwhile.
+ * No per-channel LDS staging, so occupancy is limited by registers only. */
+__global__ __launch_bounds__(64) void k_synthesize(DecPlan p, uint32_t only_layer, uint32_t deemph)
+{
+    __shared__ int32_t cpad[128];
+    const uint32_t cf = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = p.nsmp[cf / p.C], S = p.S;
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    int32_t *g = p.data + (size_t)cf * S;
+    /* linne_decoder.c:503-509: layers in reverse order; linne_lpc_synthesize.c:8-83: units are independent */
+    for (int32_t l = (int32_t)p.L - 1; l >= 0; l--) {
+        if (only_layer != 0xFFFFFFFFu && (uint32_t)l != only_layer) continue;
+        const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
+        const uint32_t np = p.P[l] / (units ? units : 1u), ns = n / (units ? units : 1u);
+        const uint32_t half = 1u << ((rs - 1u) & 31u);
+        if (units == 0 || np == 0 || ns < np) continue;
+        for (uint32_t unit = 0; unit < units; unit++) {
+            int32_t *x = g + (size_t)unit * ns;
+            __syncthreads();                /* previous unit/layer: its stores are issued, cpad is free */
+            for (uint32_t j = lane; j < 128; j += 64) cpad[j] = (j >= 128 - np) ? rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + unit * np + (j - (128 - np))] : 0;
+            __syncthreads();
+            /* history: slot m holds x[t'] with t' = m (mod 128); the first np samples pass through unchanged */
+            int32_t h0 = (lane < np) ? x[lane] : 0, h1 = (lane + 64 < np) ? x[lane + 64] : 0;
+            const uint32_t c_first = np & ~63u;
+            int32_t vin = (c_first + lane < ns) ? x[c_first + lane] : 0;
+            for (uint32_t c0 = c_first; c0 < ns; c0 += 64) {
+                const int32_t cur = vin;
+                if (c0 + 64 < ns) vin = (c0 + 64 + lane < ns) ? x[c0 + 64 + lane] : 0;       /* prefetch the next chunk */
+                const uint32_t t_begin = (c0 > np) ? c0 : np, t_end = (c0 + 64 < ns) ? (c0 + 64) : ns;
+                const bool odd = (c0 >> 6) & 1u;
+                int32_t hr = odd ? h1 : h0;                 /* the register this chunk is reconstructed into */
+                for (uint32_t t = t_begin; t < t_end; t++) {
+                    const int32_t ca = cpad[(lane - t) & 127u], cb = cpad[(lane + 64u - t) & 127u];
+                    const int32_t ha = odd ? h0 : hr, hb = odd ? hr : h1;
+                    const int32_t acc = (int32_t)((uint32_t)ha * (uint32_t)ca + (uint32_t)hb * (uint32_t)cb);
+                    const uint32_t pred = half + (uint32_t)wave_sum_i32(acc);
+                    const int32_t res = __builtin_amdgcn_readlane(cur, (int)(t - c0));
+                    const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
+                    if (lane == (t & 63u)) hr = y;
+                }
+                if (odd) h1 = hr; else h0 = hr;
+                if (c0 + lane >= t_begin && c0 + lane < t_end) x[c0 + lane] = hr;
+            }
+        }
+    }
+    __syncthreads();
+    /* two-stage de-emphasis (linne_utility.c:215-241): stage-2 inverse then stage-1 inverse, fused; the recurrence
+     * itself is scalar (wave-uniform), chunks of 64 samples move through a register */
+    if (n > 0 && deemph) {
+        const int32_t c0e = rec[LINNE_AMD_PRM_PCOEF + 0], c1e = rec[LINNE_AMD_PRM_PCOEF + 1];
+        int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
+        int32_t vin = (lane < n) ? g[lane] : 0;
+        for (uint32_t c0 = 0; c0 < n; c0 += 64) {
+            const int32_t cur = vin;
+            if (c0 + 64 < n) vin = (c0 + 64 + lane < n) ? g[c0 + 64 + lane] : 0;
+            const uint32_t cnt = (n - c0 < 64) ? (n - c0) : 64;
+            int32_t outv = cur;
+            for (uint32_t i = 0; i < cnt; i++) {
+                const int32_t b = __builtin_amdgcn_readlane(cur, (int)i);
+                const int32_t z = (int32_t)((uint32_t)b + (uint32_t)mulshr5(zp, c1e));
+                const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                zp = z; yp = y;
+                if (lane == i) outv = y;
+            }
+            if (lane < cnt) g[c0 + lane] = outv;
+        }
+    }
+}
+
+/* Synthesis of a SHORT layer (order <= 16), lanes = channel-frames: a wavefront reconstructs the same layer of 64
+ * channel-frames, each lane running its own recurrence (linne_lpc_synthesize.c:8-83) with its unit's coefficients
+ * (zero-extended to PL taps) and the last PL outputs in registers -- the time loop is unrolled over one turn of that
+ * history ring, so no register moves.  The int32 dot product is evaluated in FP64: coefficients are 8-bit, so
+ * |sum c*y| < 2^45 and every FMA is exact; the sum is then reduced modulo 2^32, which is what the reference's wrap-around
+ * int32 accumulation holds.  Samples travel in 64 x 64 tiles transposed through LDS (coalesced loads and stores, next
+ * tile prefetched into registers).  DEEMPH fuses the two de-emphasis stages (linne_utility.c:215-241), a scalar
+ * recurrence per lane, behind layer 0. */
+#define SYN_T 64
+template <int PL, bool DEEMPH>
+__global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
+{
+    __shared__ int32_t tile[SYN_T][65];
+    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64, S = p.S;
+    const uint32_t nrows = p.F * p.C;
+    uint32_t cf = row0 + lane;
+    const bool have = cf < nrows;
+    if (!have) cf = nrows - 1;
+    const uint32_t n = p.nsmp[cf / p.C];
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + layer], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + layer];
+    const uint32_t np = (units ? PL / units : 0u), ns = (units ? n / units : 0u);
+    const bool skip = (units == 0 || np == 0 || ns < np);         /* linne_decoder.c: such a layer leaves the data unchanged */
+    const uint32_t half = 1u << ((rs - 1u) & 31u);
+    const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
+    double c[PL], h[PL];
+#pragma unroll
+    for (int k = 0; k < PL; k++) { c[k] = 0.0; h[k] = 0.0; }
+    uint32_t tl = 0, unit = 0;                                   /* place inside the current unit; its index */
+    bool fresh = true;                                           /* the unit's coefficients are not loaded yet */
+    int32_t zp = 0, yp = 0, c0e = 0, c1e = 0;
+    if (DEEMPH) { c0e = rec[LINNE_AMD_PRM_PCOEF + 0]; c1e = rec[LINNE_AMD_PRM_PCOEF + 1]; zp = rec[LINNE_AMD_PRM_PREV + 1]; yp = rec[LINNE_AMD_PRM_PREV + 0]; }
+    /* wave-uniform number of tiles: the longest frame of the block */
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    const uint32_t ntiles = (nmax + SYN_T - 1) / SYN_T;
+    int32_t pre[64];
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const uint32_t row = (row0 + r < nrows) ? row0 + r : nrows - 1, sidx = t * SYN_T + lane;
+            pre[r] = (sidx < S) ? p.data[(size_t)row * S + sidx] : 0;
+        }
+    };
+    if (ntiles) issue(0);
+    for (uint32_t t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) tile[lane][r] = pre[r];      /* transposed: tile[sample][row] */
+        if (t + 1 < ntiles) issue(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t s0 = 0; s0 < SYN_T; s0 += PL) {
+#pragma unroll
+            for (int tt = 0; tt < PL; tt++) {                    /* sample index = tt (mod PL): ring slot tt is the oldest */
+                const uint32_t sidx = t * SYN_T + s0 + tt;
+                if (fresh && !skip && unit < units) {            /* first sample of a unit: its zero-extended coefficients */
+#pragma unroll
+                    for (int k = 0; k < PL; k++) c[k] = ((uint32_t)k >= PL - np) ? (double)crec[unit * np + ((uint32_t)k - (PL - np))] : 0.0;
+                }
+                fresh = false;
+                const int32_t res = tile[s0 + tt][lane];
+                /* four partial sums (exact integers: any order) keep the FMA chain short */
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int k = 0; k < PL; k++) {
+                    const double prod_h = h[(tt + k) % PL];
+                    if ((k & 3) == 0) a0 = __builtin_fma(c[k], prod_h, a0);
+                    else if ((k & 3) == 1) a1 = __builtin_fma(c[k], prod_h, a1);
+                    else if ((k & 3) == 2) a2 = __builtin_fma(c[k], prod_h, a2);
+                    else a3 = __builtin_fma(c[k], prod_h, a3);
+                }
+                const double acc = (a0 + a1) + (a2 + a3);
+                const uint32_t sum32 = (uint32_t)__double2loint(acc + 6755399441055744.0);   /* acc mod 2^32: |acc| < 2^45, so adding 1.5 * 2^52 leaves the integer in the low mantissa bits, two's complement */
+                const uint32_t pred = half + sum32;
+                int32_t y = res;
+                if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
+                h[tt] = (double)y;
+                tl++;
+                if (tl == ns) { tl = 0; unit++; fresh = true; }
+                if (DEEMPH) {
+                    const int32_t z = (int32_t)((uint32_t)y + (uint32_t)mulshr5(zp, c1e));
+                    const int32_t yy = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                    if (sidx < n) { zp = z; yp = yy; }
+                    y = yy;
+                }
+                tile[s0 + tt][lane] = y;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const uint32_t row = row0 + r, sidx = t * SYN_T + lane;
+            if (row < nrows && sidx < p.nsmp[row / p.C]) p.data[(size_t)row * S + sidx] = tile[lane][r];
+        }
+        __syncthreads();
+    }
+}
+
+/* Synthesis of a LONG layer (order 32..128), four lanes per channel-frame: a wavefront reconstructs the same layer of 16
+ * channel-frames; lane g of a channel-frame owns the taps k = g (mod 4) of the zero-extended coefficient vector, in
+ * registers as doubles.  The last PL outputs live in LDS as doubles in a ring stored twice (slot i and i + PL), so a
+ * lane's taps are a strided run without wrap-around, read with immediate offsets; the row stride and the tap
+ * interleaving put the 32 lanes of each LDS access group on 32 different banks.  The int32 dot product is evaluated in
+ * FP64 (exact, see k_synth_small), the four partial sums of a channel-frame meet through two DPP quad permutes, and
+ * every lane of the quad finishes the step redundantly.  The newest output is forwarded in a register (its tap belongs
+ * to lane 3), so the LDS write -> read round trip is off the critical path. */
+#define SYB_T 64
+template <int PL>
+__global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
+{
+    constexpr int TP = PL / 4;                                   /* taps per lane */
+    constexpr int RSTR = 2 * PL + 4;                             /* ring row stride in doubles: = 4 (mod 32) */
+    __shared__ __attribute__((aligned(16))) double ring[16 * RSTR];
+    __shared__ int32_t tile[16][SYB_T];
+    const uint32_t lane = threadIdx.x, cfl = lane >> 2, g = lane & 3u, S = p.S;
+    const uint32_t nrows = p.F * p.C, row0 = blockIdx.x * 16;
+    uint32_t cf = row0 + cfl;
+    if (cf >= nrows) cf = nrows - 1;
+    const uint32_t n = p.nsmp[cf / p.C];
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + layer], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + layer];
+    const uint32_t np = (units ? PL / units : 0u), ns = (units ? n / units : 0u);
+    const bool skip = (units == 0 || np == 0 || ns < np);
+    const uint32_t half = 1u << ((rs - 1u) & 31u);
+    const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
+    double c[TP];
+#pragma unroll
+    for (int j = 0; j < TP; j++) c[j] = 0.0;
+    double *myring = ring + cfl * RSTR;
+    for (uint32_t i = g; i < 2 * PL; i += 4) myring[i] = 0.0;
+    uint32_t tl = 0, unit = 0;
+    bool fresh = true;
+    double ynew = 0.0, part = 0.0;                               /* the previous step's output, forwarded; the partial sum made ahead */
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    const uint32_t ntiles = (nmax + SYB_T - 1) / SYB_T;
+    int32_t pre[16];
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t row = (row0 + r < nrows) ? row0 + r : nrows - 1, sidx = t * SYB_T + lane;
+            pre[r] = (sidx < S) ? p.data[(size_t)row * S + sidx] : 0;
+        }
+    };
+    if (ntiles) issue(0);
+    __syncthreads();
+    for (uint32_t t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) tile[r][lane] = pre[r];
+        if (t + 1 < ntiles) issue(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t s = 0; s < SYB_T; s++) {
+            const uint32_t sidx = t * SYB_T + s, tm = sidx & (PL - 1);
+            if (fresh && !skip && unit < units) {                /* first sample of a unit: my taps of its zero-extended coefficients */
+#pragma unroll
+                for (int j = 0; j < TP; j++) {
+                    const uint32_t k = 4u * (uint32_t)j + g;
+                    c[j] = (k >= PL - np) ? (double)crec[unit * np + (k - (PL - np))] : 0.0;
+                }
+            }
+            fresh = false;
+            const int32_t res = tile[cfl][s];
+            /* tap k = 4j + g multiplies y[sidx - PL + k] (ring position tm + k).  Everything but the newest tap (k = PL - 1,
+             * lane 3) was summed during the previous step (`part`); only that one product is on this step's critical path */
+            double acc = (g == 3u) ? __builtin_fma(c[TP - 1], ynew, part) : part;
+            {   /* quad sum: lanes 4q .. 4q+3 */
+                int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0xB1, 0xf, 0xf, true);     /* quad_perm: 1,0,3,2 */
+                int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0xB1, 0xf, 0xf, true);
+                acc += __hiloint2double(hi, lo);
+                lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0x4E, 0xf, 0xf, true);         /* quad_perm: 2,3,0,1 */
+                hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0x4E, 0xf, 0xf, true);
+                acc += __hiloint2double(hi, lo);
+            }
+            {   /* next step's partial sum: positions tm + 1 + k, k <= PL - 2 -- none of them is written by this step */
+                const double *hp = myring + ((tm + 1u) & (PL - 1)) + g;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                for (int j = 0; j < TP - 1; j++) {
+                    const double hv = hp[4 * j];
+                    if ((j & 3) == 0) a0 = __builtin_fma(c[j], hv, a0);
+                    else if ((j & 3) == 1) a1 = __builtin_fma(c[j], hv, a1);
+                    else if ((j & 3) == 2) a2 = __builtin_fma(c[j], hv, a2);
+                    else a3 = __builtin_fma(c[j], hv, a3);
+                }
+                const double hl = (g == 3u) ? 0.0 : hp[4 * (TP - 1)];
+                a3 = __builtin_fma(c[TP - 1], hl, a3);
+                part = (a0 + a1) + (a2 + a3);
+            }
+            const uint32_t sum32 = (uint32_t)__double2loint(acc + 6755399441055744.0);      /* acc mod 2^32 (see k_synth_small) */
+            const uint32_t pred = half + sum32;
+            int32_t y = res;
+            if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
+            ynew = (double)y;
+            if (g == 0) { myring[tm] = ynew; myring[tm + PL] = ynew; tile[cfl][s] = y; }
+            tl++;
+            if (tl == ns) { tl = 0; unit++; fresh = true; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const uint32_t row = row0 + r, sidx = t * SYB_T + lane;
+            if (row < nrows && sidx < p.nsmp[row / p.C]) p.data[(size_t)row * S + sidx] = tile[r][lane];
+        }
+        __syncthreads();
+    }
+}
+
+/* MS -> LR (linne_utility.c:135-147) */
+__global__ void k_ms_to_lr(DecPlan p)
+{
+    const uint32_t f = blockIdx.x, s = blockIdx.y * blockDim.x + threadIdx.x;      /* grid = (frames, sample tiles) */
+    if (s >= p.nsmp[f]) return;
+    int32_t *m = p.data + (size_t)f * p.C * p.S, *sd = m + p.S;
+    const uint32_t l = (uint32_t)m[s] - (uint32_t)(sd[s] >> 1);
+    m[s] = (int32_t)l;
+    sd[s] = (int32_t)((uint32_t)sd[s] + l);
+}
+
+
+
+#endif

@@ -1,0 +1,323 @@
+/* lnn_k_fir.h -- double-precision FIR kernels (k_fir2), ordered sums (k_chain_sum) and the unit-count decision (k_select).
+ * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
+#ifndef LNN_K_FIR_H_INCLUDED
+#define LNN_K_FIR_H_INCLUDED
+
+/* ------------------------------------------------------------------------------------------------
+ * K_C / K_D (v2): the two double-precision FIR evaluations of a layer, register-blocked.
+ *   MODE 0  trial residual magnitude for every unit-count trial (linne_network.c:318-335):
+ *           residual = x[s]; residual += h[k]*x[s-p+k], k = 0..p-1; |residual| -> wx[job][trial][s]
+ *   MODE 1  forward with the chosen unit count (linne_network.c:165-210):
+ *           predict = 0; predict += h[k]*x[s-p+k]; out[s] = x[s] + predict
+ * A lane owns 4 consecutive samples and slides a 4-wide register window over the taps: per 4 taps it issues
+ * 16 unfused mul+add pairs against 4 LDS reads (2 of samples, 2 of coefficients).  Each sample's sum stays one
+ * chain in increasing tap order.  Lanes whose 4 samples touch the start of the frame (taps are skipped there),
+ * a unit boundary of a ragged tail frame, or p < 4 take the sample-at-a-time path.
+ * ---------------------------------------------------------------------------------------------- */
+/* order-free sum of one double per lane over the wavefront, result in lane 63 (DPP row shifts / broadcasts on the two
+ * halves of the value: no LDS round trip, unlike __shfl_xor).  Only for sums whose order is free (the certified search). */
+__device__ __forceinline__ double wave_sum_f64_lane63(double v)
+{
+#define LNN_DPP_ADD(CTRL, ROWMASK) { \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true); \
+        v += __hiloint2double(hi_, lo_); }
+    LNN_DPP_ADD(0x111, 0xf)   /* row_shr:1 */
+    LNN_DPP_ADD(0x112, 0xf)   /* row_shr:2 */
+    LNN_DPP_ADD(0x114, 0xf)   /* row_shr:4 */
+    LNN_DPP_ADD(0x118, 0xf)   /* row_shr:8 */
+    LNN_DPP_ADD(0x142, 0xa)   /* row_bcast:15 -> rows 1, 3 */
+    LNN_DPP_ADD(0x143, 0xc)   /* row_bcast:31 -> rows 2, 3 */
+#undef LNN_DPP_ADD
+    return v;
+}
+
+#define FIR_THREADS 256
+#define FIR_SPL     8                       /* consecutive samples per lane */
+#define FIR_TILE    (FIR_THREADS * FIR_SPL)
+template <int MODE, bool L0>
+__global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
+{
+    __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
+    __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
+    __shared__ __attribute__((aligned(16))) double ob[(MODE == 2) ? 1 : FIR_THREADS / 64][(MODE == 2) ? 2 : 64 * FIR_SPL];   /* per-wave store transpose (MODE 0/1) */
+    __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
+    const uint32_t job = blockIdx.x, tid = threadIdx.x;          /* grid = (jobs, tiles): the job count is not bound by 65535 */
+    if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
+    const DevClass &c = job_class(p, job);
+    const uint32_t na = c.na;
+    const uint32_t P = p.P[layer];
+    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;          /* layer 0 reads the pre-emphasised int32 channel (linne_encoder.c:661-663) */
+    const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
+    if (MODE == 0 && tid < LNN_MAXT) chain[tid] = 0.0;
+    {
+        const double *hsrc = (MODE != 1) ? (p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
+        for (uint32_t i = tid; i < ntr * LNN_MAXP; i += FIR_THREADS) { const uint32_t tt = i / LNN_MAXP, k = i % LNN_MAXP; if (k < P) hs[tt][k] = hsrc[i]; }
+    }
+    /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
+    for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.y * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
+    __syncthreads();
+    if (!L0 && s0 >= LNN_MAXP && s0 + FIR_TILE + 8 <= na) {          /* interior tile: 16-byte loads (S, s0, MAXP are even) */
+        for (uint32_t i = 2 * tid; i < LNN_MAXP + FIR_TILE + 8; i += 2 * FIR_THREADS)
+            *(lnn_d2 *)(xs + i) = *(const lnn_d2 *)(x + (s0 - LNN_MAXP + i));
+    } else {
+        for (uint32_t i = tid; i < LNN_MAXP + FIR_TILE + 8; i += FIR_THREADS) {
+            const int64_t g = (int64_t)s0 - LNN_MAXP + i;
+            xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
+        }
+    }
+    const uint32_t s = s0 + FIR_SPL * tid;
+    const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
+    for (uint32_t t = 0; t < ntr; t++) {
+        const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
+        const uint32_t n = na / u, np = P / u;
+        const double *hbuf = hs[t];
+        if (t == 0) __syncthreads();                                 /* tile and coefficients are staged */
+        double acc[FIR_SPL];
+        if (s < na) {
+            /* all FIR_SPL samples in one unit, every tap present */
+            const bool whole = ((n & (FIR_SPL - 1)) == 0) && (s >= np) && (s + FIR_SPL - 1 < na);
+            if (whole && (np & 3u) == 0) {
+                const double *hb = hbuf + (size_t)(s / n) * np;
+                const double *xw = xc - np;                              /* -> x[s - np] */
+                /* Window x[s-np+k .. +11] in a register ring of 16 (element e lives in w[e % 16]): a step of 4 taps reads
+                 * 11 of them, the LDS reads of the next step's 4 new samples and coefficients land in the free quarter
+                 * while the 32 multiply-adds of this step issue, and nothing is ever moved. */
+                double w[16];
+                static_assert(FIR_SPL == 8, "the ring below is laid out for 8 samples per lane");
+#pragma unroll
+                for (int j = 0; j < 12; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE != 1) ? xc[j] : 0.0;
+                lnn_d2 ha0 = *(const lnn_d2 *)(hb), ha1 = *(const lnn_d2 *)(hb + 2), hb0, hb1;
+                uint32_t k = 0;
+#define FIR_STEP(G, HC0, HC1, HN0, HN1) { \
+                    const lnn_d2 na_ = *(const lnn_d2 *)(xw + k + 12), nb_ = *(const lnn_d2 *)(xw + k + 14);   /* in bounds: xs/hs are padded */ \
+                    HN0 = *(const lnn_d2 *)(hb + k + 4); HN1 = *(const lnn_d2 *)(hb + k + 6); \
+                    w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y; \
+                    const double hh_[4] = { HC0.x, HC0.y, HC1.x, HC1.y }; \
+                    _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
+                        _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) acc[j] += hh_[kk] * w[(4 * G + kk + j) % 16]; } \
+                    k += 4; }
+                for (;;) {
+                    FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
+                    FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
+                    FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
+                    FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
+                }
+#undef FIR_STEP
+            } else if (whole && np <= 2) {
+                const double *hb = hbuf + (size_t)(s / n) * np;
+                const double h0 = hb[0];
+                if (np == 1) {
+#pragma unroll
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
+                } else {
+                    const double h1 = hb[1];
+#pragma unroll
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < FIR_SPL; j++) {
+                    const uint32_t sj = s + j;
+                    double v = (MODE != 1) ? xc[j] : 0.0;
+                    if (sj < na && sj != 0) {
+                        const double *hb = hbuf + (size_t)(sj / n) * np;
+                        const uint32_t kstart = (sj < np) ? (np - sj) : 0;  /* taps before sample 0 are skipped */
+                        for (uint32_t k = kstart; k < np; k++) v += hb[k] * xc[(int)j - (int)np + (int)k];
+                    }
+                    acc[j] = v;
+                }
+            }
+            /* results: |residual| (MODE 0) or x + predict (MODE 1) */
+#pragma unroll
+            for (int j = 0; j < FIR_SPL; j++) {
+                if (MODE != 1) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; acc[j] = av; }
+                else { const double xv = xc[j]; acc[j] = (s + j == 0) ? xv : (xv + acc[j]); }
+            }
+        }
+        if (MODE == 2) {
+            /* order-free partial sum of this wave's |residual| values; the exact ordered chain is evaluated later only for
+             * jobs whose argmin these sums cannot certify (k_select) */
+            double ps = 0.0;
+            if (s < na) {
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) if (s + j < na) ps += acc[j];
+            }
+            ps = wave_sum_f64_lane63(ps);
+            if ((tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
+        } else if (MODE == 0) {
+            /* exact path: the tile's |residual| values go to LDS in sample order and ONE lane adds them to the trial's
+             * running sum, continuing the single chain of linne_network.c:326-337 across tiles */
+            if (s < na) {
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) ob[0][FIR_SPL * tid + j] = (s + j < na) ? acc[j] : 0.0;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                const uint32_t cnt = (na - s0 < FIR_TILE) ? (na - s0) : FIR_TILE;
+                double v = chain[t];
+                for (uint32_t i = 0; i < cnt; i++) v += ob[0][i];
+                chain[t] = v;
+            }
+            __syncthreads();
+        } else {   /* coalesced store: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive lanes write
+             * consecutive 16-byte pieces (a lane's own 8 results are 64 bytes apart from its neighbour's) */
+            const uint32_t wv = tid >> 6, ln = tid & 63u, wbase = s0 + wv * 64 * FIR_SPL;
+            double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
+            if (wbase < na) {
+                if (s < na) {
+#pragma unroll
+                    for (int j = 0; j < FIR_SPL; j += 2) { lnn_d2 v; v.x = acc[j]; v.y = acc[j + 1]; *(lnn_d2 *)(&ob[wv][ln * FIR_SPL + j]) = v; }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0): the wave's own LDS writes have landed */
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < FIR_SPL / 2; i++) {
+                    const uint32_t e = 2 * ln + 128 * i, g = wbase + e;
+                    if (g + 1 < na) *(lnn_d2 *)(dst + g) = *(const lnn_d2 *)(&ob[wv][e]);
+                    else if (g < na) dst[g] = ob[wv][e];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    }
+    if (MODE == 0) {
+        __syncthreads();
+        if (tid < ntr) p.tloss[(size_t)job * LNN_MAXT + tid] = chain[tid] / (double)na;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * ordered sums (v2): 64 chains per wavefront.  Rows are staged through LDS with coalesced loads and each lane then
+ * adds its own row strictly in sample order, so every sum is the same single chain the reference evaluates.
+ *   MODE 0  mean |residual| of each trial  (rows of wx)            (linne_network.c:326,334,337)
+ *   MODE 1  L1 loss of the last layer's output (rows of sig, fabs) (linne_network.c:50-63)
+ * ---------------------------------------------------------------------------------------------- */
+#define SUM_THREADS 256
+template <int MODE>
+__global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t layer, uint32_t cur)
+{
+    __shared__ double tile[2][64][65];
+    __shared__ uint32_t row_na[64];
+    __shared__ const double *row_ptr[64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, row0 = blockIdx.x * 64;
+    const uint32_t nrows = (MODE == 0) ? p.J * LNN_MAXT : p.J;
+    /* wave 0's lanes own the 64 chains; all four waves stage 16 rows each */
+    uint32_t my_na = 0;
+    if (wave == 0) {
+        const uint32_t myrow = row0 + lane;
+        const double *my_ptr = p.sig;               /* always dereferenceable */
+        if (myrow < nrows) {
+            const uint32_t job = (MODE == 0) ? myrow / LNN_MAXT : myrow;
+            const DevClass &c = job_class(p, job);
+            if (MODE == 1 || ((myrow % LNN_MAXT) < c.ntrials[layer] && p.uncertain[job])) {
+                my_na = c.na;
+                my_ptr = p.sig + ((size_t)job * 2 + cur) * p.S;
+            }
+        }
+        row_na[lane] = my_na; row_ptr[lane] = my_ptr;
+    }
+    __syncthreads();
+    uint32_t na_blk = 0;
+    for (uint32_t i = 0; i < 64; i++) na_blk = row_na[i] > na_blk ? row_na[i] : na_blk;     /* uniform loop bound */
+    const uint32_t ntiles = (na_blk + 63) / 64;
+    double ld[16];
+    auto fetch = [&](uint32_t tileidx) {            /* 16 unconditional loads in flight; zero beyond a row's end */
+        const uint32_t sl = tileidx * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint32_t r = wave * 16 + i, rn = row_na[r];
+            const uint32_t idx = (sl < rn) ? sl : 0u;
+            double v = row_ptr[r][idx];
+            if (MODE == 1) v = fabs(v);
+            ld[i] = (sl < rn) ? v : 0.0;            /* adding +0.0 leaves a non-negative chain unchanged */
+        }
+    };
+    auto stash = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) tile[buf][wave * 16 + i][lane] = ld[i];
+    };
+    double sum = 0.0;
+    if (ntiles) { fetch(0); stash(0); }
+    __syncthreads();
+    for (uint32_t k = 0; k < ntiles; k++) {
+        if (k + 1 < ntiles) fetch(k + 1);
+        if (wave == 0) {
+#pragma unroll 16
+            for (uint32_t j = 0; j < 64; j++) sum += tile[k & 1u][lane][j];
+        }
+        if (k + 1 < ntiles) stash((k + 1) & 1u);
+        __syncthreads();
+    }
+    if (wave == 0 && my_na) {
+        if (MODE == 0) p.tloss[row0 + lane] = sum / (double)my_na; else p.jloss[row0 + lane] = sum / (double)my_na;
+    }
+}
+
+/* strict-< argmin over the trials (linne_network.c:338-341), keep its coefficients (== SetParameter,
+ * :350-376, which recomputes the same values) and, for the last layer, the value the layer leaves in
+ * parcor[P0] (Q2): the last call in reference order -- trials in order, then SetParameter's units -- that
+ * wrote it. */
+__global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= p.J) return;
+    if (exact && !p.uncertain[job]) return;
+    const DevClass &c = job_class(p, job);
+    double min_loss = (double)FLT_MAX;
+    uint32_t best = 0;
+    const uint32_t nt = c.ntrials[layer];
+    if (exact) {
+        for (uint32_t t = 0; t < nt; t++) {
+            const double l = p.tloss[(size_t)job * LNN_MAXT + t];
+            if (l < min_loss) { min_loss = l; best = t; }
+        }
+    } else {
+        /* Certified search.  m_t below is the mean of an order-free sum of the same non-negative terms the reference
+         * adds sequentially; both sums are within gamma_n * S of the exact sum S, so they differ by at most
+         * rel = (2 na + 8) * 2^-53 relatively.  If the smallest mean is separated from every other by more than that,
+         * the reference's strict-< argmin (linne_network.c:338-341) is the same trial; otherwise the job is flagged and
+         * the ordered chains are evaluated (k_fir2<0>, then k_select exact). */
+        double m[LNN_MAXT];
+        const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
+        int ok = 1;
+        for (uint32_t t = 0; t < nt; t++) {
+            double sm = 0.0;
+            const uint32_t np_used = ((c.na + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64);
+            const double *ps = p.tsum + ((size_t)job * LNN_MAXT + t) * p.npart;
+            for (uint32_t i = 0; i < np_used; i++) sm += ps[i];
+            m[t] = sm / (double)c.na;
+            if (!(m[t] >= 0.0) || !(m[t] < (double)FLT_MAX)) ok = 0;
+            if (m[t] < min_loss) { min_loss = m[t]; best = t; }
+        }
+        for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) > min_loss * (1.0 + rel))) ok = 0;
+        p.uncertain[job] = ok ? 0 : 1;
+        if (!ok) atomicAdd(p.ucount, 1u);
+    }
+    const uint32_t P = p.P[layer];
+    p.lunits[(size_t)job * LNN_MAXL + layer] = c.trial_u[layer][best];
+    const double *h = p.tcoef + ((size_t)job * LNN_MAXT + best) * LNN_MAXP;
+    double *dst = p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP;
+    for (uint32_t k = 0; k < P; k++) dst[k] = h[k];
+    if (layer + 1 == p.L) {
+        double tail = 0.0; int set = 0;
+        const uint32_t bu = c.trial_u[layer][best];
+        for (int32_t unit = (int32_t)bu - 1; unit >= 0 && !set; unit--) {
+            const size_t o = ((size_t)job * LNN_MAXT + best) * LNN_MAXU + unit;
+            if (p.ptail_set[o]) { tail = p.ptail[o]; set = 1; }
+        }
+        for (int32_t t = (int32_t)c.ntrials[layer] - 1; t >= 0 && !set; t--)
+            for (int32_t unit = (int32_t)c.trial_u[layer][t] - 1; unit >= 0 && !set; unit--) {
+                const size_t o = ((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit;
+                if (p.ptail_set[o]) { tail = p.ptail[o]; set = 1; }
+            }
+        p.jtail[job] = tail;
+    }
+}
+
+
+#endif

@@ -1,0 +1,129 @@
+/* lnn_k_levinson.h -- ridge + Levinson-Durbin kernels (k_levinson, k_levinson_lds).
+ * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
+#ifndef LNN_K_LEVINSON_H_INCLUDED
+#define LNN_K_LEVINSON_H_INCLUDED
+
+/* ridge + Levinson-Durbin per (trial, unit) (lpc.c:327-366, 578-633 with zero AF iterations), lanes = jobs.
+ * Writes the coefficients in filter order (reversed, linne_network.c:310-316). */
+__global__ void k_levinson(Plan p, uint32_t layer)
+{
+    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
+    if (job >= p.J) return;
+    const DevClass &c = job_class(p, job);
+    uint32_t pr = blockIdx.y, t = 0;
+    for (; t < c.ntrials[layer]; t++) {
+        if (pr < c.trial_u[layer][t]) break;
+        pr -= c.trial_u[layer][t];
+    }
+    if (t >= c.ntrials[layer]) return;
+    const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u, unit = pr;
+    if (np >= 16u) return;                                  /* orders >= 16 are solved by k_levinson_lds */
+    const uint32_t P0 = p.P[0];
+    const double reg = p.regs[job % p.R];
+    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
+    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    double a[LNN_MAXP + 2];
+    double tail = 0.0; int tail_set = 0;
+    int zero = 0;
+    if (n < np) {                                           /* lpc.c:349-355 */
+        zero = 1;
+    } else {
+        const double r0 = r[0] * (1.0 + reg);               /* lpc.c:358 */
+        if (fabs(r0) < (double)FLT_EPSILON) zero = 1;       /* lpc.c:271-276, 597-602 */
+        else {
+            double pc[LNN_MAXP + 1];
+            levinson(r, r0, np, a, (layer + 1 == p.L) ? pc : nullptr);
+            if (layer + 1 == p.L && np > P0) { tail = pc[P0]; tail_set = 1; }
+        }
+    }
+    if (zero) {
+        for (uint32_t k = 0; k < np; k++) h[k] = 0.0;
+        if (np >= P0) { tail = 0.0; tail_set = 1; }         /* zero branches write parcor[0..order] */
+    } else {
+        for (uint32_t k = 0; k < np; k++) h[k] = a[np - k];
+    }
+    if (layer + 1 == p.L) {
+        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
+        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
+    }
+}
+
+#define LEV_WAVE_MIN_ORDER 16u      /* orders from here on are solved by k_levinson_lds, smaller ones by k_levinson */
+/* Levinson-Durbin for the large problems (order >= 16), lanes = jobs: a wavefront solves the SAME (trial, unit) problem of 64
+ * consecutive jobs, each lane running the scalar recursion of `levinson` above on its own column of two LDS arrays
+ * (a[i][lane], r[i][lane]: conflict-free 8-byte accesses).  Every wave instruction therefore advances 64 problems; the
+ * ordered sum a[0]r[k+1] + ... + a[k]r[1] (lpc.c:295-297) is one chain per lane.  grid = (job groups, units of the trial). */
+__global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uint32_t t)
+{
+    extern __shared__ __attribute__((aligned(16))) double lev_lds[];
+    const uint32_t lane = threadIdx.x, unit = blockIdx.y;
+    uint32_t job = blockIdx.x * 64 + lane;
+    const bool inrange = job < p.J;
+    if (!inrange) job = p.J - 1;
+    const DevClass &c = job_class(p, job);
+    const uint32_t P = p.P[layer], u = 1u << t, np = P >> t, P0 = p.P[0];
+    const bool have = inrange && t < c.ntrials[layer];
+    const uint32_t n = c.na / u;
+    double *sa = lev_lds + lane, *sr = lev_lds + (size_t)(np + 2) * 64 + lane;      /* element i at [i * 64] */
+    const double reg = p.regs[job % p.R];
+    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
+    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    const bool last = (layer + 1 == p.L);
+    for (uint32_t i = 0; i <= np; i++) sr[(size_t)i * 64] = have ? r[i] : 0.0;
+    for (uint32_t i = 0; i < np + 2; i++) sa[(size_t)i * 64] = 0.0;
+    double tail = 0.0; int tail_set = 0;
+    const double r0 = sr[0] * (1.0 + reg);                    /* lpc.c:358 */
+    const bool zero = (n < np) || (fabs(r0) < (double)FLT_EPSILON);      /* lpc.c:349-355, 271-276 */
+    {   /* lanes with a zero problem (or none) run along on values nobody reads */
+        const double r1 = sr[64];
+        double ek = r0;
+        const double a1 = -r1 / r0;
+        ek += r1 * a1;
+        sa[0] = 1.0; sa[64] = a1;
+        for (uint32_t k = 1; k < np; k++) {
+            double gamma = 0.0;
+            {
+                const double *pa = sa, *pr = sr + (size_t)(k + 1) * 64;
+                uint32_t i = 0;
+                for (; i + 4 <= k + 1; i += 4) {                /* four terms per trip, reads ahead of the adds */
+                    const double a0 = pa[0], a1_ = pa[64], a2 = pa[128], a3 = pa[192];
+                    const double q0 = pr[0], q1 = *(pr - 64), q2 = *(pr - 128), q3 = *(pr - 192);
+                    gamma += a0 * q0; gamma += a1_ * q1; gamma += a2 * q2; gamma += a3 * q3;
+                    pa += 256; pr -= 256;
+                }
+                for (; i <= k; i++) { gamma += pa[0] * pr[0]; pa += 64; pr -= 64; }
+            }
+            gamma /= -ek;
+            ek *= (1.0 - gamma * gamma);
+            const double a0n = 1.0 + gamma * 0.0;              /* u[0]   + gamma*v[0]   */
+            const double ak1 = 0.0 + gamma * 1.0;              /* u[k+1] + gamma*v[k+1] */
+            uint32_t i = 1, j = k;
+            while (i < j) {
+                const double ai = sa[(size_t)i * 64], aj = sa[(size_t)j * 64];
+                sa[(size_t)i * 64] = ai + gamma * aj;
+                sa[(size_t)j * 64] = aj + gamma * ai;
+                i++; j--;
+            }
+            if (i == j) { const double ai = sa[(size_t)i * 64]; sa[(size_t)i * 64] = ai + gamma * ai; }
+            sa[0] = a0n; sa[(size_t)(k + 1) * 64] = ak1;
+            if (last && k == P0) { tail = -gamma; tail_set = 1; }
+        }
+    }
+    if (!have) return;
+    if (zero) {
+        for (uint32_t k = 0; k < np; k++) h[k] = 0.0;
+        tail = 0.0; tail_set = (np >= P0) ? 1 : 0;             /* zero branches write parcor[0..order] */
+    } else {
+        for (uint32_t k = 0; k < np; k++) h[k] = sa[(size_t)(np - k) * 64];
+        if (!(last && np > P0)) { tail = 0.0; tail_set = 0; }
+    }
+    if (last) {
+        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
+        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
+    }
+}
+
+
+#endif

@@ -287,3 +287,24 @@ def test_own_cli_matches_the_reference_cli(tmp_path):
         r = str(tmp_path / (name + "_ref.wav"))
         subprocess.run([refcli, "-d", str(out / (name + ".lnn")), r], check=True, stdout=subprocess.DEVNULL)
         assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
+
+
+@pytest.mark.parametrize("kernel", ["wave", "lanes"])
+@pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
+def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
+    """DecodeFramesDevice picks its kernels by batch size (one wave per channel-frame for small batches; lanes =
+    channel-frames / four lanes per channel-frame for large ones, whose int32 dot products run in FP64).  Both forms must
+    restore the input exactly and agree with the oracle's synthesis, on every preset family, ragged tails included."""
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", kernel)
+    ms = nch >= 2
+    F = 5
+    frames = music_frames(F, nch, block, bits, seed=77 + nch + preset)
+    frames[1] = waveform("chirp", nch, block, bits, seed=3)
+    ns = np.full(F, block, dtype=np.uint32); ns[-1] = tail
+    frames[-1, :, tail:] = 0
+    shape = ctx.shape(nch, bits, block, preset, ms)
+    res, prm, st = ctx.encode_frames_host(shape, frames, ns)
+    dec = ctx.decode_frames_host(shape, res, prm, ns)
+    for f in range(F):
+        n = int(ns[f])
+        assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f}"
