@@ -448,7 +448,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         ps.pcm = d_pcm; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
         hipStream_t ss = ctx->stream;
         if (ctx->has_side && use_sub) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
-        const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames), dim3(64), 0, ss, ps); span_end(ctx, sp_, ss);
+        const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps); span_end(ctx, sp_, ss);
         if (ss != ctx->stream) HIPCHK(ctx, hipEventRecord(ctx->side_done, ss));
     }
     uint32_t chunk_index = 0;

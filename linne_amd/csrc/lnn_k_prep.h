@@ -137,48 +137,54 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
 }
 
 /* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW channel at
- * order P0 = layer-0 size, one chain per (channel, lag), then Levinson-Durbin.  Independent of the analysis, so it runs
- * on a side stream concurrently with it. */
-__global__ __launch_bounds__(64) void k_stats(Plan p)
+ * order P0 = layer-0 size, then Levinson-Durbin.  One block per (frame, channel): all threads window a chunk of samples
+ * and form the lag products into LDS, then lane `lag` adds its products in sample order -- one chain per lag, as in the
+ * reference.  Independent of the analysis, so it runs on a side stream concurrently with it. */
+#define STAT_THREADS 256
+#define STAT_CHUNK   512
+__global__ __launch_bounds__(STAT_THREADS) void k_stats(Plan p)
 {
-    __shared__ double sh_r[LNN_MAXCH][8];
-    const uint32_t f = blockIdx.x, tid = threadIdx.x;
+    __shared__ double sv[STAT_CHUNK + 8];
+    __shared__ double sprod[5][STAT_CHUNK];
+    __shared__ double sh_r[8];
+    const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
-    const int32_t *in = p.pcm + (size_t)f * C * S;
-    const uint32_t P0 = p.P[0];
+    const int32_t *x = p.pcm + ((size_t)f * C + ch) * S;
+    const uint32_t P0 = p.P[0];                              /* 2 or 4 */
     const double *sinw = p.sintab + c.sin_off;
-    if (tid < C * (P0 + 1)) {
-        const uint32_t ch = tid / (P0 + 1), lag = tid % (P0 + 1);
-        const int32_t *x = in + (size_t)ch * S;
-        double r = 0.0;
-        if (lag < n) {
-            const uint32_t cnt = n - lag;
-            uint32_t i = 0;
-            for (; i + 8 <= cnt; i += 8) {              /* loads and products of 8 steps are independent; the adds stay in order */
-                double pr[8];
-#pragma unroll
-                for (int k = 0; k < 8; k++) {
-                    const double a = ((double)x[i + k] * p.scale) * sinw[i + k];
-                    const double b = ((double)x[i + k + lag] * p.scale) * sinw[i + k + lag];
-                    pr[k] = a * b;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; k++) r += pr[k];
-            }
-            for (; i < cnt; i++) {
-                const double a = ((double)x[i] * p.scale) * sinw[i];
-                const double b = ((double)x[i + lag] * p.scale) * sinw[i + lag];
-                r += a * b;
-            }
+    double r = 0.0;
+    for (uint32_t base = 0; base < n; base += STAT_CHUNK) {
+        __syncthreads();
+        for (uint32_t i = tid; i < STAT_CHUNK + P0; i += STAT_THREADS) {
+            const uint32_t g = base + i;
+            sv[i] = (g < n) ? ((double)x[g] * p.scale) * sinw[g] : 0.0;
         }
-        sh_r[ch][lag] = r;
+        __syncthreads();
+        for (uint32_t idx = tid; idx < (P0 + 1) * STAT_CHUNK; idx += STAT_THREADS) {
+            const uint32_t lag = idx / STAT_CHUNK, i = idx % STAT_CHUNK;
+            sprod[lag][i] = sv[i] * sv[i + lag];
+        }
+        __syncthreads();
+        if (tid <= P0 && tid < n) {                          /* lag = tid: terms i < n - lag */
+            const uint32_t lag = tid, total = n - lag;
+            const uint32_t cnt = (total > base) ? ((total - base < STAT_CHUNK) ? (total - base) : STAT_CHUNK) : 0u;
+            const double *q = sprod[lag];
+            uint32_t i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                const double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3], q4 = q[i + 4], q5 = q[i + 5], q6 = q[i + 6], q7 = q[i + 7];
+                r += q0; r += q1; r += q2; r += q3; r += q4; r += q5; r += q6; r += q7;
+            }
+            for (; i < cnt; i++) r += q[i];
+        }
     }
     __syncthreads();
-    if (tid < C) {
+    if (tid <= P0) sh_r[tid] = r;
+    __syncthreads();
+    if (tid == 0) {
         double a[8], pc[8], rl[8];
-        double *st = p.stats + ((size_t)f * C + tid) * LINNE_AMD_STAT_WORDS;
-        for (uint32_t i = 0; i <= P0; i++) rl[i] = sh_r[tid][i];
+        double *st = p.stats + ((size_t)f * C + ch) * LINNE_AMD_STAT_WORDS;
+        for (uint32_t i = 0; i <= P0; i++) rl[i] = sh_r[i];
         const double r0 = rl[0] * (1.0 + 0.0);
         const int zero = (n < P0) || (fabs(r0) < (double)FLT_EPSILON);
         for (uint32_t i = 0; i < 8; i++) pc[i] = 0.0;
