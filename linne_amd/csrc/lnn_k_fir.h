@@ -68,6 +68,10 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
         }
     }
     const uint32_t s = s0 + FIR_SPL * tid;
+    /* unit index of sample s under the finest split (128 units), one division per tile: a trial with u units (a power of
+     * two) then finds its unit with a shift.  Only when the analysis length is a multiple of 128; else divide per trial. */
+    const bool fine_ok = (na % LNN_MAXU) == 0;
+    const uint32_t fine_unit = fine_ok ? s / (na / LNN_MAXU) : 0u;
     const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
     for (uint32_t t = 0; t < ntr; t++) {
         const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
@@ -79,7 +83,8 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
             /* all FIR_SPL samples in one unit, every tap present */
             const bool whole = ((n & (FIR_SPL - 1)) == 0) && (s >= np) && (s + FIR_SPL - 1 < na);
             if (whole && (np & 3u) == 0) {
-                const double *hb = hbuf + (size_t)(s / n) * np;
+                const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - (uint32_t)(__ffs((int)u) - 1))) : (s / n);
+                const double *hb = hbuf + (size_t)my_unit * np;
                 const double *xw = xc - np;                              /* -> x[s - np] */
                 /* Window x[s-np+k .. +11] in a register ring of 16 (element e lives in w[e % 16]): a step of 4 taps reads
                  * 11 of them, the LDS reads of the next step's 4 new samples and coefficients land in the free quarter
@@ -108,7 +113,8 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
                 }
 #undef FIR_STEP
             } else if (whole && np <= 2) {
-                const double *hb = hbuf + (size_t)(s / n) * np;
+                const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - (uint32_t)(__ffs((int)u) - 1))) : (s / n);
+                const double *hb = hbuf + (size_t)my_unit * np;
                 const double h0 = hb[0];
                 if (np == 1) {
 #pragma unroll
