@@ -308,3 +308,38 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
     for f in range(F):
         n = int(ns[f])
         assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f}"
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LINNE_FUZZ_SEEDS", "16"))))
+def test_random_configurations_match_the_oracle(product, oracle, seed):
+    """randomised sweep over what the API accepts: channels, bit depth, preset, (even) block size, MS on/off, stream length
+    with a ragged tail, and material that mixes music, silence, noise and a constant; the .lnn must equal the oracle's
+    byte for byte and decode back to the input"""
+    rng = np.random.default_rng(1000 + seed)
+    nch = int(rng.integers(1, 9))
+    bits = int(rng.choice([8, 16, 24]))
+    preset = int(rng.integers(0, 8))
+    maxp = 32 if preset < 2 else (64 if preset < 5 else 128)
+    block = int(rng.choice([2 * int(rng.integers(max(maxp, 128) // 2 + 1, 1500)), 1024, 2048, 4096]))     # the handle is created for 128-tap layers
+    ms = bool(nch >= 2 and rng.integers(0, 2))
+    nblocks = int(rng.integers(2, 6))
+    total = nblocks * block + int(rng.integers(1, block))
+    parts, left = [], total
+    while left > 0:
+        n = int(min(left, rng.integers(block // 2, 2 * block)))
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            parts.append(np.zeros((nch, n), dtype=np.int32))
+        elif kind == 1:
+            parts.append(waveform("white_noise", nch, n, bits, seed=int(rng.integers(1 << 30))))
+        elif kind == 2:
+            parts.append(waveform("positive_const", nch, n, bits, seed=1))
+        else:
+            parts.append(music(nch, n, bits, seed=int(rng.integers(1 << 30))))
+        left -= n
+    x = np.concatenate(parts, axis=1)
+    mine = product.encode_whole(x, bits, 44100, block, preset, ms)
+    want = oracle.encode_whole(x, bits, 44100, block, preset, ms)
+    assert mine == want, f"nch={nch} bits={bits} preset={preset} block={block} ms={ms} total={total}"
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
