@@ -343,3 +343,22 @@ def test_random_configurations_match_the_oracle(product, oracle, seed):
     assert mine == want, f"nch={nch} bits={bits} preset={preset} block={block} ms={ms} total={total}"
     ret, dec = product.decode_whole(mine)
     assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("kernel", ["wave", "lanes"])
+def test_corrupt_streams_do_not_hang_or_fault(product, oracle, monkeypatch, kernel):
+    """with the CRC check off a damaged payload reaches the parser and the GPU with arbitrary parameters (unit counts,
+    shifts, coefficients, residuals): decoding must come back with a result code (and the device must stay usable)"""
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", kernel)
+    rng = np.random.default_rng(4242)
+    x = music(2, 6 * 2048 + 100, 16, seed=8)
+    good = oracle.encode_whole(x, 16, 44100, 2048, 7, True)
+    for trial in range(60):
+        bad = bytearray(good)
+        for _ in range(int(rng.integers(1, 6))):
+            pos = int(rng.integers(41, len(bad)))                 # past the stream header and the first block header
+            bad[pos] = int(rng.integers(0, 256))
+        ret, dec = product.decode_whole(bytes(bad), check_crc=0)
+        assert ret in range(8)
+    ret, dec = product.decode_whole(good)                          # the device still works
+    assert ret == 0 and np.array_equal(dec, x)
