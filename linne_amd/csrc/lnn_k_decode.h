@@ -153,6 +153,45 @@ __global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
         __syncthreads();
 #pragma unroll 1
         for (uint32_t s0 = 0; s0 < SYN_T; s0 += PL) {
+            /* One turn of the history ring = PL steps.  If no lane of the wave meets a unit boundary inside the turn (the
+             * common case: boundaries are hundreds of samples apart), the turn runs as straight-line code, so the FMAs on
+             * older outputs of step k+1 overlap the tail of step k; otherwise the turn takes the careful path. */
+            const bool calm = !__any((!skip && unit < units) && (fresh || tl + PL > ns));
+            if (calm) {
+                int32_t rin[PL];                                 /* the turn's residuals, read before any output is stored */
+#pragma unroll
+                for (int tt = 0; tt < PL; tt++) rin[tt] = tile[s0 + tt][lane];
+#pragma unroll
+                for (int tt = 0; tt < PL; tt++) {
+                    const uint32_t sidx = t * SYN_T + s0 + tt;
+                    const int32_t res = rin[tt];
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < PL; k++) {
+                        const double prod_h = h[(tt + k) % PL];
+                        if ((k & 3) == 0) a0 = __builtin_fma(c[k], prod_h, a0);
+                        else if ((k & 3) == 1) a1 = __builtin_fma(c[k], prod_h, a1);
+                        else if ((k & 3) == 2) a2 = __builtin_fma(c[k], prod_h, a2);
+                        else a3 = __builtin_fma(c[k], prod_h, a3);
+                    }
+                    const double acc = (a0 + a1) + (a2 + a3);
+                    const uint32_t pred = half + (uint32_t)__double2loint(acc + 6755399441055744.0);
+                    const bool predict = !skip && (tl + (uint32_t)tt >= np) && unit < units;
+                    int32_t y = predict ? (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u))) : res;
+                    h[tt] = (double)y;
+                    if (DEEMPH) {
+                        const int32_t z = (int32_t)((uint32_t)y + (uint32_t)mulshr5(zp, c1e));
+                        const int32_t yy = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                        const bool live = sidx < n;
+                        zp = live ? z : zp; yp = live ? yy : yp;
+                        y = yy;
+                    }
+                    tile[s0 + tt][lane] = y;
+                }
+                tl += PL;                                        /* tl + PL <= ns for predicting lanes; == ns closes the unit */
+                if (!skip && unit < units && tl == ns) { tl = 0; unit++; fresh = true; }
+                continue;
+            }
 #pragma unroll
             for (int tt = 0; tt < PL; tt++) {                    /* sample index = tt (mod PL): ring slot tt is the oldest */
                 const uint32_t sidx = t * SYN_T + s0 + tt;
