@@ -61,6 +61,7 @@ struct LINNEAmdContext {
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
     hipStream_t copy_in, copy_out; int has_copy;
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
+    int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -120,6 +121,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
         ctx->has_side = (ctx->nsub > 0) && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
     }
+    { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * (2 * LNN_MAXP + 3)));
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
@@ -398,6 +400,15 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     return b + 4096;
 }
 
+/* k_fir2 launcher: layer 0 reads the int32 channel (L0); `spec` = the search also writes the one-unit trial's forward output
+ * (MODE 2) / the forward pass skips the jobs that chose one unit (MODE 1) */
+template <int MODE> static void launch_fir(hipStream_t st, const Plan &p, uint32_t l, uint32_t cur, uint32_t J, uint32_t tiles, bool spec)
+{
+    const dim3 grid(J, tiles), blk(FIR_THREADS);
+    if (l == 0) { if (spec) hipLaunchKernelGGL((k_fir2<MODE, true, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<MODE, true, false>), grid, blk, 0, st, p, l, cur); }
+    else        { if (spec) hipLaunchKernelGGL((k_fir2<MODE, false, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<MODE, false, false>), grid, blk, 0, st, p, l, cur); }
+}
+
 extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         const int32_t *d_pcm, const uint32_t *h_num_samples, uint32_t num_frames,
         int32_t *d_residual, int32_t *d_params, double *d_stats)
@@ -481,6 +492,8 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         uint32_t cur = 0;
         for (uint32_t l = 0; l < hs.L; l++) {
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
+            /* the first two layers nearly always keep one unit: their search pass also writes that trial's forward output */
+            const uint32_t fir_spec = (ctx->fir_spec && l + 1 < hs.L) ? 1u : 0u;
             uint32_t nt = 0, nprob = 0, nchain = 0;
             for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
             {
@@ -495,12 +508,12 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
               }
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); if (l == 0) hipLaunchKernelGGL((k_fir2<2, true>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<2, false>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
-            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
+            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : 8, st); if (l == 0) hipLaunchKernelGGL((k_fir2<1, true>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<1, false>), dim3((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), dim3(FIR_THREADS), 0, st, p, l, cur); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : 8, st); launch_fir<1>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
         { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }

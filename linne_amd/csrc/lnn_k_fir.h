@@ -35,15 +35,19 @@ __device__ __forceinline__ double wave_sum_f64_lane63(double v)
 #define FIR_THREADS 256
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
-template <int MODE, bool L0>
-__global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
+template <int MODE, bool L0, bool SPEC>
+__global__ __launch_bounds__(FIR_THREADS, (SPEC && MODE == 2) ? 3 : 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
+    constexpr uint32_t spec = SPEC ? 1u : 0u;        /* MODE 2: also write the one-unit trial's forward output; MODE 1: skip the jobs it covered */
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
     __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
     __shared__ __attribute__((aligned(16))) double ob[(MODE == 2) ? 1 : FIR_THREADS / 64][(MODE == 2) ? 2 : 64 * FIR_SPL];   /* per-wave store transpose (MODE 0/1) */
     __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
     const uint32_t job = blockIdx.x, tid = threadIdx.x;          /* grid = (jobs, tiles): the job count is not bound by 65535 */
     if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
+    /* speculation (layers whose search usually picks one unit): the search pass already wrote the forward output of the
+     * one-unit trial -- same coefficients, same products, its own accumulation chain -- so such a job has nothing to do here */
+    if (MODE == 1 && spec && p.lunits[(size_t)job * LNN_MAXL + layer] == 1u) return;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
     const uint32_t P = p.P[layer];
@@ -73,12 +77,37 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
     const bool fine_ok = (na % LNN_MAXU) == 0;
     const uint32_t fine_unit = fine_ok ? s / (na / LNN_MAXU) : 0u;
     const double *xc = xs + LNN_MAXP + FIR_SPL * tid;                /* -> x[s], 16-byte aligned */
+    /* coalesced store of a tile of layer output: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive
+     * lanes write consecutive 16-byte pieces (a lane's own 8 results are 64 bytes apart from its neighbour's) */
+    auto store_rows = [&](const double *vals) {
+        const uint32_t wv = tid >> 6, ln = tid & 63u, wbase = s0 + wv * 64 * FIR_SPL;
+        double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
+        if (wbase < na) {
+            if (s < na) {
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j += 2) { lnn_d2 v; v.x = vals[j]; v.y = vals[j + 1]; *(lnn_d2 *)(&ob[wv][ln * FIR_SPL + j]) = v; }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0): the wave's own LDS writes have landed */
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < FIR_SPL / 2; i++) {
+                const uint32_t e = 2 * ln + 128 * i, g = wbase + e;
+                if (g + 1 < na) *(lnn_d2 *)(dst + g) = *(const lnn_d2 *)(&ob[wv][e]);
+                else if (g < na) dst[g] = ob[wv][e];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
     for (uint32_t t = 0; t < ntr; t++) {
         const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
         const uint32_t n = na / u, np = P / u;
         const double *hbuf = hs[t];
         if (t == 0) __syncthreads();                                 /* tile and coefficients are staged */
         double acc[FIR_SPL];
+        double acc2[FIR_SPL];                                        /* MODE 2, trial 0 with `spec`: predict-first sums of the forward pass */
+        const bool dual = (MODE == 2) && SPEC && (t == 0);
+#pragma unroll
+        for (int j = 0; j < FIR_SPL; j++) acc2[j] = 0.0;
         if (s < na) {
             /* all FIR_SPL samples in one unit, every tap present */
             const bool whole = ((n & (FIR_SPL - 1)) == 0) && (s >= np) && (s + FIR_SPL - 1 < na);
@@ -105,36 +134,61 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
                     _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
                         _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) acc[j] += hh_[kk] * w[(4 * G + kk + j) % 16]; } \
                     k += 4; }
-                for (;;) {
+#define FIR_STEP2(G, HC0, HC1, HN0, HN1) { \
+                    const lnn_d2 na_ = *(const lnn_d2 *)(xw + k + 12), nb_ = *(const lnn_d2 *)(xw + k + 14); \
+                    HN0 = *(const lnn_d2 *)(hb + k + 4); HN1 = *(const lnn_d2 *)(hb + k + 6); \
+                    w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y; \
+                    const double hh_[4] = { HC0.x, HC0.y, HC1.x, HC1.y }; \
+                    _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
+                        _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) { const double pr_ = hh_[kk] * w[(4 * G + kk + j) % 16]; acc[j] += pr_; acc2[j] += pr_; } } \
+                    k += 4; }
+                if (dual) for (;;) {                                 /* one product, two chains: residual (starts at x) and prediction (starts at 0) */
+                    FIR_STEP2(0, ha0, ha1, hb0, hb1); if (k >= np) break;
+                    FIR_STEP2(1, hb0, hb1, ha0, ha1); if (k >= np) break;
+                    FIR_STEP2(2, ha0, ha1, hb0, hb1); if (k >= np) break;
+                    FIR_STEP2(3, hb0, hb1, ha0, ha1); if (k >= np) break;
+                } else for (;;) {
                     FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
                     FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
                     FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
                     FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
                 }
 #undef FIR_STEP
+#undef FIR_STEP2
             } else if (whole && np <= 2) {
                 const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - (uint32_t)(__ffs((int)u) - 1))) : (s / n);
                 const double *hb = hbuf + (size_t)my_unit * np;
                 const double h0 = hb[0];
                 if (np == 1) {
 #pragma unroll
-                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 1]; }
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; const double p0_ = h0 * xc[j - 1]; acc[j] += p0_; acc2[j] += p0_; }
                 } else {
                     const double h1 = hb[1];
 #pragma unroll
-                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; acc[j] += h0 * xc[j - 2]; acc[j] += h1 * xc[j - 1]; }
+                    for (int j = 0; j < FIR_SPL; j++) { acc[j] = (MODE != 1) ? xc[j] : 0.0; const double p0_ = h0 * xc[j - 2], p1_ = h1 * xc[j - 1]; acc[j] += p0_; acc[j] += p1_; acc2[j] += p0_; acc2[j] += p1_; }
                 }
             } else {
 #pragma unroll 1
                 for (int j = 0; j < FIR_SPL; j++) {
                     const uint32_t sj = s + j;
-                    double v = (MODE != 1) ? xc[j] : 0.0;
+                    double v = (MODE != 1) ? xc[j] : 0.0, v2 = 0.0;
                     if (sj < na && sj != 0) {
                         const double *hb = hbuf + (size_t)(sj / n) * np;
                         const uint32_t kstart = (sj < np) ? (np - sj) : 0;  /* taps before sample 0 are skipped */
-                        for (uint32_t k = kstart; k < np; k++) v += hb[k] * xc[(int)j - (int)np + (int)k];
+                        for (uint32_t k = kstart; k < np; k++) { const double pr_ = hb[k] * xc[(int)j - (int)np + (int)k]; v += pr_; v2 += pr_; }
                     }
-                    acc[j] = v;
+                    acc[j] = v; acc2[j] = v2;
+                }
+            }
+            if (dual) {                                              /* the forward output of the one-unit trial (linne_network.c:165-210): straight from
+                                                                      * the registers -- a lane's 8 results are 64 contiguous bytes; routing them through
+                                                                      * an LDS transpose like MODE 1 costs this kernel more in occupancy than it saves */
+                double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j += 2) {
+                    const double o0 = (s + j == 0) ? xc[j] : (xc[j] + acc2[j]), o1 = xc[j + 1] + acc2[j + 1];
+                    if (s + j + 1 < na) { lnn_d2 v; v.x = o0; v.y = o1; *(lnn_d2 *)(dst + j) = v; }
+                    else if (s + j < na) dst[j] = o0;
                 }
             }
             /* results: |residual| (MODE 0) or x + predict (MODE 1) */
@@ -169,25 +223,8 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir2(Plan p, uint32_t layer,
                 chain[t] = v;
             }
             __syncthreads();
-        } else {   /* coalesced store: the wave's 64*FIR_SPL consecutive results go through LDS so that consecutive lanes write
-             * consecutive 16-byte pieces (a lane's own 8 results are 64 bytes apart from its neighbour's) */
-            const uint32_t wv = tid >> 6, ln = tid & 63u, wbase = s0 + wv * 64 * FIR_SPL;
-            double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
-            if (wbase < na) {
-                if (s < na) {
-#pragma unroll
-                    for (int j = 0; j < FIR_SPL; j += 2) { lnn_d2 v; v.x = acc[j]; v.y = acc[j + 1]; *(lnn_d2 *)(&ob[wv][ln * FIR_SPL + j]) = v; }
-                }
-                __builtin_amdgcn_s_waitcnt(0xC07F);       /* lgkmcnt(0): the wave's own LDS writes have landed */
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int i = 0; i < FIR_SPL / 2; i++) {
-                    const uint32_t e = 2 * ln + 128 * i, g = wbase + e;
-                    if (g + 1 < na) *(lnn_d2 *)(dst + g) = *(const lnn_d2 *)(&ob[wv][e]);
-                    else if (g < na) dst[g] = ob[wv][e];
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+        } else {
+            store_rows(acc);
         }
     }
     }

@@ -362,3 +362,23 @@ def test_corrupt_streams_do_not_hang_or_fault(product, oracle, monkeypatch, kern
         assert ret in range(8)
     ret, dec = product.decode_whole(good)                          # the device still works
     assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("speculate", ["0", "1"])
+def test_search_with_and_without_the_fused_forward(product, oracle, monkeypatch, speculate):
+    """by default the unit-count search of the first layers also writes the forward output of the one-unit trial, and the
+    forward pass skips the jobs that chose one unit (LINNE_AMD_SPECULATE); both schedules must give the oracle's bytes --
+    on music (mostly one unit) and on a signal whose statistics change inside the frame (several units)"""
+    monkeypatch.setenv("LINNE_AMD_SPECULATE", speculate)
+    block = 4096
+    seg = [music(2, 3 * block, 16, seed=51)]
+    rng = np.random.default_rng(7)
+    t = np.arange(2 * block)
+    burst = (8000 * np.sin(2 * np.pi * t * (0.01 + 0.2 * (t // 512 % 2))) * (t // 256 % 2) + rng.integers(-30, 30, size=2 * block)).astype(np.int32)
+    seg.append(np.stack([burst, -burst // 2]))
+    x = np.concatenate(seg, axis=1)
+    mine = product.encode_whole(x, 16, 44100, block, 7, True)
+    assert mine == oracle.encode_whole(x, 16, 44100, block, 7, True)
+    # some channel-frame of the second part must have chosen more than one unit in layer 0 or 1 (else the test shows nothing)
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
