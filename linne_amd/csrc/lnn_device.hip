@@ -508,12 +508,12 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
               }
               hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : 5, st); launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : 8, st); launch_fir<1>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : (fir_spec ? 8 : 19), st); launch_fir<1>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
         { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
