@@ -494,20 +494,16 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
             /* the first two layers nearly always keep one unit: their search pass also writes that trial's forward output */
             const uint32_t fir_spec = (ctx->fir_spec && l + 1 < hs.L) ? 1u : 0u;
-            uint32_t nt = 0, nprob = 0, nchain = 0;
-            for (uint32_t u = 1; u <= maxu; u <<= 1) { nt++; nprob += u; nchain += hs.P[l] + u; }
             {
                 const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max); span_end(ctx, sp_, st);
             }
             { const int sp_ = span_begin(ctx, 4, st);
-              uint32_t nbig = 0; for (uint32_t u = 1; u <= maxu && hs.P[l] / u >= 16u; u <<= 1) nbig += u;
-              (void)nbig;
-              for (uint32_t t = 0, u = 1; u <= maxu && hs.P[l] / u >= LEV_WAVE_MIN_ORDER; u <<= 1, t++) {
+              for (uint32_t t = 0, u = 1; u <= maxu; u <<= 1, t++) {             /* one launch per trial: every order on LDS columns */
                   const uint32_t np = hs.P[l] / u;
                   const size_t lds = sizeof(double) * 64 * (size_t)(2 * np + 3);
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
               }
-              hipLaunchKernelGGL(k_levinson, dim3(((uint32_t)J + 63) / 64, nprob), dim3(64), 0, st, p, l); span_end(ctx, sp_, st); }
+              span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */

@@ -484,7 +484,7 @@ template <> struct AcsWaves<4>  { static constexpr int NW = 3; };
 template <> struct AcsWaves<2>  { static constexpr int NW = 2; };
 
 template <int P, bool L0>
-__global__ __launch_bounds__(64 * AcsWaves<P>::NW, 4) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+__global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 2) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     using Cfg = AcCfg<P>;
     constexpr int NT = Cfg::NT, NW = AcsWaves<P>::NW;

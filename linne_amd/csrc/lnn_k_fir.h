@@ -36,7 +36,7 @@ __device__ __forceinline__ double wave_sum_f64_lane63(double v)
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
 template <int MODE, bool L0, bool SPEC>
-__global__ __launch_bounds__(FIR_THREADS, (SPEC && MODE == 2) ? 3 : 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
+__global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3 : 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     constexpr uint32_t spec = SPEC ? 1u : 0u;        /* MODE 2: also write the one-unit trial's forward output; MODE 1: skip the jobs it covered */
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];

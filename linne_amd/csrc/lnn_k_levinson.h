@@ -1,56 +1,9 @@
-/* lnn_k_levinson.h -- ridge + Levinson-Durbin kernels (k_levinson, k_levinson_lds).
+/* lnn_k_levinson.h -- ridge + Levinson-Durbin kernel (k_levinson_lds).
  * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
 #ifndef LNN_K_LEVINSON_H_INCLUDED
 #define LNN_K_LEVINSON_H_INCLUDED
 
-/* ridge + Levinson-Durbin per (trial, unit) (lpc.c:327-366, 578-633 with zero AF iterations), lanes = jobs.
- * Writes the coefficients in filter order (reversed, linne_network.c:310-316). */
-__global__ void k_levinson(Plan p, uint32_t layer)
-{
-    const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
-    if (job >= p.J) return;
-    const DevClass &c = job_class(p, job);
-    uint32_t pr = blockIdx.y, t = 0;
-    for (; t < c.ntrials[layer]; t++) {
-        if (pr < c.trial_u[layer][t]) break;
-        pr -= c.trial_u[layer][t];
-    }
-    if (t >= c.ntrials[layer]) return;
-    const uint32_t P = p.P[layer], u = c.trial_u[layer][t], n = c.na / u, np = P / u, unit = pr;
-    if (np >= 16u) return;                                  /* orders >= 16 are solved by k_levinson_lds */
-    const uint32_t P0 = p.P[0];
-    const double reg = p.regs[job % p.R];
-    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
-    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
-    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
-    double a[LNN_MAXP + 2];
-    double tail = 0.0; int tail_set = 0;
-    int zero = 0;
-    if (n < np) {                                           /* lpc.c:349-355 */
-        zero = 1;
-    } else {
-        const double r0 = r[0] * (1.0 + reg);               /* lpc.c:358 */
-        if (fabs(r0) < (double)FLT_EPSILON) zero = 1;       /* lpc.c:271-276, 597-602 */
-        else {
-            double pc[LNN_MAXP + 1];
-            levinson(r, r0, np, a, (layer + 1 == p.L) ? pc : nullptr);
-            if (layer + 1 == p.L && np > P0) { tail = pc[P0]; tail_set = 1; }
-        }
-    }
-    if (zero) {
-        for (uint32_t k = 0; k < np; k++) h[k] = 0.0;
-        if (np >= P0) { tail = 0.0; tail_set = 1; }         /* zero branches write parcor[0..order] */
-    } else {
-        for (uint32_t k = 0; k < np; k++) h[k] = a[np - k];
-    }
-    if (layer + 1 == p.L) {
-        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
-        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
-    }
-}
-
-#define LEV_WAVE_MIN_ORDER 16u      /* orders from here on are solved by k_levinson_lds, smaller ones by k_levinson */
-/* Levinson-Durbin for the large problems (order >= 16), lanes = jobs: a wavefront solves the SAME (trial, unit) problem of 64
+/* ridge + Levinson-Durbin of every (trial, unit) problem (lpc.c:327-366, 578-633 with zero AF iterations), lanes = jobs: a wavefront solves the SAME (trial, unit) problem of 64
  * consecutive jobs, each lane running the scalar recursion of `levinson` above on its own column of two LDS arrays
  * (a[i][lane], r[i][lane]: conflict-free 8-byte accesses).  Every wave instruction therefore advances 64 problems; the
  * ordered sum a[0]r[k+1] + ... + a[k]r[1] (lpc.c:295-297) is one chain per lane.  grid = (job groups, units of the trial). */
