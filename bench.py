@@ -193,7 +193,7 @@ def main():
     ap.add_argument("--preset", type=int, default=7)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames-per-thread", type=int, default=128)
-    ap.add_argument("--scratch-gib", type=float, default=24.0)
+    ap.add_argument("--scratch-gib", type=float, default=30.0)
     ap.add_argument("--channels", type=int, default=2, help="other BASELINE configs, e.g. configs[4]: --channels 8 --bits 24 --rate 96000")
     ap.add_argument("--bits", type=int, default=16)
     ap.add_argument("--rate", type=int, default=44100)

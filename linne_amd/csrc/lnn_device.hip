@@ -442,6 +442,11 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         if (chunk > even) chunk = even;
         const uint64_t lim = 4194304u / ((uint64_t)C * hs.R);
         if (chunk > lim) chunk = lim;
+        /* chunks of equal size (a multiple of the stream count): a small last chunk would run the latency-bound kernels
+         * nearly empty */
+        uint64_t nchunks = (num_frames + chunk - 1) / chunk;
+        nchunks = ((nchunks + nsub - 1) / nsub) * nsub;
+        chunk = (num_frames + nchunks - 1) / nchunks;
     }
     ctx->nspans = 0;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount, 0, sizeof(uint32_t), ctx->stream));
