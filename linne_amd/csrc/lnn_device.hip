@@ -61,6 +61,7 @@ struct LINNEAmdContext {
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
     hipStream_t copy_in, copy_out; int has_copy;
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
+    int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
 };
 
@@ -122,6 +123,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
                 && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
     }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
+    { const char *sp = getenv("LINNE_AMD_FIR_SMALL"); ctx->fir_small = sp ? atoi(sp) : 1; }
     (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * (2 * LNN_MAXP + 3)));
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
@@ -409,6 +411,17 @@ template <int MODE> static void launch_fir(hipStream_t st, const Plan &p, uint32
     else        { if (spec) hipLaunchKernelGGL((k_fir2<MODE, false, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<MODE, false, false>), grid, blk, 0, st, p, l, cur); }
 }
 
+/* search of a short layer (P <= 16): register-window kernel */
+static void launch_fir_small_search(hipStream_t st, const Plan &p, uint32_t l, uint32_t cur, uint32_t J, uint32_t tiles, bool spec, uint32_t P)
+{
+    const dim3 grid(J, tiles), blk(FIR_THREADS);
+#define LNN_FS(PP) do { \
+        if (l == 0) { if (spec) hipLaunchKernelGGL((k_fir_small<PP, true, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir_small<PP, true, false>), grid, blk, 0, st, p, l, cur); } \
+        else        { if (spec) hipLaunchKernelGGL((k_fir_small<PP, false, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir_small<PP, false, false>), grid, blk, 0, st, p, l, cur); } } while (0)
+    switch (P) { case 2: LNN_FS(2); break; case 4: LNN_FS(4); break; case 8: LNN_FS(8); break; default: LNN_FS(16); break; }
+#undef LNN_FS
+}
+
 extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         const int32_t *d_pcm, const uint32_t *h_num_samples, uint32_t num_frames,
         int32_t *d_residual, int32_t *d_params, double *d_stats)
@@ -509,7 +522,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
               }
               span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]); else launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);

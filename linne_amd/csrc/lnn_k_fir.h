@@ -234,6 +234,95 @@ __global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3
     }
 }
 
+/* Unit-count search of a SHORT layer (P <= 16 taps in all): like k_fir2<2>, but a lane keeps its 8 samples and the P
+ * before them in registers and evaluates every trial from there -- one window load per tile instead of one per trial, the
+ * tap loops fully unrolled.  A tile whose lanes all see whole units and full history (every tile of a 10240-sample frame
+ * but the first lanes of the first) takes this path; other lanes fall back to the sample-at-a-time form.  SPEC: also writes
+ * the one-unit trial's forward output (see k_fir2). */
+template <int P, bool L0, bool SPEC>
+__global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t layer, uint32_t cur)
+{
+    constexpr int NT = (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2;
+    constexpr int HP = (P < 2) ? 2 : P;                           /* history kept in front of the tile (even, >= P) */
+    __shared__ __attribute__((aligned(16))) double xs[HP + FIR_TILE];
+    __shared__ __attribute__((aligned(16))) double hs[NT][HP];
+    const uint32_t job = blockIdx.x, tid = threadIdx.x, s0 = blockIdx.y * FIR_TILE;
+    const DevClass &c = job_class(p, job);
+    const uint32_t na = c.na;
+    if (s0 >= na) return;
+    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
+    const uint32_t ntr = c.ntrials[layer];
+    for (uint32_t i = tid; i < NT * P; i += FIR_THREADS) hs[i / P][i % P] = p.tcoef[((size_t)job * LNN_MAXT + i / P) * LNN_MAXP + i % P];
+    for (uint32_t i = tid; i < HP + FIR_TILE; i += FIR_THREADS) {
+        const int64_t g = (int64_t)s0 - HP + i;
+        xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
+    }
+    __syncthreads();
+    const uint32_t s = s0 + FIR_SPL * tid;
+    const double *xc = xs + HP + FIR_SPL * tid;                     /* -> x[s] */
+    double wv[HP + FIR_SPL];                                        /* x[s - HP .. s + 7] */
+#pragma unroll
+    for (int i = 0; i < HP + FIR_SPL; i += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc - HP + i); wv[i] = v.x; wv[i + 1] = v.y; }
+    const bool live = s < na;
+    const bool fast = live && (s >= (uint32_t)P) && (s + FIR_SPL - 1 < na) && ((na % (uint32_t)(FIR_SPL * P)) == 0);
+    double ps[NT], fwd[FIR_SPL];
+#pragma unroll
+    for (int j = 0; j < FIR_SPL; j++) fwd[j] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int np = P >> t;                                     /* a constant once the loop is unrolled */
+        const uint32_t u = 1u << t, n = na / u;
+        double sum = 0.0;
+        if ((uint32_t)t < ntr && live) {
+            if (fast) {
+                const double *hb = hs[t] + (size_t)(s / n) * np;
+                double h[(P >> 0)];
+#pragma unroll
+                for (int k = 0; k < np; k++) h[k] = hb[k];
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j++) {
+                    double acc = wv[HP + j], acc2 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < np; k++) { const double pr = h[k] * wv[HP - np + k + j]; acc += pr; if (SPEC && t == 0) acc2 += pr; }
+                    if (SPEC && t == 0) fwd[j] = wv[HP + j] + acc2;
+                    sum += (acc > 0) ? acc : -acc;
+                }
+            } else {
+#pragma unroll 1
+                for (int j = 0; j < FIR_SPL; j++) {
+                    const uint32_t sj = s + j;
+                    double v = xc[j], v2 = 0.0;
+                    if (sj < na && sj != 0) {
+                        const double *hb = hs[t] + (size_t)(sj / n) * np;
+                        const uint32_t kstart = (sj < (uint32_t)np) ? ((uint32_t)np - sj) : 0;   /* taps before sample 0 are skipped */
+                        for (uint32_t k = kstart; k < (uint32_t)np; k++) { const double pr = hb[k] * xc[(int)j - np + (int)k]; v += pr; v2 += pr; }
+                    }
+                    double av = (v > 0) ? v : -v;
+                    if (sj == 0) av = 0.0;
+                    if (sj < na) sum += av;
+                    if (SPEC && t == 0) fwd[j] = (sj == 0) ? xc[j] : (xc[j] + v2);
+                }
+            }
+        }
+        ps[t] = sum;
+    }
+    if (SPEC && live) {                                             /* forward output of the one-unit trial, straight from the registers */
+        double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+#pragma unroll
+        for (int j = 0; j < FIR_SPL; j += 2) {
+            if (s + j + 1 < na) { lnn_d2 v; v.x = fwd[j]; v.y = fwd[j + 1]; *(lnn_d2 *)(dst + j) = v; }
+            else if (s + j < na) dst[j] = fwd[j];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const double tot = wave_sum_f64_lane63(ps[t]);
+        if ((uint32_t)t < ntr && (tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = tot;
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------
  * ordered sums (v2): 64 chains per wavefront.  Rows are staged through LDS with coalesced loads and each lane then
  * adds its own row strictly in sample order, so every sum is the same single chain the reference evaluates.
