@@ -71,23 +71,49 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
                 xt[i] = (g >= 0 && g < (int64_t)n) ? src[g] : 0;
             }
             __syncthreads();
-#pragma unroll
-            for (uint32_t j = 0; j < 4; j++) {
-                const uint32_t e = tid + j * FIN_THREADS, s = s0 + e;
-                if (s >= n) continue;
-                int32_t v = xt[LNN_MAXP + e];
-                const uint32_t unit = s / (ns ? ns : 1u);
-                if (ns >= np && unit < units) {
-                    const uint32_t loc = s - unit * ns;
-                    if (loc >= np) {
-                        uint32_t pred = half;
-                        const int32_t *cc = s_coef[l] + unit * np;
-                        const int32_t *xx = xt + LNN_MAXP + e - np;
-                        for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
-                        v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
+            {   /* a lane owns 4 consecutive samples: when they sit in one unit past its first np samples (the usual case) the
+                 * taps slide a 4-wide register window over the tile, one coefficient and one new sample per tap for four
+                 * multiply-adds (int32 wrap-around: any order); otherwise sample by sample */
+                const uint32_t e0 = 4 * tid, sb = s0 + e0;
+                const uint32_t nsd = ns ? ns : 1u;
+                const uint32_t unit0 = sb / nsd, loc0 = sb - unit0 * nsd;
+                const bool quad = (sb + 3 < n) && (ns >= np) && (unit0 < units) && (loc0 >= np) && (loc0 + 3 < ns);
+                if (quad) {
+                    const int32_t *cc = s_coef[l] + unit0 * np;
+                    const int32_t *xx = xt + LNN_MAXP + e0 - np;      /* -> x[sb - np] */
+                    uint32_t p0 = half, p1 = half, p2 = half, p3 = half;
+                    uint32_t w0 = (uint32_t)xx[0], w1 = (uint32_t)xx[1], w2 = (uint32_t)xx[2];
+                    for (uint32_t k = 0; k < np; k++) {
+                        const uint32_t ck = (uint32_t)cc[k], w3 = (uint32_t)xx[k + 3];
+                        p0 += ck * w0; p1 += ck * w1; p2 += ck * w2; p3 += ck * w3;
+                        w0 = w1; w1 = w2; w2 = w3;
+                    }
+                    const int32_t *xv = xt + LNN_MAXP + e0;
+                    int4 o;
+                    o.x = (int32_t)((uint32_t)xv[0] + (uint32_t)((int32_t)p0 >> (rs & 31u)));
+                    o.y = (int32_t)((uint32_t)xv[1] + (uint32_t)((int32_t)p1 >> (rs & 31u)));
+                    o.z = (int32_t)((uint32_t)xv[2] + (uint32_t)((int32_t)p2 >> (rs & 31u)));
+                    o.w = (int32_t)((uint32_t)xv[3] + (uint32_t)((int32_t)p3 >> (rs & 31u)));
+                    *(int4 *)(out + sb) = o;                          /* sb is a multiple of 4, rows are 16-byte aligned */
+                } else {
+                    for (uint32_t j = 0; j < 4; j++) {
+                        const uint32_t e = e0 + j, s = s0 + e;
+                        if (s >= n) continue;
+                        int32_t v = xt[LNN_MAXP + e];
+                        const uint32_t unit = s / nsd;
+                        if (ns >= np && unit < units) {
+                            const uint32_t loc = s - unit * ns;
+                            if (loc >= np) {
+                                uint32_t pred = half;
+                                const int32_t *cc = s_coef[l] + unit * np;
+                                const int32_t *xx = xt + LNN_MAXP + e - np;
+                                for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
+                                v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
+                            }
+                        }
+                        out[s] = v;
                     }
                 }
-                out[s] = v;
             }
         }
         if (l + 1 == p.L) for (uint32_t s = n + tid; s < S; s += FIN_THREADS) out[s] = 0;
