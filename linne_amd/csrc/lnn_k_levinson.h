@@ -40,7 +40,14 @@ __global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uin
             {
                 const double *pa = sa, *pr = sr + (size_t)(k + 1) * 64;
                 uint32_t i = 0;
-                for (; i + 4 <= k + 1; i += 4) {                /* four terms per trip, reads ahead of the adds */
+                for (; i + 8 <= k + 1; i += 8) {                /* eight terms per trip: sixteen reads in flight, the adds stay in order */
+                    const double a0 = pa[0], a1_ = pa[64], a2 = pa[128], a3 = pa[192], a4 = pa[256], a5 = pa[320], a6 = pa[384], a7 = pa[448];
+                    const double q0 = pr[0], q1 = *(pr - 64), q2 = *(pr - 128), q3 = *(pr - 192), q4 = *(pr - 256), q5 = *(pr - 320), q6 = *(pr - 384), q7 = *(pr - 448);
+                    const double m0 = a0 * q0, m1 = a1_ * q1, m2 = a2 * q2, m3 = a3 * q3, m4 = a4 * q4, m5 = a5 * q5, m6 = a6 * q6, m7 = a7 * q7;
+                    gamma += m0; gamma += m1; gamma += m2; gamma += m3; gamma += m4; gamma += m5; gamma += m6; gamma += m7;
+                    pa += 512; pr -= 512;
+                }
+                for (; i + 4 <= k + 1; i += 4) {
                     const double a0 = pa[0], a1_ = pa[64], a2 = pa[128], a3 = pa[192];
                     const double q0 = pr[0], q1 = *(pr - 64), q2 = *(pr - 128), q3 = *(pr - 192);
                     gamma += a0 * q0; gamma += a1_ * q1; gamma += a2 * q2; gamma += a3 * q3;
@@ -53,6 +60,16 @@ __global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uin
             const double a0n = 1.0 + gamma * 0.0;              /* u[0]   + gamma*v[0]   */
             const double ak1 = 0.0 + gamma * 1.0;              /* u[k+1] + gamma*v[k+1] */
             uint32_t i = 1, j = k;
+            while (i + 6 < j) {                              /* four pairs per trip (i+3 < j-3, written without unsigned underflow): eight loads in flight, then the updates */
+                double *pi = sa + (size_t)i * 64, *pj = sa + (size_t)j * 64;
+                const double ai0 = pi[0], ai1 = pi[64], ai2 = pi[128], ai3 = pi[192];
+                const double aj0 = pj[0], aj1 = *(pj - 64), aj2 = *(pj - 128), aj3 = *(pj - 192);
+                pi[0] = ai0 + gamma * aj0;   pj[0] = aj0 + gamma * ai0;
+                pi[64] = ai1 + gamma * aj1;  *(pj - 64) = aj1 + gamma * ai1;
+                pi[128] = ai2 + gamma * aj2; *(pj - 128) = aj2 + gamma * ai2;
+                pi[192] = ai3 + gamma * aj3; *(pj - 192) = aj3 + gamma * ai3;
+                i += 4; j -= 4;
+            }
             while (i < j) {
                 const double ai = sa[(size_t)i * 64], aj = sa[(size_t)j * 64];
                 sa[(size_t)i * 64] = ai + gamma * aj;
