@@ -618,6 +618,32 @@ static void copy_range(void *arg, uint32_t first, uint32_t count)
     }
 }
 
+/* The serialisation pool of a batch (worst-case bytes per frame x frames: hundreds of MB of address space, a few tens of MB
+ * touched) is kept between calls: a fresh mapping per call costs thousands of page faults on 16 threads at once.  One pool per
+ * process; a second concurrent caller simply gets its own temporary one. */
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static uint8_t *g_pool = NULL; static uint64_t g_pool_size = 0; static int g_pool_busy = 0;
+static uint8_t *pool_take(uint64_t bytes, int *cached)
+{
+    uint8_t *p = NULL;
+    *cached = 0;
+    pthread_mutex_lock(&g_pool_lock);
+    if (!g_pool_busy) {
+        if (g_pool_size < bytes) { free(g_pool); g_pool = malloc(bytes); g_pool_size = g_pool ? bytes : 0; }
+        if (g_pool) { p = g_pool; g_pool_busy = 1; *cached = 1; }
+    }
+    pthread_mutex_unlock(&g_pool_lock);
+    return p ? p : malloc(bytes);
+}
+static void pool_give(uint8_t *p, int cached)
+{
+    if (!p) return;
+    if (!cached) { free(p); return; }
+    pthread_mutex_lock(&g_pool_lock);
+    g_pool_busy = 0;
+    pthread_mutex_unlock(&g_pool_lock);
+}
+
 int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
         uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats,
         uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
@@ -635,6 +661,7 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
     struct lnn_layers ly;
     uint8_t *types = NULL, *pool = NULL;
     uint64_t CS, per_slot;
+    int pool_cached = 0;
     int *rets = NULL, ret = LNN_OK;
     double state = parcor_state ? *parcor_state : 0.0;
     uint32_t f, t, C;
@@ -657,7 +684,7 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
     if (parcor_state) *parcor_state = state;
     /* parallel pass: serialise into per-worker regions, then copy the regions into place */
     per_slot = 64 + CS * 8;
-    pool = malloc(per_slot * (uint64_t)num_frames);
+    pool = pool_take(per_slot * (uint64_t)num_frames, &pool_cached);
     if (!pool) { ret = LNN_NG; goto done; }
     {
         struct pack_share sh;
@@ -683,7 +710,7 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
         lnn_parallel_for(nt, nt, copy_range, &sh);
     }
 done:
-    free(types); free(rets); free(pool);
+    free(types); free(rets); pool_give(pool, pool_cached);
     return ret;
 }
 
