@@ -540,6 +540,76 @@ template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p
     else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
 }
 
+/* Layer 0 (2 or 4 taps; 5 or 10 (trial, lag) chains per channel-frame) when every unit length is even: one block per
+ * channel-frame.  All threads window a chunk of samples for each trial and form the lag products into LDS; then lane c adds
+ * the products of chain c in sample order and stores a unit's lag when the unit ends.  The work of a chain is tiny, so what
+ * matters is that the 10240-step dependent chain is nothing but adds fed from LDS.  (The lags are the same for every
+ * regulariser pass: written to pass 0's slot, as in k_autocorr_lane.) */
+#define AL0_CHUNK 512
+template <int P>
+__global__ __launch_bounds__(256) void k_autocorr_l0(Plan p)
+{
+    constexpr int NT = (P >= 4) ? 3 : 2;
+    constexpr int NCH = (P >= 4) ? 10 : 5;
+    __shared__ double sv[NT][AL0_CHUNK + 4];
+    __shared__ double sprod[NCH][AL0_CHUNK];
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x, job = cf * p.R;
+    const DevClass &c = job_class(p, job);
+    const uint32_t na = c.na;
+    const int32_t *xi = p.xint + (size_t)cf * p.S;
+    /* my chain (threads below NCH): trial, lag, unit length */
+    uint32_t ct = 0, clag = tid;
+    if (P >= 4) { if (tid >= 8) { ct = 2; clag = tid - 8; } else if (tid >= 5) { ct = 1; clag = tid - 5; } }
+    else { if (tid >= 3) { ct = 1; clag = tid - 3; } }
+    const uint32_t cn = na >> ct, cnp = (uint32_t)P >> ct;
+    double r = 0.0;
+    uint32_t cloc = 0, cunit = 0;
+    double *cout = p.acorr + ((size_t)job * LNN_MAXT + ct) * LNN_ACW + clag;
+    for (uint32_t base = 0; base < na; base += AL0_CHUNK) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const uint32_t nt = na >> t;
+            const double *wt = p.wtab + c.wt_off[0][t];
+            uint32_t loc = (base + tid) % nt;
+            for (uint32_t i = tid; i < AL0_CHUNK + 4; i += 256) {
+                const uint32_t g = base + i;
+                sv[t][i] = (g < na) ? ((double)xi[g] * p.scale) * wt[loc] : 0.0;
+                loc += 256; while (loc >= nt) loc -= nt;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ch = 0; ch < NCH; ch++) {                          /* chain ch = (trial, lag), constants after unrolling */
+            const int t = (P >= 4) ? ((ch >= 8) ? 2 : (ch >= 5) ? 1 : 0) : ((ch >= 3) ? 1 : 0);
+            const uint32_t lag = (uint32_t)((P >= 4) ? ((ch >= 8) ? ch - 8 : (ch >= 5) ? ch - 5 : ch) : ((ch >= 3) ? ch - 3 : ch));
+            const uint32_t nt = na >> t;
+            uint32_t loc = (base + tid) % nt;
+            for (uint32_t i = tid; i < AL0_CHUNK; i += 256) {
+                const bool pair = (base + i < na) && (loc + lag < nt);   /* both samples inside the same unit */
+                sprod[ch][i] = pair ? sv[t][i] * sv[t][i + lag] : 0.0;
+                loc += 256; while (loc >= nt) loc -= nt;
+            }
+        }
+        __syncthreads();
+        if (tid < NCH) {
+            const uint32_t cnt = (na - base < AL0_CHUNK) ? (na - base) : AL0_CHUNK;
+            const double *q = sprod[tid];
+            uint32_t i = 0;
+            while (i < cnt) {                                       /* runs that end at the chunk's or the unit's end */
+                const uint32_t seg = (cnt - i < cn - cloc) ? (cnt - i) : (cn - cloc), end = i + seg;
+                for (; i + 8 <= end; i += 8) {                      /* +0.0 where the pair leaves the unit: no effect on the bits */
+                    const double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3], q4 = q[i + 4], q5 = q[i + 5], q6 = q[i + 6], q7 = q[i + 7];
+                    r += q0; r += q1; r += q2; r += q3; r += q4; r += q5; r += q6; r += q7;
+                }
+                for (; i < end; i++) r += q[i];
+                cloc += seg;
+                if (cloc == cn) { cout[(size_t)cunit * (cnp + 1)] = r; r = 0.0; cloc = 0; cunit++; }
+            }
+        }
+    }
+}
+
 template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     using Cfg = AcCfg<P>;
@@ -547,8 +617,16 @@ template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uin
     if (layer == 0) hipLaunchKernelGGL((k_autocorr2<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
     else hipLaunchKernelGGL((k_autocorr2<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
 }
-static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
+static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max, bool l0_products)
 {
+    /* the product form has a short dependent chain but few busy lanes: it wins while the batch is too small to fill the chip
+     * with k_autocorr_lane's long-running waves */
+    if (layer == 0 && l0_products && (p.P[0] == 2 || p.P[0] == 4) && p.J / p.R < 6144u) {
+        const uint32_t ncf = p.J / p.R;
+        if (p.P[0] == 4) hipLaunchKernelGGL((k_autocorr_l0<4>), dim3(ncf), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((k_autocorr_l0<2>), dim3(ncf), dim3(256), 0, st, p);
+        return;
+    }
     switch (p.P[layer]) {
     case 2: launch_autocorr_small<2>(st, p, layer, cur, na_max); break;
     case 4: launch_autocorr_small<4>(st, p, layer, cur, na_max); break;

@@ -382,3 +382,13 @@ def test_search_with_and_without_the_fused_forward(product, oracle, monkeypatch,
     # some channel-frame of the second part must have chosen more than one unit in layer 0 or 1 (else the test shows nothing)
     ret, dec = product.decode_whole(mine)
     assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("products", ["0", "1"])
+@pytest.mark.parametrize("preset", [1, 7])
+def test_layer0_autocorrelation_forms_agree(product, oracle, monkeypatch, products, preset):
+    """layer 0's lags come from k_autocorr_l0 (products staged in LDS, one lane per chain) for small batches and from
+    k_autocorr_lane for large ones; LINNE_AMD_L0_PRODUCTS=0 forces the latter here: same bytes either way"""
+    monkeypatch.setenv("LINNE_AMD_L0_PRODUCTS", products)
+    x = music(2, 5 * 4096 + 1234, 16, seed=61 + preset)
+    assert product.encode_whole(x, 16, 44100, 4096, preset, True) == oracle.encode_whole(x, 16, 44100, 4096, preset, True)
