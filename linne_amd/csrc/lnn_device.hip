@@ -61,7 +61,7 @@ struct LINNEAmdContext {
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
     hipStream_t copy_in, copy_out; int has_copy;
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
-    int l0_products;                    /* set per batch by build_classes: every class has even unit lengths in layer 0 and all its trials (k_autocorr_l0) */
+    int prod_ok;                        /* set per batch by build_classes, bit l: in layer l every class has all its trials and even unit lengths (k_autocorr_prod) */
     int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
 };
@@ -336,11 +336,16 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
         if (cls[k].na > ctx->na_max) ctx->na_max = cls[k].na;
         idx[f] = k;
     }
-    if (for_encode) {       /* layer 0 by products (k_autocorr_l0): all trials present and every unit length even, in every class */
-        const uint32_t nt0 = (hs->P[0] >= 4u) ? 3u : 2u;
+    if (for_encode) {       /* short layers by products (k_autocorr_prod): all trials present and every unit length even, in every class */
         const char *e_ = getenv("LINNE_AMD_L0_PRODUCTS");
-        ctx->l0_products = (e_ ? atoi(e_) : 1) && (hs->P[0] == 2u || hs->P[0] == 4u);
-        for (uint32_t k = 0; k < ncls; k++) if (cls[k].ntrials[0] != nt0 || (cls[k].na % (1u << nt0)) != 0) ctx->l0_products = 0;
+        ctx->prod_ok = 0;
+        for (uint32_t l = 0; l < hs->L; l++) {
+            if (hs->P[l] > 16u || !(e_ ? atoi(e_) : 1)) continue;
+            uint32_t nt = 0; for (uint32_t u = 1; u <= hs->P[l]; u <<= 1) nt++;
+            int ok = 1;
+            for (uint32_t k = 0; k < ncls; k++) if (cls[k].ntrials[l] != nt || (cls[k].na % (1u << nt)) != 0) ok = 0;
+            if (ok) ctx->prod_ok |= 1 << l;
+        }
     }
     int ret;
     if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
@@ -520,7 +525,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             /* the first two layers nearly always keep one unit: their search pass also writes that trial's forward output */
             const uint32_t fir_spec = (ctx->fir_spec && l + 1 < hs.L) ? 1u : 0u;
             {
-                const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max, ctx->l0_products != 0); span_end(ctx, sp_, st);
+                const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, st);
             }
             { const int sp_ = span_begin(ctx, 4, st);
               for (uint32_t t = 0, u = 1; u <= maxu; u <<= 1, t++) {             /* one launch per trial: every order on LDS columns */

@@ -540,52 +540,64 @@ template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p
     else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
 }
 
-/* Layer 0 (2 or 4 taps; 5 or 10 (trial, lag) chains per channel-frame) when every unit length is even: one block per
- * channel-frame.  All threads window a chunk of samples for each trial and form the lag products into LDS; then lane c adds
- * the products of chain c in sample order and stores a unit's lag when the unit ends.  The work of a chain is tiny, so what
- * matters is that the 10240-step dependent chain is nothing but adds fed from LDS.  (The lags are the same for every
- * regulariser pass: written to pass 0's slot, as in k_autocorr_lane.) */
-#define AL0_CHUNK 512
-template <int P>
-__global__ __launch_bounds__(256) void k_autocorr_l0(Plan p)
+/* Short layers when the batch is small and every unit length is even: one block per row (a job; for layer 0 a channel-frame,
+ * whose lags serve every regulariser pass).  All threads window a chunk of samples for each trial and form the lag products
+ * into LDS; then lane c adds the products of chain c = (trial, lag) in sample order and stores a unit's lag when the unit
+ * ends.  The 10240-step dependent chain is nothing but adds fed from LDS, so a row takes ~0.1 ms where k_autocorr_lane's
+ * waves take ~1 ms -- but only a few lanes are busy, so the lane kernel wins once the batch fills the chip. */
+template <int P> struct ApCfg {
+    static constexpr int NT = (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2;
+    static constexpr int nch() { int s = 0; for (int t = 0; t < NT; t++) s += (P >> t) + 1; return s; }      /* 36, 19, 10, 5 */
+    static constexpr int NCH = nch();
+    static constexpr int CHUNK = (P >= 16) ? 128 : (P >= 8) ? 256 : 512;
+    static constexpr int trial_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return t; }
+    static constexpr int lag_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return ch; }
+};
+template <int P, bool L0>
+__global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, uint32_t cur)
 {
-    constexpr int NT = (P >= 4) ? 3 : 2;
-    constexpr int NCH = (P >= 4) ? 10 : 5;
-    __shared__ double sv[NT][AL0_CHUNK + 4];
-    __shared__ double sprod[NCH][AL0_CHUNK];
-    const uint32_t cf = blockIdx.x, tid = threadIdx.x, job = cf * p.R;
+    using Cfg = ApCfg<P>;
+    constexpr int NT = Cfg::NT, NCH = Cfg::NCH, CHUNK = Cfg::CHUNK;
+    __shared__ double sv[NT][CHUNK + P];
+    __shared__ double sprod[NCH][CHUNK];
+    const uint32_t row = blockIdx.x, tid = threadIdx.x, job = L0 ? row * p.R : row;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
-    const int32_t *xi = p.xint + (size_t)cf * p.S;
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
+    const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
     /* my chain (threads below NCH): trial, lag, unit length */
     uint32_t ct = 0, clag = tid;
-    if (P >= 4) { if (tid >= 8) { ct = 2; clag = tid - 8; } else if (tid >= 5) { ct = 1; clag = tid - 5; } }
-    else { if (tid >= 3) { ct = 1; clag = tid - 3; } }
+    while (ct + 1 < (uint32_t)NT && clag >= ((uint32_t)P >> ct) + 1) { clag -= ((uint32_t)P >> ct) + 1; ct++; }
     const uint32_t cn = na >> ct, cnp = (uint32_t)P >> ct;
     double r = 0.0;
     uint32_t cloc = 0, cunit = 0;
     double *cout = p.acorr + ((size_t)job * LNN_MAXT + ct) * LNN_ACW + clag;
-    for (uint32_t base = 0; base < na; base += AL0_CHUNK) {
+    for (uint32_t base = 0; base < na; base += CHUNK) {
         __syncthreads();
+        uint32_t loc0[NT];                                          /* place of sample base + tid inside its unit, per trial: one modulo each */
+#pragma unroll
+        for (int t = 0; t < NT; t++) loc0[t] = (base + tid) % (na >> t);
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const uint32_t nt = na >> t;
-            const double *wt = p.wtab + c.wt_off[0][t];
-            uint32_t loc = (base + tid) % nt;
-            for (uint32_t i = tid; i < AL0_CHUNK + 4; i += 256) {
+            const double *wt = p.wtab + c.wt_off[layer][t];
+            uint32_t loc = loc0[t];
+            for (uint32_t i = tid; i < CHUNK + P; i += 256) {
                 const uint32_t g = base + i;
-                sv[t][i] = (g < na) ? ((double)xi[g] * p.scale) * wt[loc] : 0.0;
+                const double xv = (g < na) ? (L0 ? ((double)xi[g] * p.scale) : xd[g]) : 0.0;
+                sv[t][i] = (g < na) ? xv * wt[loc] : 0.0;
                 loc += 256; while (loc >= nt) loc -= nt;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int ch = 0; ch < NCH; ch++) {                          /* chain ch = (trial, lag), constants after unrolling */
-            const int t = (P >= 4) ? ((ch >= 8) ? 2 : (ch >= 5) ? 1 : 0) : ((ch >= 3) ? 1 : 0);
-            const uint32_t lag = (uint32_t)((P >= 4) ? ((ch >= 8) ? ch - 8 : (ch >= 5) ? ch - 5 : ch) : ((ch >= 3) ? ch - 3 : ch));
+            constexpr int dummy = 0; (void)dummy;
+            const int t = Cfg::trial_of(ch);
+            const uint32_t lag = (uint32_t)Cfg::lag_of(ch);
             const uint32_t nt = na >> t;
-            uint32_t loc = (base + tid) % nt;
-            for (uint32_t i = tid; i < AL0_CHUNK; i += 256) {
+            uint32_t loc = loc0[t];
+            for (uint32_t i = tid; i < CHUNK; i += 256) {
                 const bool pair = (base + i < na) && (loc + lag < nt);   /* both samples inside the same unit */
                 sprod[ch][i] = pair ? sv[t][i] * sv[t][i + lag] : 0.0;
                 loc += 256; while (loc >= nt) loc -= nt;
@@ -593,7 +605,7 @@ __global__ __launch_bounds__(256) void k_autocorr_l0(Plan p)
         }
         __syncthreads();
         if (tid < NCH) {
-            const uint32_t cnt = (na - base < AL0_CHUNK) ? (na - base) : AL0_CHUNK;
+            const uint32_t cnt = (na - base < CHUNK) ? (na - base) : CHUNK;
             const double *q = sprod[tid];
             uint32_t i = 0;
             while (i < cnt) {                                       /* runs that end at the chunk's or the unit's end */
@@ -617,15 +629,20 @@ template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uin
     if (layer == 0) hipLaunchKernelGGL((k_autocorr2<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
     else hipLaunchKernelGGL((k_autocorr2<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
 }
-static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max, bool l0_products)
+static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max, bool prod_ok)
 {
     /* the product form has a short dependent chain but few busy lanes: it wins while the batch is too small to fill the chip
      * with k_autocorr_lane's long-running waves */
-    if (layer == 0 && l0_products && (p.P[0] == 2 || p.P[0] == 4) && p.J / p.R < 6144u) {
-        const uint32_t ncf = p.J / p.R;
-        if (p.P[0] == 4) hipLaunchKernelGGL((k_autocorr_l0<4>), dim3(ncf), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((k_autocorr_l0<2>), dim3(ncf), dim3(256), 0, st, p);
-        return;
+    if (prod_ok && p.P[layer] <= 16u) {
+        const uint32_t rows = (layer == 0) ? p.J / p.R : p.J;
+        const bool small = (layer == 0) ? (rows < 6144u) : (rows <= 512u);
+        if (small) {
+#define LNN_AP(PP) do { if (layer == 0) hipLaunchKernelGGL((k_autocorr_prod<PP, true>), dim3(rows), dim3(256), 0, st, p, layer, cur); \
+                        else hipLaunchKernelGGL((k_autocorr_prod<PP, false>), dim3(rows), dim3(256), 0, st, p, layer, cur); } while (0)
+            switch (p.P[layer]) { case 2: LNN_AP(2); break; case 4: LNN_AP(4); break; case 8: LNN_AP(8); break; default: LNN_AP(16); break; }
+#undef LNN_AP
+            return;
+        }
     }
     switch (p.P[layer]) {
     case 2: launch_autocorr_small<2>(st, p, layer, cur, na_max); break;
