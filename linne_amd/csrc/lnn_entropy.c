@@ -255,7 +255,7 @@ struct rice_scratch {
 __attribute__((target_clones("avx512f", "avx2", "default")))
 static void rice_excess_prefix(const uint32_t *u, uint32_t parts, uint32_t ns, uint32_t k, uint32_t *t, uint32_t *prefix)
 {
-    const uint32_t k1pow = 1u << (k + 1), n = parts * ns;
+    const uint32_t k1pow = 1u << ((k + 1) & 31u), n = parts * ns;     /* k = 31: see rice_emit */
     uint32_t s, part, acc = 0;
     for (s = 0; s < n; s++) { const uint32_t v = u[s]; const uint32_t x = (v > k1pow) ? (v - k1pow) : 0u; t[s] = x >> k; }
     prefix[0] = 0;
@@ -277,7 +277,10 @@ static void rice_emit(struct bitw *w, const int32_t *data, uint32_t n, uint32_t 
         uint32_t prevk2 = 0;
         bw_put(w, best, RICE_LOG2_PARTS);
         for (part = 0; part < (1u << best); part++) {
-            const uint32_t k2 = k2s[part], k1 = k2 + 1, k1pow = 1u << k1, k2mask = (1u << k2) - 1u;
+            /* k2 = 31 (means beyond 3.2e9: not audio) makes the reference's `1U << k1` a shift by the type's width; the count
+             * is taken modulo 32 here, on the device (k_rice_plan) and in the decoder -- what the reference's x86 build does */
+            const uint32_t k2 = k2s[part], k1 = k2 + 1, k1pow = 1u << (k1 & 31u), k2mask = (1u << k2) - 1u;
+            const uint64_t lead = 1ull << k1;
             const int32_t *q = data + (size_t)part * ns;
             if (part == 0) bw_put(w, k2, 5);
             else {
@@ -296,7 +299,7 @@ static void rice_emit(struct bitw *w, const int32_t *data, uint32_t n, uint32_t 
                 for (s = 0; s < ns; s++) {
                     const uint32_t v = zz(q[s]), d = v - k1pow, quot = d >> k2;
                     const uint32_t m = 0u - (uint32_t)(v < k1pow);                       /* all ones when v < 2^k1 */
-                    const uint64_t val = (uint64_t)(((k1pow | v) & m) | (((1u << k2) | (d & k2mask)) & ~m));
+                    const uint64_t val = ((lead | v) & (0ull - (uint64_t)(m & 1u))) | (uint64_t)(((1u << k2) | (d & k2mask)) & ~m);
                     const uint32_t len = ((k1 + 1) & m) | ((quot + 2 + k2) & ~m);
                     if (__builtin_expect(len > 56 || wp >= fast_end, 0)) {
                         w->p = wp; w->acc = acc; w->n = nb;
@@ -386,7 +389,7 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
                 const uint32_t ns = n >> order;
                 uint32_t prevk2 = 0, bits = 0;
                 for (part = 0; part < (1u << order); part++) {
-                    const uint32_t k2 = sc->k2[order][part], k1 = k2 + 1, k1pow = 1u << k1;
+                    const uint32_t k2 = sc->k2[order][part], k1pow = 1u << ((k2 + 1) & 31u);
                     const uint32_t *q = u + (size_t)part * ns;
                     bits += ns * (k2 + 2) + rice_excess(q, ns, k1pow, k2);      /* (v < 2^k1) ? k1+1 : k2+2+((v-2^k1)>>k2), k1 = k2+1 */
                     bits += part ? gamma_len(zz((int32_t)k2 - (int32_t)prevk2)) : 5u;
@@ -402,21 +405,25 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
     return 0;
 }
 
-static void rice_decode(struct bitr *r, int32_t *data, uint32_t n)
+/* returns 0, or -1 for a header no encoder writes (partition order beyond the maximum, a parameter step whose gamma code
+ * is longer than 32 digits): only a damaged stream read with the CRC check off gets here */
+static int rice_decode(struct bitr *r, int32_t *data, uint32_t n)
 {
-    const uint32_t order = br_get(r, RICE_LOG2_PARTS), ns = n >> order;
+    const uint32_t order = br_get(r, RICE_LOG2_PARTS), ns = (order <= RICE_LOG2_PARTS) ? (n >> order) : 0u;
     uint32_t part, s, k2 = 0;
+    if (order > RICE_LOG2_PARTS) return -1;
     for (part = 0; part < (1u << order); part++) {
-        if (br_pos_over(r)) return;
+        if (br_pos_over(r)) return 0;
         if (part == 0) k2 = br_get(r, 5);
         else {
             const uint32_t nd = br_zero_run(r) + 1;
+            if (nd > 32) return -1;
             const uint32_t g = (nd == 1) ? 0u : (uint32_t)((1ul << (nd - 1)) + br_get(r, nd - 1) - 1);
             k2 = (uint32_t)((int32_t)k2 + unzz(g));
         }
         k2 &= 31u;
         {
-            const uint32_t k1 = (k2 + 1) & 31u, k1pow = 1u << k1;
+            const uint32_t k1 = k2 + 1, k1pow = 1u << (k1 & 31u);        /* k2 = 31: see rice_emit */
             int32_t *q = data + (size_t)part * ns;
             {   /* the reader's state lives in locals in this loop (stores to q[] do not alias it, but it keeps the window,
                  * the count and the pointer in registers across the general-reader calls' boundaries) */
@@ -443,6 +450,7 @@ static void rice_decode(struct bitr *r, int32_t *data, uint32_t n)
             }
         }
     }
+    return 0;
 }
 
 /* ------------------------------------------------------------------------------------------------ blocks */
@@ -766,7 +774,7 @@ int lnn_parse_block(const struct LINNEAmdShape *shape, const struct lnn_layers *
                 for (i = 0; i < ly->size[l]; i++) rec[LINNE_AMD_PRM_COEF + ly->offset[l] + i] = unzz(huff_get(&r));
             }
         }
-        for (ch = 0; ch < C; ch++) rice_decode(&r, samples + (size_t)ch * S, n);
+        for (ch = 0; ch < C; ch++) if (rice_decode(&r, samples + (size_t)ch * S, n) != 0) return LNN_INVALID_FORMAT;
         *consumed_out = 11 + (uint32_t)br_bytes(&r);
     } else return LNN_INVALID_FORMAT;
     return LNN_OK;

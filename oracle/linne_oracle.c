@@ -182,7 +182,8 @@ static void rice_param(double mean, uint32_t *k1, uint32_t *k2)
     *k2 = (uint32_t)((0 > t) ? 0 : t);
     *k1 = *k2 + 1;
 }
-/* linne_coder.c:203-214 */
+/* linne_coder.c:203-214 (k1 = 32, i.e. a partition mean above 3.2e9, shifts by the type's width there and here: undefined; the
+ * product takes the count modulo 32 -- see DESIGN 5) */
 static uint32_t rice_len(uint32_t k1, uint32_t k2, uint32_t u)
 {
     const uint32_t k1pow = 1u << k1;
