@@ -28,8 +28,16 @@ struct DevClass {
     uint32_t wt_off[LNN_MAXL][LNN_MAXT];      /* offset of the trial's Welch weight table (padded unit: n + max(p,4) entries) */
 };
 
+/* Rows of a chunk (channel-frames, or jobs) cut into runs of one length class, so that the kernels that put 64 rows on
+ * the lanes of a wave see blocks of one class and may take their wave-uniform fast paths; a ragged last frame gets a
+ * block of its own.  Run i = rows [row_begin[i], row_begin[i+1]) = blocks [blk_begin[i], blk_begin[i+1]) of 64 rows.
+ * More than LNN_MAXRUN runs in a chunk: one run over everything (blocks may then mix classes: slower, same results). */
+#define LNN_MAXRUN 8
+struct RowRuns { uint32_t n; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_begin[LNN_MAXRUN + 1]; };
+
 struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;
+    RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */
     uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
     double regs[LNN_MAXR];
     double scale;                       /* 2^-(bits-1), exact */

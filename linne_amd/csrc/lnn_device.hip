@@ -57,6 +57,7 @@ struct LINNEAmdContext {
     /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
     DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_for_encode, sig_valid;
     /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
+    const uint32_t *cur_idx;            /* class index per frame of the call being enqueued (host copy, in the meta ring) */
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
     hipStream_t copy_in, copy_out; int has_copy;
@@ -298,6 +299,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
     int m;
     { const int r_ = meta_acquire(ctx, F, &m); if (r_ != LNN_OK) return r_; }
     uint32_t *idx = ctx->meta_h[m], *nsm = ctx->meta_h[m] + F;
+    ctx->cur_idx = idx;
     memset(cls, 0, sizeof(cls));
     ctx->na_max = 0;
     uint64_t sin_total = 0, wt_total = 0;
@@ -396,6 +398,23 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
 }
 
 static uint64_t align_up(uint64_t v) { return (v + 255u) & ~(uint64_t)255u; }
+
+/* RowRuns of a chunk of frames whose rows are `rpf` per frame (see lnn_dev_common.h) */
+static void build_runs(RowRuns *rr, const uint32_t *idx, uint32_t F, uint32_t rpf)
+{
+    uint32_t n = 0, f = 0;
+    rr->row_begin[0] = 0; rr->blk_begin[0] = 0;
+    while (f < F) {
+        uint32_t g = f + 1;
+        while (g < F && idx[g] == idx[f]) g++;
+        if (n == LNN_MAXRUN) { n = 0; break; }                  /* too many runs: one run over everything */
+        rr->row_begin[n + 1] = g * rpf;
+        rr->blk_begin[n + 1] = rr->blk_begin[n] + ((g - f) * rpf + 63u) / 64u;
+        n++; f = g;
+    }
+    if (n == 0) { n = 1; rr->row_begin[1] = F * rpf; rr->blk_begin[1] = (F * rpf + 63u) / 64u; }
+    rr->n = n;
+}
 
 /* bytes of scratch one frame needs (C channel-frames, R passes each) */
 static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const HostShape *hs)
@@ -505,6 +524,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
         p.pcm = d_pcm + (size_t)f0 * C * S; p.resid = d_residual + (size_t)f0 * C * S;
         p.prm = d_params + (size_t)f0 * C * LINNE_AMD_PARAM_WORDS; p.stats = d_stats + (size_t)f0 * C * LINNE_AMD_STAT_WORDS;
+        build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount;
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
         uint8_t *a = abase;

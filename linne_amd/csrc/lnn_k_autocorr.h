@@ -289,10 +289,10 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
  * register window w[0..K+3]; step q adds w[q]*w[q+j] to lag j.  No LDS, no barrier.  Same chains, same order as
  * k_autocorr2.
  * ---------------------------------------------------------------------------------------------- */
-template <int K, bool L0>
+template <int K, bool L0, int D = 1>          /* D: groups of U = 4 steps by which the loads run ahead of the multiply-adds */
 __device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uint32_t cur, uint32_t q_end, uint32_t job, uint32_t t, bool active)
 {
-    constexpr int U = 4;
+    constexpr int U = 4;                      /* a group must fit in the zero zone after a unit (>= 4 steps): units are flushed between groups */
     constexpr uint32_t np = K - 1;
     const DevClass &c = job_class(p, job);
     const uint32_t u = 1u << t;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uin
         const double vv = (odd && rloc == mid) ? stale : v;
         return (rloc == 0xFFFFFFFFu) ? 0.0 : vv;
     };
-    double r[K], w[K + U], fx[U], fw[U]; uint32_t fl[U];
+    double r[K], w[K + U], fx[D][U], fw[D][U]; uint32_t fl[D][U];
 #pragma unroll
     for (int j = 0; j < K; j++) {
         r[j] = 0.0;
@@ -334,29 +334,35 @@ __device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uin
         w[j] = gen_finish(rx, rw, rl);
     }
 #pragma unroll
-    for (int j = 0; j < U; j++) gen_issue(fx[j], fw[j], fl[j]);
+    for (int d = 0; d < D; d++) {
+#pragma unroll
+        for (int j = 0; j < U; j++) gen_issue(fx[d][j], fw[d][j], fl[d][j]);
+    }
     uint32_t a_unit = 0, flush_pos = n;
     double *out = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW;
 #pragma unroll 1
-    for (uint32_t q0 = 0; q0 < q_end; q0 += U) {
-        if (active && q0 >= flush_pos) {           /* in the zero zone after a unit: store its lags, restart */
-            double *o = out + (size_t)a_unit * K;
+    for (uint32_t q0 = 0; q0 < q_end; q0 += U * D) {
 #pragma unroll
-            for (int j = 0; j < K; j++) { o[j] = r[j]; r[j] = 0.0; }
-            a_unit++;
-            flush_pos = (a_unit < u) ? (flush_pos + upl) : 0xFFFFFFFFu;
+        for (int d = 0; d < D; d++) {
+            if (active && q0 + (uint32_t)(d * U) >= flush_pos) {   /* in the zero zone after a unit: store its lags, restart */
+                double *o = out + (size_t)a_unit * K;
+#pragma unroll
+                for (int j = 0; j < K; j++) { o[j] = r[j]; r[j] = 0.0; }
+                a_unit++;
+                flush_pos = (a_unit < u) ? (flush_pos + upl) : 0xFFFFFFFFu;
+            }
+#pragma unroll
+            for (int j = 0; j < U; j++) w[K + j] = gen_finish(fx[d][j], fw[d][j], fl[d][j]);
+#pragma unroll
+            for (int j = 0; j < U; j++) gen_issue(fx[d][j], fw[d][j], fl[d][j]);     /* the loads of group +D fly during the MACs */
+#pragma unroll
+            for (int tt = 0; tt < U; tt++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) r[j] += w[tt] * w[tt + j];
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) w[j] = w[j + U];
         }
-#pragma unroll
-        for (int j = 0; j < U; j++) w[K + j] = gen_finish(fx[j], fw[j], fl[j]);
-#pragma unroll
-        for (int j = 0; j < U; j++) gen_issue(fx[j], fw[j], fl[j]);      /* next group's loads fly during the MACs */
-#pragma unroll
-        for (int tt = 0; tt < U; tt++) {
-#pragma unroll
-            for (int j = 0; j < K; j++) r[j] += w[tt] * w[tt + j];
-        }
-#pragma unroll
-        for (int j = 0; j < K; j++) w[j] = w[j + U];
     }
 }
 
@@ -473,6 +479,136 @@ __device__ __forceinline__ void autocorr_shared(const Plan &p, uint32_t layer, u
     }
 }
 
+/* Layers of order <= 4 in the fast form.  The 64 rows of a block are few waves' worth of work (layer 0: rows are channel-
+ * frames), and one wave cannot issue FP64 instructions back to back (tools/ubench/dp_rate.hip: a lone wave gets ~40 % of
+ * its SIMD's rate), so the block spreads the lags over many lean waves: wave -> (trial TT, lags J0 .. J0+JN-1).  The rows'
+ * samples pass once through a transposed LDS tile (coalesced 16-byte loads shared by the block's waves, converted and scaled
+ * on the way in; lane = row reads); a wave windows each sample for its trial (the weights of a tile sit in LDS, read by
+ * broadcast) and multiplies it with the trial's last values, kept in a register ring: lag j adds v[m-j] * v[m] when sample
+ * m arrives -- the reference's products in the reference's order (the pairs that would reach past a unit's end simply never
+ * form; in the padded-stream kernels they add +0.0).  No window generator, no stream bookkeeping: 1 + 2 JN multiply/adds
+ * per sample.  Units end at multiples of the finest unit (a multiple of 4 samples), checked once per 4 samples. */
+template <int P, bool L0, int TT, int J0, int JN, int NW>
+__device__ __forceinline__ void autocorr_rows(const Plan &p, uint32_t layer, uint32_t cur, uint32_t row0, uint32_t nrows, uint32_t rstride,
+        uint32_t na, const DevClass &c0, uint32_t wave, uint32_t lane, double (*xt)[32][65], double (*wtile)[32])
+{
+    constexpr int NT = AcCfg<P>::NT, T = 32, NLD = L0 ? 8 : 16, PT = P >> TT;      /* PT: order of my trial = ring length (divides 4) */
+    constexpr int NSLOT = (NLD + NW - 1) / NW;
+    static_assert(P <= 4 && J0 + JN <= PT + 1, "register rings are laid out for groups of 4 samples");
+    typedef typename std::conditional<L0, int4, lnn_d2>::type XV;
+    const uint32_t ntiles = na / T, seg = na >> (NT - 1), nt = na >> TT;
+    uint32_t myrow = row0 + lane; if (myrow >= nrows) myrow = nrows - 1;
+    const bool store = (row0 + lane) < nrows;
+    double *out = p.acorr + ((size_t)myrow * rstride * LNN_MAXT + TT) * LNN_ACW + J0;
+    /* tile loads: L0 -- instruction k covers rows 8k + lane/8, samples 4(lane%8)..+3; else rows 4k + lane/16, samples 2(lane%16)..+1;
+     * wave w issues the instructions k = w, w + NW, ... */
+    const uint32_t lrow = L0 ? (lane >> 3) : (lane >> 4), lsmp = L0 ? 4u * (lane & 7u) : 2u * (lane & 15u);
+    const void *src[NSLOT];
+#pragma unroll
+    for (int i = 0; i < NSLOT; i++) {
+        const uint32_t k = wave + (uint32_t)i * NW;
+        uint32_t r = row0 + (L0 ? 8u : 4u) * (k < (uint32_t)NLD ? k : 0u) + lrow; if (r >= nrows) r = nrows - 1;
+        if (L0) src[i] = p.xint + (size_t)r * p.S + lsmp;                   /* rows are channel-frames */
+        else src[i] = p.sig + ((size_t)r * 2 + cur) * p.S + lsmp;
+    }
+    const double *wt = p.wtab + (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.wt_off[layer][TT]);
+    /* the weights of a tile, all trials: wave t (< NT) fetches trial t's */
+    const double *wts = p.wtab + (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.wt_off[layer][wave < (uint32_t)NT ? wave : 0u]);
+    const uint32_t wnt = na >> (wave < (uint32_t)NT ? wave : 0u);
+    uint32_t wloc = 0;
+    (void)wt; (void)nt;
+    XV pre[NSLOT]; double prew = 0.0;
+    auto issue = [&](uint32_t tile_idx) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++)
+            if (wave + (uint32_t)i * NW < (uint32_t)NLD) pre[i] = *(const XV *)((L0 ? (const char *)src[i] + (size_t)tile_idx * T * 4 : (const char *)src[i] + (size_t)tile_idx * T * 8));
+        if (wave < (uint32_t)NT) {
+            uint32_t l = wloc + (lane & (T - 1u)); if (l >= wnt) l -= wnt;      /* wnt >= seg >= T */
+            prew = wts[l];
+            wloc += T; if (wloc >= wnt) wloc -= wnt;
+        }
+    };
+    auto commit = [&](uint32_t buf) {
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NW;
+            if (k < (uint32_t)NLD) {
+                const uint32_t r = (L0 ? 8u : 4u) * k + lrow;
+                if (L0) {
+                    const int4 v = *(const int4 *)&pre[i];
+                    xt[buf][lsmp][r] = (double)v.x * p.scale; xt[buf][lsmp + 1][r] = (double)v.y * p.scale;
+                    xt[buf][lsmp + 2][r] = (double)v.z * p.scale; xt[buf][lsmp + 3][r] = (double)v.w * p.scale;
+                } else { const lnn_d2 v = *(const lnn_d2 *)&pre[i]; xt[buf][lsmp][r] = v.x; xt[buf][lsmp + 1][r] = v.y; }
+            }
+        }
+        if (wave < (uint32_t)NT && lane < T) wtile[buf * NT + wave][lane] = prew;
+    };
+    double r[JN], ring[PT], q[JN];
+#pragma unroll
+    for (int j = 0; j < JN; j++) { r[j] = 0.0; q[j] = 0.0; }
+#pragma unroll
+    for (int j = 0; j < PT; j++) ring[j] = 0.0;
+    /* The two tiles form a ring of 2T samples.  Hand-pipelined: in one step the adds of sample m-1's products, the products
+     * of sample m, the windowing of sample m+1 (independent of each other), with the LDS reads of the next group in flight. */
+    auto read_group = [&](uint32_t slot, double *xv, double *wv) {         /* slot: ring position of the group, multiple of 4 */
+        const uint32_t buf = slot / T, o = slot % T;
+#pragma unroll
+        for (int i = 0; i < 4; i++) xv[i] = xt[buf][o + i][lane];
+        const lnn_d2 a = *(const lnn_d2 *)&wtile[buf * NT + TT][o], b = *(const lnn_d2 *)&wtile[buf * NT + TT][o + 2];
+        wv[0] = a.x; wv[1] = a.y; wv[2] = b.x; wv[3] = b.y;
+    };
+    issue(0); commit(0);
+    __syncthreads();
+    double xv[4], wv[4], vcur;
+    read_group(0, xv, wv);
+    vcur = xv[0] * wv[0];
+    uint32_t to_b = seg, bcount = 0, unit = 0;
+#pragma unroll 1
+    for (uint32_t ti = 0; ti < ntiles; ti++) {
+        const uint32_t buf = ti & 1u;
+        if (ti + 1 < ntiles) issue(ti + 1);
+#pragma unroll
+        for (int g = 0; g < T / 4; g++) {
+            if (g == T / 4 - 1) {                                   /* the next group lies in the other tile: publish it */
+                if (ti + 1 < ntiles) commit(buf ^ 1u);
+                __syncthreads();
+            }
+            double nx[4], nw[4];
+            read_group((buf * T + 4 * (uint32_t)g + 4) % (2 * T), nx, nw);      /* past the last tile: stale data, never used */
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+#pragma unroll
+                for (int j = 0; j < JN; j++) r[j] += q[j];          /* adds of the previous sample's products */
+                const double v = vcur;
+#pragma unroll
+                for (int j = 0; j < JN; j++) q[j] = (J0 + j == 0) ? (v * v) : (ring[((i - (J0 + j)) % PT + PT) % PT] * v);
+                ring[i % PT] = v;
+                vcur = (i < 3) ? (xv[(i + 1) & 3] * wv[(i + 1) & 3]) : (nx[0] * nw[0]);          /* window the next one */
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { xv[i] = nx[i]; wv[i] = nw[i]; }
+            to_b -= 4;
+            if (to_b == 0) {                                        /* a finest unit ends here; my trial's unit with every 2^(NT-1-TT)-th */
+                to_b = seg; bcount++;
+                if ((bcount & ((1u << (NT - 1 - TT)) - 1u)) == 0) {
+#pragma unroll
+                    for (int j = 0; j < JN; j++) { r[j] += q[j]; q[j] = 0.0; }           /* the unit's last products */
+                    if (store) {
+                        double *o = out + (size_t)unit * (PT + 1);
+#pragma unroll
+                        for (int j = 0; j < JN; j++) o[j] = r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < JN; j++) r[j] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < PT; j++) ring[j] = 0.0;
+                    unit++;
+                }
+            }
+        }
+    }
+}
+
 /* Short layers (P <= 16).  grid.x = groups of 64 rows: a row is a job, or for layer 0 a channel-frame (its input, the
  * pre-emphasised channel, is the same for every regulariser pass, so the lags are computed once and the Levinson kernels
  * read pass 0's copy).  A wave of the block owns 2 to 7 lags of one trial of the 64 rows (AcsWaves), ordered so that the
@@ -480,17 +616,25 @@ __device__ __forceinline__ void autocorr_shared(const Plan &p, uint32_t layer, u
 template <int P> struct AcsWaves;
 template <> struct AcsWaves<16> { static constexpr int NW = 8; };
 template <> struct AcsWaves<8>  { static constexpr int NW = 5; };
-template <> struct AcsWaves<4>  { static constexpr int NW = 3; };
-template <> struct AcsWaves<2>  { static constexpr int NW = 2; };
+template <> struct AcsWaves<4>  { static constexpr int NW = 10; };
+template <> struct AcsWaves<2>  { static constexpr int NW = 5; };
 
 template <int P, bool L0>
-__global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 2) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
+__global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 5) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     using Cfg = AcCfg<P>;
     constexpr int NT = Cfg::NT, NW = AcsWaves<P>::NW;
     __shared__ double tile[2][ACS_T][65];
+    __shared__ __attribute__((aligned(16))) double wts_mem[(P <= 4) ? 2 * NT * 32 : 2];     /* autocorr_rows: the weights of two tiles, every trial */
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t rstride = L0 ? p.R : 1u, nrows = p.J / rstride, row0 = blockIdx.x * 64;
+    const uint32_t rstride = L0 ? p.R : 1u;
+    /* my block of 64 rows of one class run (RowRuns); the blocks are taken in reverse so that a ragged last frame, whose
+     * block may need the slow general form, starts first and runs beside the others */
+    const RowRuns &rr = p.runs[L0 ? 0 : 1];
+    const uint32_t b = gridDim.x - 1u - blockIdx.x;
+    uint32_t run = 0;
+    while (run + 1 < rr.n && b >= rr.blk_begin[run + 1]) run++;
+    const uint32_t row0 = rr.row_begin[run] + (b - rr.blk_begin[run]) * 64u, nrows = rr.row_begin[run + 1];
     uint32_t row = row0 + lane;
     const bool inrange = row < nrows;
     if (!inrange) row = nrows - 1;
@@ -500,8 +644,25 @@ __global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 2) void k_auto
     const DevClass &c0 = p.cls[ci0];
     const uint32_t na = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.na);
     const bool fast = __all(ci == ci0) && c0.ntrials[layer] == (uint32_t)NT && (na % (4u << (NT - 1))) == 0 && (na % ACS_T) == 0;
-#define ACS_RUN(T_, K_, J0_, JN_) autocorr_shared<K_, J0_, JN_, L0, NW>(p, layer, cur, row0, nrows, rstride, na, \
+    constexpr int NWS = (P == 4) ? 3 : (P == 2) ? 2 : NW;     /* waves of the shared-tile form (orders <= 4 run it only when autocorr_rows cannot) */
+#define ACS_RUN(T_, K_, J0_, JN_) autocorr_shared<K_, J0_, JN_, L0, NWS>(p, layer, cur, row0, nrows, rstride, na, \
         (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.wt_off[layer][T_]), T_, wave, lane, tile)
+    if constexpr (P <= 4) {
+        if (fast && (na >> (NT - 1)) >= 32u && (p.S & 3u) == 0) {    /* one lag per wave */
+            double (*wtile)[32] = (double (*)[32])wts_mem;
+#define ROWS_RUN(T_, J0_) autocorr_rows<P, L0, T_, J0_, 1, NW>(p, layer, cur, row0, nrows, rstride, na, c0, wave, lane, tile, wtile)
+            if constexpr (P == 4) switch (wave) {
+                case 0: ROWS_RUN(0, 0); break; case 1: ROWS_RUN(0, 1); break; case 2: ROWS_RUN(0, 2); break; case 3: ROWS_RUN(0, 3); break;
+                case 4: ROWS_RUN(0, 4); break; case 5: ROWS_RUN(1, 0); break; case 6: ROWS_RUN(1, 1); break; case 7: ROWS_RUN(1, 2); break;
+                case 8: ROWS_RUN(2, 0); break; default: ROWS_RUN(2, 1); break;
+            } else switch (wave) {
+                case 0: ROWS_RUN(0, 0); break; case 1: ROWS_RUN(0, 1); break; case 2: ROWS_RUN(0, 2); break;
+                case 3: ROWS_RUN(1, 0); break; default: ROWS_RUN(1, 1); break;
+            }
+#undef ROWS_RUN
+            return;
+        }
+    }
     if (fast) {                                             /* every wave of the block sees the same rows: same decision */
         if (P == 16) switch (wave) {                        /* waves w and w+4 share a SIMD: 9 / 9 / 10 / 8 lags per SIMD */
             case 0: ACS_RUN(0, 17, 10, 7); break; case 1: ACS_RUN(0, 17, 0, 5); break;  case 2: ACS_RUN(0, 17, 5, 5); break;
@@ -511,9 +672,9 @@ __global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 2) void k_auto
             case 0: ACS_RUN(0, 9, 0, 5); break;   case 1: ACS_RUN(0, 9, 5, 4); break;   case 2: ACS_RUN(1, 5, 0, 5); break;
             case 3: ACS_RUN(2, 3, 0, 3); break;   default: ACS_RUN(3, 2, 0, 2); break;
         } else if (P == 4) switch (wave) {
-            case 0: ACS_RUN(0, 5, 0, 5); break;   case 1: ACS_RUN(1, 3, 0, 3); break;   default: ACS_RUN(2, 2, 0, 2); break;
+            case 0: ACS_RUN(0, 5, 0, 5); break;   case 1: ACS_RUN(1, 3, 0, 3); break;   case 2: ACS_RUN(2, 2, 0, 2); break;   default: break;
         } else switch (wave) {
-            case 0: ACS_RUN(0, 3, 0, 3); break;   default: ACS_RUN(1, 2, 0, 2); break;
+            case 0: ACS_RUN(0, 3, 0, 3); break;   case 1: ACS_RUN(1, 2, 0, 2); break;   default: break;
         }
         return;
     }
@@ -522,20 +683,23 @@ __global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 2) void k_auto
     if (wave >= (uint32_t)NT) return;
     const uint32_t t = wave;
     const bool active = inrange && (t < job_class(p, job).ntrials[layer]);
-    const uint32_t q_end = na_max + Cfg::MAXPAD + 8;
+    /* a wave of this form waits for its loads every group of 4 steps: the few-lag layers, whose groups hold little arithmetic
+     * and whose kernel has registers to spare, keep 4 groups of loads in flight */
+    constexpr int D = 1;
+    const uint32_t q_end = na_max + Cfg::MAXPAD + 8 + 4 * D;
     switch (P >> t) {       /* wave-uniform: the trial fixes the number of lags */
-    case 16: if (P >= 16) autocorr_lane<17, L0>(p, layer, cur, q_end, job, t, active); break;
-    case 8:  if (P >= 8)  autocorr_lane<9, L0>(p, layer, cur, q_end, job, t, active); break;
-    case 4:  if (P >= 4)  autocorr_lane<5, L0>(p, layer, cur, q_end, job, t, active); break;
-    case 2:  autocorr_lane<3, L0>(p, layer, cur, q_end, job, t, active); break;
-    default: autocorr_lane<2, L0>(p, layer, cur, q_end, job, t, active); break;
+    case 16: if (P >= 16) autocorr_lane<17, L0, D>(p, layer, cur, q_end, job, t, active); break;
+    case 8:  if (P >= 8)  autocorr_lane<9, L0, D>(p, layer, cur, q_end, job, t, active); break;
+    case 4:  if (P >= 4)  autocorr_lane<5, L0, D>(p, layer, cur, q_end, job, t, active); break;
+    case 2:  autocorr_lane<3, L0, D>(p, layer, cur, q_end, job, t, active); break;
+    default: autocorr_lane<2, L0, D>(p, layer, cur, q_end, job, t, active); break;
     }
 }
 
 template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
-    const uint32_t nrows = (layer == 0) ? p.J / p.R : p.J;
-    const dim3 grid((nrows + 63) / 64);
+    const RowRuns &rr = p.runs[layer == 0 ? 0 : 1];
+    const dim3 grid(rr.blk_begin[rr.n]);
     if (layer == 0) hipLaunchKernelGGL((k_autocorr_lane<P, true>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
     else hipLaunchKernelGGL((k_autocorr_lane<P, false>), grid, dim3(64 * AcsWaves<P>::NW), 0, st, p, layer, cur, na_max);
 }

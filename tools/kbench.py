@@ -11,9 +11,10 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--decode", action="store_true")
 ap.add_argument("--preset", type=int, default=7)
 ap.add_argument("--no-timing", action="store_true")
+ap.add_argument("--tail", type=int, default=0, help="length of a ragged last frame (0: all frames full)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-track = synth_track(a.frames * 10240, 2, 16, 1, dev)
+track = synth_track(a.frames * 10240 - ((10240 - a.tail) if a.tail else 0), 2, 16, 1, dev)
 frames, nsm = frames_from_track(track, 10240)
 ctx = linne_amd.Context(0, scratch_bytes=12 << 30)
 shape = ctx.shape(2, 16, 10240, a.preset, True)
