@@ -34,12 +34,12 @@ MAC_PER_CF_EXECUTED = 30.7e6        # bit-exact de-duplicated schedule this buil
 HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
 FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
-ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19)
+ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
                 5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward)",
                 18: "k_fir_small<P,false,*> (search of the last, short layer)", 15: "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)",
                 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false,true> (forward, jobs with several units)",
-                19: "k_fir2<1,false,false> (forward of the last layer)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
+                19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_fwd_loss<P> (last layer: forward pass + ordered loss)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
                 9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synth_small+k_synth_big (all layers, de-emphasis)", 12: "k_ms_to_lr"}
 
 

@@ -159,7 +159,8 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * 13 block-type statistics (runs on a side stream beside the analysis), 14 autocorrelation of the short layers
  * (kind 3 is the long layer's kernel), 15 / 16 trial residual / forward of layer 0 (int32 input; kinds 5 / 8 are the
  * double-input instantiations used by the other layers; when those layers run without the fused one-unit forward --
- * the last layer, or LINNE_AMD_SPECULATE=0 -- they are different kernels and report as kinds 18 / 19). */
+ * the last layer, or LINNE_AMD_SPECULATE=0 -- they are different kernels and report as kinds 18 / 19), 20 the last layer's
+ * forward pass fused with its loss (k_fwd_loss; replaces 19 + 9 for the frames it takes). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);

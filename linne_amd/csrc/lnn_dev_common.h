@@ -37,6 +37,7 @@ struct RowRuns { uint32_t n; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_be
 
 struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;
+    uint32_t fused_last;                /* the last layer's forward pass and loss come from k_fwd_loss where it takes the job (fwd_loss_takes) */
     RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */
     uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
     double regs[LNN_MAXR];
@@ -57,6 +58,9 @@ struct Plan {
     uint32_t *lunits;                   /* [J][MAXL]                   */
     double *jloss, *jtail;              /* [J]                         */
 };
+
+/* does k_fwd_loss (lnn_k_fwdloss.h) produce this job's last-layer loss?  (na: the job's analysis length) */
+__device__ __forceinline__ bool fwd_loss_takes(const Plan &p, uint32_t layer, uint32_t na) { return p.fused_last && layer + 1 == p.L && (na % (4u * p.P[layer])) == 0; }
 
 /* ------------------------------------------------------------------------------------------------
  * small device helpers

@@ -26,10 +26,13 @@
 
 /* the kernels, in pipeline order */
 #include "lnn_dev_common.h"
+#define LEV_LDS(np_) (sizeof(double) * 64 * (size_t)(2 * (np_) + 3))       /* LDS columns of one Levinson problem set of order np_ */
+#define LEV_LDS_BUDGET ((size_t)160 * 1024)                                   /* LDS of a CU */
 #include "lnn_k_prep.h"
 #include "lnn_k_autocorr.h"
 #include "lnn_k_levinson.h"
 #include "lnn_k_fir.h"
+#include "lnn_k_fwdloss.h"
 #include "lnn_k_finalize.h"
 #include "lnn_k_decode.h"
 #include "lnn_k_rice.h"
@@ -57,6 +60,8 @@ struct LINNEAmdContext {
     /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
     DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_for_encode, sig_valid;
     /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
+    int fwd_loss;                       /* LINNE_AMD_FWD_LOSS (default 1): last layer's forward pass and loss in one kernel (k_fwd_loss) */
+    int lev_ride;                       /* short Levinson trials ride along with the one-unit trial (LINNE_AMD_LEV_RIDE, default 1) */
     const uint32_t *cur_idx;            /* class index per frame of the call being enqueued (host copy, in the meta ring) */
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
@@ -125,8 +130,10 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
                 && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
     }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
+    { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
+    { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : 1; }
     { const char *sp = getenv("LINNE_AMD_FIR_SMALL"); ctx->fir_small = sp ? atoi(sp) : 1; }
-    (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(double) * 64 * (2 * LNN_MAXP + 3)));
+    (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEV_LDS_BUDGET);
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
     return ctx;
@@ -524,6 +531,13 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
         p.pcm = d_pcm + (size_t)f0 * C * S; p.resid = d_residual + (size_t)f0 * C * S;
         p.prm = d_params + (size_t)f0 * C * LINNE_AMD_PARAM_WORDS; p.stats = d_stats + (size_t)f0 * C * LINNE_AMD_STAT_WORDS;
+        /* last layer: forward pass + loss in one kernel for the jobs it takes (fwd_loss_takes); the two-kernel form runs only
+         * when the chunk holds frames it does not take */
+        const uint32_t Plast = hs.P[hs.L - 1];
+        const bool fuse_cfg = ctx->fwd_loss && hs.L > 1 && (Plast == 2u || Plast == 4u || Plast == 8u || Plast == 16u);
+        bool fuse_all = fuse_cfg;
+        for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
+        p.fused_last = fuse_cfg ? 1u : 0u;
         build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount;
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
@@ -548,10 +562,16 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, st);
             }
             { const int sp_ = span_begin(ctx, 4, st);
-              for (uint32_t t = 0, u = 1; u <= maxu; u <<= 1, t++) {             /* one launch per trial: every order on LDS columns */
+              /* one launch per trial, every order on LDS columns -- except that the short trials whose columns fit beside the
+               * one-unit trial's ride along with it on a second wave (k_levinson_lds) */
+              uint32_t ride = LNN_MAXT;
+              for (uint32_t t = 1, u = 2; u <= maxu && ctx->lev_ride; u <<= 1, t++)
+                  if (LEV_LDS(hs.P[l]) + LEV_MAXRIDE * LEV_LDS(hs.P[l] / u) <= LEV_LDS_BUDGET) { ride = t; break; }
+              for (uint32_t t = 0, u = 1; u <= maxu && t < (ride < LNN_MAXT ? ride : LNN_MAXT); u <<= 1, t++) {
                   const uint32_t np = hs.P[l] / u;
-                  const size_t lds = sizeof(double) * 64 * (size_t)(2 * np + 3);
-                  hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(64), lds, st, p, l, t);
+                  const bool carry = (t == 0 && ride < LNN_MAXT);
+                  const size_t lds = LEV_LDS(np) + (carry ? LEV_MAXRIDE * LEV_LDS(hs.P[l] >> ride) : 0);
+                  hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(carry ? 64 * (1 + LEV_MAXRIDE) : 64), lds, st, p, l, t, carry ? ride : (uint32_t)LNN_MAXT);
               }
               span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]); else launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
@@ -559,10 +579,23 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
               hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 16 : (fir_spec ? 8 : 19), st); launch_fir<1>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
+            /* the last layer's output is only ever summed: layers of <= 16 taps do the forward pass and the ordered loss in one
+             * kernel and write nothing else */
+            if (l + 1 == hs.L && fuse_cfg) {
+                const int sp_ = span_begin(ctx, 20, st);
+                const dim3 g(((uint32_t)J + 63) / 64), b(64);
+                switch (hs.P[l]) {
+                case 2: hipLaunchKernelGGL(k_fwd_loss<2>, g, b, 0, st, p, l, cur); break;
+                case 4: hipLaunchKernelGGL(k_fwd_loss<4>, g, b, 0, st, p, l, cur); break;
+                case 8: hipLaunchKernelGGL(k_fwd_loss<8>, g, b, 0, st, p, l, cur); break;
+                default: hipLaunchKernelGGL(k_fwd_loss<16>, g, b, 0, st, p, l, cur); break;
+                }
+                span_end(ctx, sp_, st);
+            }
+            if (!(l + 1 == hs.L && fuse_all)) { const int sp_ = span_begin(ctx, (l == 0) ? 16 : (fir_spec ? 8 : 19), st); launch_fir<1>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
-        { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
+        if (!fuse_all) { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
         { const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st); }
         HIPCHK(ctx, hipGetLastError());
     }

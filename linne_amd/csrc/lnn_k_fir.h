@@ -50,6 +50,7 @@ __global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3
     if (MODE == 1 && spec && p.lunits[(size_t)job * LNN_MAXL + layer] == 1u) return;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
+    if (MODE == 1 && fwd_loss_takes(p, layer, na)) return;         /* the last layer of this job is k_fwd_loss's */
     const uint32_t P = p.P[layer];
     const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;          /* layer 0 reads the pre-emphasised int32 channel (linne_encoder.c:661-663) */
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
         if (myrow < nrows) {
             const uint32_t job = (MODE == 0) ? myrow / LNN_MAXT : myrow;
             const DevClass &c = job_class(p, job);
-            if (MODE == 1 || ((myrow % LNN_MAXT) < c.ntrials[layer] && p.uncertain[job])) {
+            if ((MODE == 1 && !fwd_loss_takes(p, p.L - 1u, c.na)) || (MODE == 0 && (myrow % LNN_MAXT) < c.ntrials[layer] && p.uncertain[job])) {
                 my_na = c.na;
                 my_ptr = p.sig + ((size_t)job * 2 + cur) * p.S;
             }

@@ -7,11 +7,9 @@
  * consecutive jobs, each lane running the scalar recursion of `levinson` above on its own column of two LDS arrays
  * (a[i][lane], r[i][lane]: conflict-free 8-byte accesses).  Every wave instruction therefore advances 64 problems; the
  * ordered sum a[0]r[k+1] + ... + a[k]r[1] (lpc.c:295-297) is one chain per lane.  grid = (job groups, units of the trial). */
-__global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uint32_t t)
+__device__ __forceinline__ void levinson_problem(const Plan &p, uint32_t layer, uint32_t t, uint32_t unit, double *lev_lds, uint32_t lane, uint32_t job0)
 {
-    extern __shared__ __attribute__((aligned(16))) double lev_lds[];
-    const uint32_t lane = threadIdx.x, unit = blockIdx.y;
-    uint32_t job = blockIdx.x * 64 + lane;
+    uint32_t job = job0 + lane;
     const bool inrange = job < p.J;
     if (!inrange) job = p.J - 1;
     const DevClass &c = job_class(p, job);
@@ -81,7 +79,7 @@ __global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uin
             if (last && k == P0) { tail = -gamma; tail_set = 1; }
         }
     }
-    if (!have) return;
+    if (!have) return;                                         /* (lanes of a wave only: the caller's loops are wave-uniform) */
     if (zero) {
         for (uint32_t k = 0; k < np; k++) h[k] = 0.0;
         tail = 0.0; tail_set = (np >= P0) ? 1 : 0;             /* zero branches write parcor[0..order] */
@@ -95,5 +93,24 @@ __global__ __launch_bounds__(64) void k_levinson_lds(Plan p, uint32_t layer, uin
     }
 }
 
+/* grid = (job groups, units of trial t).  Wave 0 of a block solves problem (t, blockIdx.y).  A block may carry riding waves
+ * (blockDim 64 * (1 + nride), `ride` < LNN_MAXT): together they solve every problem of the trials ride, ride+1, ... of the
+ * same 64 jobs, dealt out in turn, one after the other in each wave's own LDS columns behind wave 0's.  The long layer's
+ * one-unit trial holds 130 KB of LDS -- one wave per CU, on one of its four SIMDs -- so the many tiny problems of its short
+ * trials (latency, not arithmetic) ride along on the other three instead of taking launches of their own. */
+#define LEV_MAXRIDE 3
+__global__ __launch_bounds__(64 * (1 + LEV_MAXRIDE)) void k_levinson_lds(Plan p, uint32_t layer, uint32_t t, uint32_t ride)
+{
+    extern __shared__ __attribute__((aligned(16))) double lev_lds[];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, job0 = blockIdx.x * 64;
+    if (wave == 0) { levinson_problem(p, layer, t, blockIdx.y, lev_lds, lane, job0); return; }
+    const uint32_t nride = (blockDim.x >> 6) - 1u;
+    double *mine = lev_lds + (size_t)(2 * (p.P[layer] >> t) + 3) * 64 + (size_t)(wave - 1u) * (2 * (p.P[layer] >> ride) + 3) * 64;
+    const uint32_t maxu = p.P[layer] < (uint32_t)LNN_MAXU ? p.P[layer] : (uint32_t)LNN_MAXU;
+    uint32_t q = 0;
+    for (uint32_t tt = ride, u = 1u << ride; u <= maxu; tt++, u <<= 1)
+        for (uint32_t unit = 0; unit < u; unit++, q++)
+            if (q % nride == wave - 1u) levinson_problem(p, layer, tt, unit, mine, lane, job0);
+}
 
 #endif

@@ -392,3 +392,24 @@ def test_layer0_autocorrelation_forms_agree(product, oracle, monkeypatch, produc
     monkeypatch.setenv("LINNE_AMD_L0_PRODUCTS", products)
     x = music(2, 5 * 4096 + 1234, 16, seed=61 + preset)
     assert product.encode_whole(x, 16, 44100, 4096, preset, True) == oracle.encode_whole(x, 16, 44100, 4096, preset, True)
+
+
+@pytest.mark.parametrize("fwd_loss,lev_ride", [("0", "1"), ("1", "0"), ("1", "1")])
+@pytest.mark.parametrize("preset", [3, 7])
+def test_last_layer_loss_kernel_and_riding_levinson_trials(product, oracle, monkeypatch, fwd_loss, lev_ride, preset):
+    """the last layer's forward pass + ordered loss come from one kernel (k_fwd_loss) for frames whose unit lengths are all
+    multiples of 4 and from k_fir2<1> + k_chain_sum otherwise (LINNE_AMD_FWD_LOSS=0: always the latter); the short Levinson
+    trials ride along with the one-unit trial's launch (LINNE_AMD_LEV_RIDE=0: a launch per trial).  Same bytes as the oracle
+    every way -- on music, on a signal that makes the last layer choose several units, and with a tail frame the fused
+    kernel does not take (so one call runs both forms side by side)"""
+    monkeypatch.setenv("LINNE_AMD_FWD_LOSS", fwd_loss)
+    monkeypatch.setenv("LINNE_AMD_LEV_RIDE", lev_ride)
+    block = 4096
+    rng = np.random.default_rng(17)
+    t = np.arange(2 * block)
+    burst = (6000 * np.sin(2 * np.pi * t * (0.02 + 0.15 * (t // 256 % 2))) * (t // 128 % 2) + rng.integers(-40, 40, size=2 * block)).astype(np.int32)
+    x = np.concatenate([music(2, 2 * block, 16, seed=71 + preset), np.stack([burst, burst[::-1] // 3]), music(2, 1234, 16, seed=5)], axis=1)
+    mine = product.encode_whole(x, 16, 44100, block, preset, True)
+    assert mine == oracle.encode_whole(x, 16, 44100, block, preset, True)
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
