@@ -37,6 +37,7 @@ struct RowRuns { uint32_t n; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_be
 
 struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;
+    uint32_t rows16;                    /* order-16 layers take the register-ring autocorrelation form (LINNE_AMD_ROWS16, default 1) */
     uint32_t fused_last;                /* the last layer's forward pass and loss come from k_fwd_loss where it takes the job (fwd_loss_takes) */
     RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */
     uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];

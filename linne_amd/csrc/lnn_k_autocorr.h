@@ -494,7 +494,7 @@ __device__ __forceinline__ void autocorr_rows(const Plan &p, uint32_t layer, uin
 {
     constexpr int NT = AcCfg<P>::NT, T = 32, NLD = L0 ? 8 : 16, PT = P >> TT;      /* PT: order of my trial = ring length (divides 4) */
     constexpr int NSLOT = (NLD + NW - 1) / NW;
-    static_assert(P <= 4 && J0 + JN <= PT + 1, "register rings are laid out for groups of 4 samples");
+    static_assert(P <= 16 && J0 + JN <= PT + 1 && T % 16 == 0, "register rings: sample m lives in slot m % PT, and the tile loop is unrolled over T samples");
     typedef typename std::conditional<L0, int4, lnn_d2>::type XV;
     const uint32_t ntiles = na / T, seg = na >> (NT - 1), nt = na >> TT;
     uint32_t myrow = row0 + lane; if (myrow >= nrows) myrow = nrows - 1;
@@ -581,8 +581,8 @@ __device__ __forceinline__ void autocorr_rows(const Plan &p, uint32_t layer, uin
                 for (int j = 0; j < JN; j++) r[j] += q[j];          /* adds of the previous sample's products */
                 const double v = vcur;
 #pragma unroll
-                for (int j = 0; j < JN; j++) q[j] = (J0 + j == 0) ? (v * v) : (ring[((i - (J0 + j)) % PT + PT) % PT] * v);
-                ring[i % PT] = v;
+                for (int j = 0; j < JN; j++) q[j] = (J0 + j == 0) ? (v * v) : (ring[((4 * g + i - (J0 + j)) % PT + PT) % PT] * v);
+                ring[(4 * g + i) % PT] = v;
                 vcur = (i < 3) ? (xv[(i + 1) & 3] * wv[(i + 1) & 3]) : (nx[0] * nw[0]);          /* window the next one */
             }
 #pragma unroll
@@ -619,13 +619,14 @@ template <> struct AcsWaves<8>  { static constexpr int NW = 5; };
 template <> struct AcsWaves<4>  { static constexpr int NW = 10; };
 template <> struct AcsWaves<2>  { static constexpr int NW = 5; };
 
+#define ACS_ROWS(P_) ((P_) <= 4 || p.rows16)      /* LINNE_AMD_ROWS16=0: orders 8 and 16 keep the shared-tile form */
 template <int P, bool L0>
 __global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 5) void k_autocorr_lane(Plan p, uint32_t layer, uint32_t cur, uint32_t na_max)
 {
     using Cfg = AcCfg<P>;
     constexpr int NT = Cfg::NT, NW = AcsWaves<P>::NW;
     __shared__ double tile[2][ACS_T][65];
-    __shared__ __attribute__((aligned(16))) double wts_mem[(P <= 4) ? 2 * NT * 32 : 2];     /* autocorr_rows: the weights of two tiles, every trial */
+    __shared__ __attribute__((aligned(16))) double wts_mem[2 * NT * 32];     /* autocorr_rows: the weights of two tiles, every trial */
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t rstride = L0 ? p.R : 1u;
     /* my block of 64 rows of one class run (RowRuns); the blocks are taken in reverse so that a ragged last frame, whose
@@ -647,17 +648,23 @@ __global__ __launch_bounds__(64 * AcsWaves<P>::NW, (P >= 8) ? 4 : 5) void k_auto
     constexpr int NWS = (P == 4) ? 3 : (P == 2) ? 2 : NW;     /* waves of the shared-tile form (orders <= 4 run it only when autocorr_rows cannot) */
 #define ACS_RUN(T_, K_, J0_, JN_) autocorr_shared<K_, J0_, JN_, L0, NWS>(p, layer, cur, row0, nrows, rstride, na, \
         (uint32_t)__builtin_amdgcn_readfirstlane((int)c0.wt_off[layer][T_]), T_, wave, lane, tile)
-    if constexpr (P <= 4) {
-        if (fast && (na >> (NT - 1)) >= 32u && (p.S & 3u) == 0) {    /* one lag per wave */
+    if constexpr (P <= 16) {
+        if (fast && (na >> (NT - 1)) >= 32u && (p.S & 3u) == 0 && ACS_ROWS(P)) {
             double (*wtile)[32] = (double (*)[32])wts_mem;
-#define ROWS_RUN(T_, J0_) autocorr_rows<P, L0, T_, J0_, 1, NW>(p, layer, cur, row0, nrows, rstride, na, c0, wave, lane, tile, wtile)
-            if constexpr (P == 4) switch (wave) {
-                case 0: ROWS_RUN(0, 0); break; case 1: ROWS_RUN(0, 1); break; case 2: ROWS_RUN(0, 2); break; case 3: ROWS_RUN(0, 3); break;
-                case 4: ROWS_RUN(0, 4); break; case 5: ROWS_RUN(1, 0); break; case 6: ROWS_RUN(1, 1); break; case 7: ROWS_RUN(1, 2); break;
-                case 8: ROWS_RUN(2, 0); break; default: ROWS_RUN(2, 1); break;
+#define ROWS_RUN(T_, J0_, JN_) autocorr_rows<P, L0, T_, J0_, JN_, NW>(p, layer, cur, row0, nrows, rstride, na, c0, wave, lane, tile, wtile)
+            if constexpr (P == 16) switch (wave) {              /* as in the shared-tile form: waves w and w+4 share a SIMD */
+                case 0: ROWS_RUN(0, 10, 7); break; case 1: ROWS_RUN(0, 0, 5); break; case 2: ROWS_RUN(0, 5, 5); break; case 3: ROWS_RUN(1, 0, 5); break;
+                case 4: ROWS_RUN(4, 0, 2); break;  case 5: ROWS_RUN(1, 5, 4); break; case 6: ROWS_RUN(2, 0, 5); break; default: ROWS_RUN(3, 0, 3); break;
+            } else if constexpr (P == 8) switch (wave) {
+                case 0: ROWS_RUN(0, 0, 5); break; case 1: ROWS_RUN(0, 5, 4); break; case 2: ROWS_RUN(1, 0, 5); break; case 3: ROWS_RUN(2, 0, 3); break;
+                default: ROWS_RUN(3, 0, 2); break;
+            } else if constexpr (P == 4) switch (wave) {        /* few rows (channel-frames), few lags: one lag per wave keeps more SIMDs busy */
+                case 0: ROWS_RUN(0, 0, 1); break; case 1: ROWS_RUN(0, 1, 1); break; case 2: ROWS_RUN(0, 2, 1); break; case 3: ROWS_RUN(0, 3, 1); break;
+                case 4: ROWS_RUN(0, 4, 1); break; case 5: ROWS_RUN(1, 0, 1); break; case 6: ROWS_RUN(1, 1, 1); break; case 7: ROWS_RUN(1, 2, 1); break;
+                case 8: ROWS_RUN(2, 0, 1); break; default: ROWS_RUN(2, 1, 1); break;
             } else switch (wave) {
-                case 0: ROWS_RUN(0, 0); break; case 1: ROWS_RUN(0, 1); break; case 2: ROWS_RUN(0, 2); break;
-                case 3: ROWS_RUN(1, 0); break; default: ROWS_RUN(1, 1); break;
+                case 0: ROWS_RUN(0, 0, 1); break; case 1: ROWS_RUN(0, 1, 1); break; case 2: ROWS_RUN(0, 2, 1); break;
+                case 3: ROWS_RUN(1, 0, 1); break; default: ROWS_RUN(1, 1, 1); break;
             }
 #undef ROWS_RUN
             return;

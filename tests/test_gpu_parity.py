@@ -413,3 +413,17 @@ def test_last_layer_loss_kernel_and_riding_levinson_trials(product, oracle, monk
     assert mine == oracle.encode_whole(x, 16, 44100, block, preset, True)
     ret, dec = product.decode_whole(mine)
     assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("rows16", ["0", "1"])
+@pytest.mark.parametrize("preset", [3, 7])
+def test_short_layer_autocorrelation_forms_agree(product, oracle, monkeypatch, rows16, preset):
+    """the lags of the order-8 / order-16 layers come from the register-ring form (autocorr_rows) when every unit length of
+    the frame is a multiple of 4, from the shared-tile form with LINNE_AMD_ROWS16=0, and from the per-lane form for the
+    ragged tail here: same bytes as the oracle either way (LINNE_AMD_L0_PRODUCTS=0 keeps the small batch off the product
+    kernel so that these forms run at all)"""
+    monkeypatch.setenv("LINNE_AMD_ROWS16", rows16)
+    monkeypatch.setenv("LINNE_AMD_L0_PRODUCTS", "0")
+    x = music(2, 6 * 4096 + 777, 16, seed=83 + preset)
+    mine = product.encode_whole(x, 16, 44100, 4096, preset, True)
+    assert mine == oracle.encode_whole(x, 16, 44100, 4096, preset, True)
