@@ -160,7 +160,9 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * (kind 3 is the long layer's kernel), 15 / 16 trial residual / forward of layer 0 (int32 input; kinds 5 / 8 are the
  * double-input instantiations used by the other layers; when those layers run without the fused one-unit forward --
  * the last layer, or LINNE_AMD_SPECULATE=0 -- they are different kernels and report as kinds 18 / 19), 20 the last layer's
- * forward pass fused with its loss (k_fwd_loss; replaces 19 + 9 for the frames it takes). */
+ * forward pass fused with its loss (k_fwd_loss; replaces 19 + 9 for the frames it takes), 21 / 22 / 23 the long layer's
+ * autocorrelation with lanes = jobs (k_autocorr_hist for the trials of order P and P/2, k_autocorr_sub for the shorter ones;
+ * replace 3 for the frames they take). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);

@@ -37,6 +37,7 @@ struct RowRuns { uint32_t n; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_be
 
 struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;
+    uint32_t hist;                      /* the long layer's lags come from k_autocorr_hist / k_autocorr_sub where they take the frame (LINNE_AMD_HIST, default 1) */
     uint32_t rows16;                    /* order-16 layers take the register-ring autocorrelation form (LINNE_AMD_ROWS16, default 1) */
     uint32_t fused_last;                /* the last layer's forward pass and loss come from k_fwd_loss where it takes the job (fwd_loss_takes) */
     RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */
@@ -62,6 +63,16 @@ struct Plan {
 
 /* does k_fwd_loss (lnn_k_fwdloss.h) produce this job's last-layer loss?  (na: the job's analysis length) */
 __device__ __forceinline__ bool fwd_loss_takes(const Plan &p, uint32_t layer, uint32_t na) { return p.fused_last && layer + 1 == p.L && (na % (4u * p.P[layer])) == 0; }
+
+/* Which frames k_autocorr_hist / k_autocorr_sub (lnn_k_autocorr_hist.h) take (the others stay with k_autocorr2, which skips
+ * the ones taken there): every trial present,
+ * every unit a whole number of 16-sample tiles, the finest unit at least one weight tile long, rows 16-byte aligned. */
+__device__ __forceinline__ bool hist_takes(const Plan &p, uint32_t layer, const DevClass &c)
+{
+    const uint32_t P = p.P[layer];
+    uint32_t nt = 0; for (uint32_t u = 1; u <= P && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
+    return p.hist && P >= 64u && c.ntrials[layer] == nt && (c.na % (16u << (nt - 1))) == 0 && (c.na >> (nt - 1)) >= 32u && (p.S & 3u) == 0;
+}
 
 /* ------------------------------------------------------------------------------------------------
  * small device helpers

@@ -56,6 +56,7 @@ struct LINNEAmdContext {
      * layers, Levinson, ordered sums) overlap the throughput-bound phases of another */
     hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub;
     hipStream_t side; hipEvent_t side_done; int has_side;     /* block-type statistics run beside the analysis */
+    hipEvent_t fork_ev, join_ev;        /* side stream: the general autocorrelation kernel for the few frames the lanes = jobs kernels do not take */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
     /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
     DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_for_encode, sig_valid;
@@ -127,7 +128,9 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
         }
         if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) ctx->nsub = 0;
         ctx->has_side = (ctx->nsub > 0) && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess
-                && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess;
+                && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess
+                && hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) == hipSuccess
+                && hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming) == hipSuccess;
     }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
@@ -149,7 +152,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_ucount) hipFree(ctx->d_ucount);
     for (int i = 0; i < ctx->nsub; i++) { hipStreamSynchronize(ctx->sub[i]); hipStreamDestroy(ctx->sub[i]); hipEventDestroy(ctx->sub_done[i]); }
     if (ctx->nsub) hipEventDestroy(ctx->ev_start);
-    if (ctx->has_side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); hipEventDestroy(ctx->side_done); }
+    if (ctx->has_side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); hipEventDestroy(ctx->side_done); hipEventDestroy(ctx->fork_ev); hipEventDestroy(ctx->join_ev); }
     if (ctx->d_sin) hipFree(ctx->d_sin);
     if (ctx->d_wt) hipFree(ctx->d_wt);
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
@@ -539,6 +542,16 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
         p.fused_last = fuse_cfg ? 1u : 0u;
         { const char *e_ = getenv("LINNE_AMD_ROWS16"); p.rows16 = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
+        { const char *e_ = getenv("LINNE_AMD_HIST"); p.hist = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
+        bool hist_all[LNN_MAXL];                                /* per layer: every frame of the chunk is k_autocorr_hist's (host copy of hist_takes) */
+        for (uint32_t l = 0; l < hs.L; l++) {
+            uint32_t nt = 0; for (uint32_t u = 1; u <= hs.P[l] && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
+            hist_all[l] = p.hist && hs.P[l] >= 64u && (S & 3u) == 0;
+            for (uint32_t f = f0; f < f0 + Fc && hist_all[l]; f++) {
+                const DevClass &c = ctx->sig_cls[ctx->cur_idx[f]];
+                if (!(c.ntrials[l] == nt && (c.na % (16u << (nt - 1))) == 0 && (c.na >> (nt - 1)) >= 32u)) hist_all[l] = false;
+            }
+        }
         build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount;
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
@@ -560,7 +573,25 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             /* the first two layers nearly always keep one unit: their search pass also writes that trial's forward output */
             const uint32_t fir_spec = (ctx->fir_spec && l + 1 < hs.L) ? 1u : 0u;
             {
-                const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, st);
+                const bool hist_layer = p.hist && hs.P[l] >= 64u;
+                /* the general kernels serve what the lanes = jobs kernels do not take -- usually one ragged frame, a launch that is
+                 * all latency: it runs beside them on the side stream */
+                const bool beside = hist_layer && !hist_all[l] && ctx->has_side && use_sub;
+                if (beside) {
+                    HIPCHK(ctx, hipEventRecord(ctx->fork_ev, st)); HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_ev, 0));
+                    const int sp_ = span_begin(ctx, 3, ctx->side); dispatch_autocorr2(ctx->side, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, ctx->side);
+                    HIPCHK(ctx, hipEventRecord(ctx->join_ev, ctx->side));
+                }
+                if (hist_layer) {                               /* long layer: lanes = jobs kernels for the frames they take (hist_takes) */
+                    for (int w = 0; w < 3; w++) {
+                        if (hs.P[l] == 64u && w == 1) continue;
+                        const int sp_ = span_begin(ctx, 21 + w, st); (void)launch_autocorr_hist(st, p, l, cur, w); span_end(ctx, sp_, st);
+                    }
+                }
+                if (beside) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->join_ev, 0));
+                else if (!hist_all[l]) {
+                    const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, st);
+                }
             }
             { const int sp_ = span_begin(ctx, 4, st);
               /* one launch per trial, every order on LDS columns -- except that the short trials whose columns fit beside the

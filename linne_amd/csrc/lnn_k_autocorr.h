@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
             a_job = blockIdx.x * Cfg::JPW + jl;
             if (a_job < p.J) {
                 const DevClass &c = job_class(p, a_job);
-                if (t < c.ntrials[layer]) {
+                if (t < c.ntrials[layer] && !hist_takes(p, layer, c)) {
                     active = true;
                     a_t = t; a_lag0 = rem * K; a_u = 1u << t; a_p = P >> t;
                     const uint32_t n = c.na / a_u;
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
             const uint32_t job = blockIdx.x * Cfg::JPW + jl;
             if (job < p.J) {
                 const DevClass &c = job_class(p, job);
-                if (t < c.ntrials[layer]) {
+                if (t < c.ntrials[layer] && !hist_takes(p, layer, c)) {
                     gen = true;
                     g_u = 1u << t; g_n = c.na / g_u;
                     const uint32_t pp = P >> t;
@@ -109,6 +109,8 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
             }
         }
     }
+
+    if (__all(!active && !gen)) return;             /* every job of the wave is k_autocorr_hist's (or beyond the batch) */
 
     /* Fast generator: when every stream of the wave has unit and padded-unit lengths that are multiples of 4 (always for
      * frame lengths that are multiples of 4 * 128), a generator lane produces 4 consecutive stream positions at a time --
@@ -494,7 +496,7 @@ __device__ __forceinline__ void autocorr_rows(const Plan &p, uint32_t layer, uin
 {
     constexpr int NT = AcCfg<P>::NT, T = 32, NLD = L0 ? 8 : 16, PT = P >> TT;      /* PT: order of my trial = ring length (divides 4) */
     constexpr int NSLOT = (NLD + NW - 1) / NW;
-    static_assert(P <= 16 && J0 + JN <= PT + 1 && T % 16 == 0, "register rings: sample m lives in slot m % PT, and the tile loop is unrolled over T samples");
+    static_assert(PT <= 32 && T % PT == 0 && J0 + JN <= PT + 1, "register rings: sample m lives in slot m % PT, and the tile loop is unrolled over T samples");
     typedef typename std::conditional<L0, int4, lnn_d2>::type XV;
     const uint32_t ntiles = na / T, seg = na >> (NT - 1), nt = na >> TT;
     uint32_t myrow = row0 + lane; if (myrow >= nrows) myrow = nrows - 1;
@@ -800,6 +802,29 @@ template <int P> static void launch_autocorr2(hipStream_t st, const Plan &p, uin
     if (layer == 0) hipLaunchKernelGGL((k_autocorr2<P, true>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
     else hipLaunchKernelGGL((k_autocorr2<P, false>), dim3(blocks), dim3(64), 0, st, p, layer, cur, na_max);
 }
+#include "lnn_k_autocorr_hist.h"
+
+/* the long layer's lanes = jobs kernels, for the frames they take (hist_takes); which: 0 / 1 the trials of order P and P/2
+ * (k_autocorr_hist), 2 the shorter ones (k_autocorr_sub).  Returns false when the layer has no such kernel. */
+static bool launch_autocorr_hist(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, int which)
+{
+    const RowRuns &rr = p.runs[1];
+    const dim3 grid(rr.blk_begin[rr.n]);
+    if (p.P[layer] == 128u) {
+        if (which == 0) hipLaunchKernelGGL((k_autocorr_hist<128, 0>), grid, dim3(64 * HIST_WAVES(128)), 0, st, p, layer, cur);
+        else if (which == 1) hipLaunchKernelGGL((k_autocorr_hist<128, 1>), grid, dim3(64 * HIST_WAVES(64)), 0, st, p, layer, cur);
+        else hipLaunchKernelGGL((k_autocorr_sub<128>), grid, dim3(640), 0, st, p, layer, cur);
+        return true;
+    }
+    if (p.P[layer] == 64u) {
+        if (which == 0) hipLaunchKernelGGL((k_autocorr_hist<64, 0>), grid, dim3(64 * HIST_WAVES(64)), 0, st, p, layer, cur);
+        else if (which == 2) hipLaunchKernelGGL((k_autocorr_sub<64>), grid, dim3(640), 0, st, p, layer, cur);
+        else return false;
+        return true;
+    }
+    return false;
+}
+
 static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max, bool prod_ok)
 {
     /* the product form has a short dependent chain but few busy lanes: it wins while the batch is too small to fill the chip

@@ -427,3 +427,15 @@ def test_short_layer_autocorrelation_forms_agree(product, oracle, monkeypatch, r
     x = music(2, 6 * 4096 + 777, 16, seed=83 + preset)
     mine = product.encode_whole(x, 16, 44100, 4096, preset, True)
     assert mine == oracle.encode_whole(x, 16, 44100, 4096, preset, True)
+
+
+@pytest.mark.parametrize("hist", ["0", "1"])
+@pytest.mark.parametrize("preset,block", [(3, 4096), (7, 4096), (7, 2048)])
+def test_long_layer_autocorrelation_forms_agree(product, oracle, monkeypatch, hist, preset, block):
+    """the lags of the order-64 / order-128 layer come from the lanes = jobs kernels (k_autocorr_hist, k_autocorr_sub) for the
+    frames whose units are whole 16-sample tiles, from k_autocorr2 otherwise (ragged tail; 2048-sample blocks, whose finest
+    unit is too short; LINNE_AMD_HIST=0: always) -- one call here runs both side by side: same bytes as the oracle"""
+    monkeypatch.setenv("LINNE_AMD_HIST", hist)
+    x = music(2, 5 * block + 1001, 16, seed=91 + preset)
+    mine = product.encode_whole(x, 16, 44100, block, preset, True)
+    assert mine == oracle.encode_whole(x, 16, 44100, block, preset, True)
