@@ -54,6 +54,7 @@ struct Plan {
     double *tloss;                      /* [J][MAXT] exact mean |residual| (ordered chain)            */
     double *tsum;                       /* [J][MAXT][npart] per-wave partial sums of |residual| (certified search) */
     uint32_t npart;                     /* partial sums per (job, trial): tiles x waves per block      */
+    double *txmax;                      /* [J][npart] per-wave max |input| of the layer (search_slack in k_select)               */
     uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
     uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
     double *lparams;                    /* [J][MAXL][MAXP]             */

@@ -16,11 +16,12 @@
  * position and wave. */
 /* lags per wave (measured): order 128 -- 11 (12 waves, one block per CU); order 64 -- 9 (8 waves, two blocks per CU) */
 #define HIST_LPW(PT_) ((PT_) >= 128 ? 11 : 9)
+#define HIST_TILE(PT_) 16                                    /* positions per tile (a multiple of 16; 32 was measured: far slower for order 128) */
 #define HIST_WAVES(PT_) (((PT_) + HIST_LPW(PT_)) / HIST_LPW(PT_))
 template <int P, int TT>
 __global__ __launch_bounds__(64 * HIST_WAVES(P >> TT), ((P >> TT) >= 128) ? 3 : 4) void k_autocorr_hist(Plan p, uint32_t layer, uint32_t cur)
 {
-    constexpr int PT = P >> TT, NLAG = PT + 1, LPW = HIST_LPW(PT), NW = HIST_WAVES(PT), T = 16, D = PT + 2 * T, NLD = 8;
+    constexpr int PT = P >> TT, NLAG = PT + 1, LPW = HIST_LPW(PT), NW = HIST_WAVES(PT), T = HIST_TILE(PT), D = PT + 2 * T, NLD = T / 2, RPI = 128 / T;   /* RPI: rows per load instruction */
     constexpr int NSLOT = (NLD + NW - 1) / NW;                /* tile load instructions per wave */
     static_assert(LPW <= 16, "a wave's lags come from a 16-deep register ring");
     static_assert(PT % T == 0 && D % T == 0, "tiles must not straddle a unit's end or the ring's end");
@@ -44,13 +45,13 @@ __global__ __launch_bounds__(64 * HIST_WAVES(P >> TT), ((P >> TT) >= 128) ? 3 : 
     double *out = p.acorr + ((size_t)myrow * LNN_MAXT + TT) * LNN_ACW + J0;
     /* zero the ring: the stream before position 0 */
     for (uint32_t i = threadIdx.x; i < (uint32_t)(D + T) * 65u; i += blockDim.x) (&ring_lds[0][0])[i] = 0.0;
-    /* tile loads: instruction k covers rows 8k + lane/8, positions 2(lane%8)..+1; wave w issues the instructions w, w + NW, ... */
-    const uint32_t lrow = lane >> 3, lsmp = 2u * (lane & 7u);
+    /* tile loads: instruction k covers rows RPI k + lane/(T/2), positions 2(lane%(T/2))..+1; wave w issues the instructions w, w + NW, ... */
+    const uint32_t lrow = lane / (uint32_t)(T / 2), lsmp = 2u * (lane % (uint32_t)(T / 2));
     const double *src[NSLOT];
 #pragma unroll
     for (int i = 0; i < NSLOT; i++) {
         const uint32_t k = wave + (uint32_t)i * NW;
-        uint32_t lr = row0 + 8u * (k < (uint32_t)NLD ? k : 0u) + lrow; if (lr >= nrows) lr = nrows - 1;
+        uint32_t lr = row0 + (uint32_t)RPI * (k < (uint32_t)NLD ? k : 0u) + lrow; if (lr >= nrows) lr = nrows - 1;
         src[i] = p.sig + ((size_t)lr * 2 + cur) * p.S + lsmp;
     }
     /* the tile being fetched: place in the padded stream */
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(64 * HIST_WAVES(P >> TT), ((P >> TT) >= 128) ? 3 : 
         for (int i = 0; i < NSLOT; i++) {
             const uint32_t k = wave + (uint32_t)i * NW;
             if (k < (uint32_t)NLD) {
-                const uint32_t r = 8u * k + lrow;
+                const uint32_t r = (uint32_t)RPI * k + lrow;
                 ring_lds[slot0 + lsmp][r] = pre[i].x; ring_lds[slot0 + lsmp + 1][r] = pre[i].y;
                 if (slot0 == 0) { ring_lds[D + lsmp][r] = pre[i].x; ring_lds[D + lsmp + 1][r] = pre[i].y; }
             }

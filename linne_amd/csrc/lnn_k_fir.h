@@ -32,11 +32,22 @@ __device__ __forceinline__ double wave_sum_f64_lane63(double v)
     return v;
 }
 
+__device__ __forceinline__ double wave_max_f64_lane63(double v)     /* max of non-negative values over the wavefront, in lane 63 (lanes read 0.0 where a row has no source) */
+{
+#define LNN_DPP_MAX(CTRL, ROWMASK) { \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWMASK, 0xf, true); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWMASK, 0xf, true); \
+        v = fmax(v, __hiloint2double(hi_, lo_)); }
+    LNN_DPP_MAX(0x111, 0xf) LNN_DPP_MAX(0x112, 0xf) LNN_DPP_MAX(0x114, 0xf) LNN_DPP_MAX(0x118, 0xf) LNN_DPP_MAX(0x142, 0xa) LNN_DPP_MAX(0x143, 0xc)
+#undef LNN_DPP_MAX
+    return v;
+}
+
 #define FIR_THREADS 256
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
 template <int MODE, bool L0, bool SPEC>
-__global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3 : 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
+__global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
     constexpr uint32_t spec = SPEC ? 1u : 0u;        /* MODE 2: also write the one-unit trial's forward output; MODE 1: skip the jobs it covered */
     __shared__ __attribute__((aligned(16))) double xs[LNN_MAXP + FIR_TILE + 8];
@@ -124,7 +135,7 @@ __global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3
 #pragma unroll
                 for (int j = 0; j < 12; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + j); w[j] = v.x; w[j + 1] = v.y; }
 #pragma unroll
-                for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE != 1) ? xc[j] : 0.0;
+                for (int j = 0; j < FIR_SPL; j++) acc[j] = (MODE != 1 && !dual) ? xc[j] : 0.0;     /* dual: the forward pass's chain (from 0.0) serves both */
                 lnn_d2 ha0 = *(const lnn_d2 *)(hb), ha1 = *(const lnn_d2 *)(hb + 2), hb0, hb1;
                 uint32_t k = 0;
 #define FIR_STEP(G, HC0, HC1, HN0, HN1) { \
@@ -135,27 +146,21 @@ __global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3
                     _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
                         _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) acc[j] += hh_[kk] * w[(4 * G + kk + j) % 16]; } \
                     k += 4; }
-#define FIR_STEP2(G, HC0, HC1, HN0, HN1) { \
-                    const lnn_d2 na_ = *(const lnn_d2 *)(xw + k + 12), nb_ = *(const lnn_d2 *)(xw + k + 14); \
-                    HN0 = *(const lnn_d2 *)(hb + k + 4); HN1 = *(const lnn_d2 *)(hb + k + 6); \
-                    w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y; \
-                    const double hh_[4] = { HC0.x, HC0.y, HC1.x, HC1.y }; \
-                    _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
-                        _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) { const double pr_ = hh_[kk] * w[(4 * G + kk + j) % 16]; acc[j] += pr_; acc2[j] += pr_; } } \
-                    k += 4; }
-                if (dual) for (;;) {                                 /* one product, two chains: residual (starts at x) and prediction (starts at 0) */
-                    FIR_STEP2(0, ha0, ha1, hb0, hb1); if (k >= np) break;
-                    FIR_STEP2(1, hb0, hb1, ha0, ha1); if (k >= np) break;
-                    FIR_STEP2(2, ha0, ha1, hb0, hb1); if (k >= np) break;
-                    FIR_STEP2(3, hb0, hb1, ha0, ha1); if (k >= np) break;
-                } else for (;;) {
+                for (;;) {
                     FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
                     FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
                     FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
                     FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
                 }
+                if (dual) {
+                    /* One chain for two results: acc is the forward pass's predict sum (linne_network.c:165-210), x + predict its
+                     * output -- and |x + predict| stands in for the search's |((x + p0) + p1) + ...| (linne_network.c:318-335).
+                     * The two differ by rounding only, within 2 gamma_(np+1) (|x| + sum |h_k x_k|) per sample; k_select widens
+                     * this trial's interval by that bound (search_slack) before it certifies the argmin. */
+#pragma unroll
+                    for (int j = 0; j < FIR_SPL; j++) { acc2[j] = acc[j]; acc[j] = xc[j] + acc[j]; }
+                }
 #undef FIR_STEP
-#undef FIR_STEP2
             } else if (whole && np <= 2) {
                 const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - (uint32_t)(__ffs((int)u) - 1))) : (s / n);
                 const double *hb = hbuf + (size_t)my_unit * np;
@@ -209,6 +214,15 @@ __global__ __launch_bounds__(FIR_THREADS, ((SPEC && MODE == 2) || MODE == 0) ? 3
             }
             ps = wave_sum_f64_lane63(ps);
             if ((tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
+            if (SPEC && t == 0) {                                    /* max |x| of the wave's samples, for search_slack */
+                double mx = 0.0;
+                if (s < na) {
+#pragma unroll
+                    for (int j = 0; j < FIR_SPL; j++) if (s + j < na) mx = fmax(mx, fabs(xc[j]));
+                }
+                mx = wave_max_f64_lane63(mx);
+                if ((tid & 63u) == 63u) p.txmax[(size_t)job * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = mx;
+            }
         } else if (MODE == 0) {
             /* exact path: the tile's |residual| values go to LDS in sample order and ONE lane adds them to the trial's
              * running sum, continuing the single chain of linne_network.c:326-337 across tiles */
@@ -284,11 +298,18 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
                 for (int k = 0; k < np; k++) h[k] = hb[k];
 #pragma unroll
                 for (int j = 0; j < FIR_SPL; j++) {
-                    double acc = wv[HP + j], acc2 = 0.0;
+                    if (SPEC && t == 0) {                           /* one chain for two results, as in k_fir2's dual form (search_slack) */
+                        double acc2 = 0.0;
 #pragma unroll
-                    for (int k = 0; k < np; k++) { const double pr = h[k] * wv[HP - np + k + j]; acc += pr; if (SPEC && t == 0) acc2 += pr; }
-                    if (SPEC && t == 0) fwd[j] = wv[HP + j] + acc2;
-                    sum += (acc > 0) ? acc : -acc;
+                        for (int k = 0; k < np; k++) acc2 += h[k] * wv[HP - np + k + j];
+                        fwd[j] = wv[HP + j] + acc2;
+                        sum += fabs(fwd[j]);
+                    } else {
+                        double acc = wv[HP + j];
+#pragma unroll
+                        for (int k = 0; k < np; k++) acc += h[k] * wv[HP - np + k + j];
+                        sum += (acc > 0) ? acc : -acc;
+                    }
                 }
             } else {
 #pragma unroll 1
@@ -321,6 +342,15 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     for (int t = 0; t < NT; t++) {
         const double tot = wave_sum_f64_lane63(ps[t]);
         if ((uint32_t)t < ntr && (tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = tot;
+    }
+    if (SPEC) {                                                     /* max |x| of the wave's samples, for search_slack */
+        double mx = 0.0;
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < FIR_SPL; j++) if (s + j < na) mx = fmax(mx, fabs(wv[HP + j]));
+        }
+        mx = wave_max_f64_lane63(mx);
+        if ((tid & 63u) == 63u) p.txmax[(size_t)job * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = mx;
     }
 }
 
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
  * :350-376, which recomputes the same values) and, for the last layer, the value the layer leaves in
  * parcor[P0] (Q2): the last call in reference order -- trials in order, then SetParameter's units -- that
  * wrote it. */
-__global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
+__global__ void k_select(Plan p, uint32_t layer, uint32_t exact, uint32_t spec)
 {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= p.J) return;
@@ -418,6 +448,21 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
         double m[LNN_MAXT];
         const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
         int ok = 1;
+        /* search_slack: with the fused one-unit forward (spec) trial 0's terms are |x + predict| with predict summed from 0.0,
+         * not the reference's |((x + p0) + p1) + ...|.  Both are floating-point sums of the same np + 1 numbers, each within
+         * gamma_(np+1) (|x| + sum |p_k|) of the exact value, so a term is off by at most 2 gamma_(np+1) max|x| (1 + sum |h_k|)
+         * (taken with a factor 4 and np + 2 here), and so is the mean. */
+        double slack0 = 0.0;
+        if (spec) {
+            const uint32_t np_used = ((c.na + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64);
+            const double *px = p.txmax + (size_t)job * p.npart;
+            double xmax = 0.0, hsum = 0.0;
+            for (uint32_t i = 0; i < np_used; i++) xmax = fmax(xmax, px[i]);
+            const double *h0 = p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP;
+            for (uint32_t k = 0; k < p.P[layer]; k++) hsum += fabs(h0[k]);
+            slack0 = 4.0 * ((double)p.P[layer] + 2.0) * 1.1102230246251565e-16 * xmax * (1.0 + hsum);
+            if (!(slack0 >= 0.0) || !(slack0 < (double)FLT_MAX)) ok = 0;
+        }
         for (uint32_t t = 0; t < nt; t++) {
             double sm = 0.0;
             const uint32_t np_used = ((c.na + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64);
@@ -427,7 +472,10 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
             if (!(m[t] >= 0.0) || !(m[t] < (double)FLT_MAX)) ok = 0;
             if (m[t] < min_loss) { min_loss = m[t]; best = t; }
         }
-        for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) > min_loss * (1.0 + rel))) ok = 0;
+        {   /* the smallest mean's upper end must lie below every other mean's lower end */
+            const double hi_best = min_loss * (1.0 + rel) + (best == 0 ? slack0 : 0.0);
+            for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) - (t == 0 ? slack0 : 0.0) > hi_best)) ok = 0;
+        }
         p.uncertain[job] = ok ? 0 : 1;
         if (!ok) atomicAdd(p.ucount, 1u);
     }
