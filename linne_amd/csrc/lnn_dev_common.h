@@ -55,6 +55,7 @@ struct Plan {
     double *tsum;                       /* [J][MAXT][npart] per-wave partial sums of |residual| (certified search) */
     uint32_t npart;                     /* partial sums per (job, trial): tiles x waves per block      */
     double *txmax;                      /* [J][npart] per-wave max |input| of the layer (search_slack in k_select)               */
+    double *thsum;                      /* [J][MAXT] per trial: the largest L1 norm of a unit's coefficients (search_slack)      */
     uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
     uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
     double *lparams;                    /* [J][MAXL][MAXP]             */

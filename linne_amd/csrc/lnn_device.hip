@@ -438,6 +438,7 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     b += J * LNN_MAXT * LNN_MAXU * (sizeof(double) + 1);
     b += J * LNN_MAXT * sizeof(double) * (1 + (uint64_t)((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64)) + J;
     b += J * sizeof(double) * (uint64_t)((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64) + 256;
+    b += J * LNN_MAXT * sizeof(double) + 256;
     b += J * LNN_MAXL * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXL * sizeof(uint32_t);
     b += J * 2 * sizeof(double);
@@ -562,7 +563,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TAKE(p.sig, double, J * 2 * S);
         TAKE(p.acorr, double, J * LNN_MAXT * LNN_ACW); TAKE(p.tcoef, double, J * LNN_MAXT * LNN_MAXP);
         TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
-        TAKE(p.tloss, double, J * LNN_MAXT); p.npart = ((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64); TAKE(p.tsum, double, J * LNN_MAXT * p.npart); TAKE(p.txmax, double, J * p.npart); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
+        TAKE(p.tloss, double, J * LNN_MAXT); p.npart = ((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64); TAKE(p.tsum, double, J * LNN_MAXT * p.npart); TAKE(p.txmax, double, J * p.npart); TAKE(p.thsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
 #undef TAKE
         if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
@@ -608,10 +609,10 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
               }
               span_end(ctx, sp_, st); }
             { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]); else launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u, fir_spec); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
-              hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u, fir_spec); span_end(ctx, sp_, st); }
+              hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
             /* the last layer's output is only ever summed: layers of <= 16 taps do the forward pass and the ordered loss in one
              * kernel and write nothing else */
             if (l + 1 == hs.L && fuse_cfg) {

@@ -71,6 +71,15 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
         const double *hsrc = (MODE != 1) ? (p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
         for (uint32_t i = tid; i < ntr * LNN_MAXP; i += FIR_THREADS) { const uint32_t tt = i / LNN_MAXP, k = i % LNN_MAXP; if (k < P) hs[tt][k] = hsrc[i]; }
     }
+    if (MODE == 2 && blockIdx.y == 0) {                             /* per trial: the largest L1 norm of a unit's coefficients (search_slack) */
+        __syncthreads();
+        if (tid < ntr) {
+            const uint32_t u = c.trial_u[layer][tid], np = P / u;
+            double mx = 0.0;
+            for (uint32_t un = 0; un < u; un++) { double a = 0.0; for (uint32_t k = 0; k < np; k++) a += fabs(hs[tid][un * np + k]); mx = fmax(mx, a); }
+            p.thsum[(size_t)job * LNN_MAXT + tid] = mx;
+        }
+    }
     /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
     for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.y * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
     __syncthreads();
@@ -110,14 +119,15 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
             __builtin_amdgcn_wave_barrier();
         }
     };
-    for (uint32_t t = 0; t < ntr; t++) {
+    /* one trial of the tile; DUAL (a compile-time tag): MODE 2's trial 0 with SPEC, whose chain is also the forward output */
+    auto trial_body = [&](auto dual_tag, const uint32_t t) {
+        constexpr bool dual = decltype(dual_tag)::value;
         const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
         const uint32_t n = na / u, np = P / u;
         const double *hbuf = hs[t];
         if (t == 0) __syncthreads();                                 /* tile and coefficients are staged */
         double acc[FIR_SPL];
         double acc2[FIR_SPL];                                        /* MODE 2, trial 0 with `spec`: predict-first sums of the forward pass */
-        const bool dual = (MODE == 2) && SPEC && (t == 0);
 #pragma unroll
         for (int j = 0; j < FIR_SPL; j++) acc2[j] = 0.0;
         if (s < na) {
@@ -144,13 +154,27 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
                     w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y; \
                     const double hh_[4] = { HC0.x, HC0.y, HC1.x, HC1.y }; \
                     _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
-                        _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) acc[j] += hh_[kk] * w[(4 * G + kk + j) % 16]; } \
+                        _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) acc[j] = FUSE_ ? __builtin_fma(hh_[kk], w[(4 * G + kk + j) % 16], acc[j]) : (acc[j] + hh_[kk] * w[(4 * G + kk + j) % 16]); } \
                     k += 4; }
-                for (;;) {
-                    FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
-                    FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
-                    FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
-                    FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
+                /* The search (MODE 2) only has to land inside the certificate's interval (k_select, search_slack), not on the
+                 * reference's bits: its trials run on fused multiply-adds -- half the instructions.  The chain that doubles as the
+                 * forward output (dual), the exact fallback and the forward pass keep the reference's separate multiply and add. */
+                if (MODE == 2 && !dual) {
+                    constexpr bool FUSE_ = true;
+                    for (;;) {
+                        FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
+                        FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
+                        FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
+                        FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
+                    }
+                } else {
+                    constexpr bool FUSE_ = false;
+                    for (;;) {
+                        FIR_STEP(0, ha0, ha1, hb0, hb1); if (k >= np) break;
+                        FIR_STEP(1, hb0, hb1, ha0, ha1); if (k >= np) break;
+                        FIR_STEP(2, ha0, ha1, hb0, hb1); if (k >= np) break;
+                        FIR_STEP(3, hb0, hb1, ha0, ha1); if (k >= np) break;
+                    }
                 }
                 if (dual) {
                     /* One chain for two results: acc is the forward pass's predict sum (linne_network.c:165-210), x + predict its
@@ -214,7 +238,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
             }
             ps = wave_sum_f64_lane63(ps);
             if ((tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
-            if (SPEC && t == 0) {                                    /* max |x| of the wave's samples, for search_slack */
+            if (t == 0) {                                            /* max |x| of the wave's samples, for search_slack */
                 double mx = 0.0;
                 if (s < na) {
 #pragma unroll
@@ -241,6 +265,12 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
         } else {
             store_rows(acc);
         }
+    };
+    if (MODE == 2 && SPEC) {
+        trial_body(std::true_type{}, 0u);
+        for (uint32_t t = 1; t < ntr; t++) trial_body(std::false_type{}, t);
+    } else {
+        for (uint32_t t = 0; t < ntr; t++) trial_body(std::false_type{}, t);
     }
     }
     if (MODE == 0) {
@@ -305,9 +335,9 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
                         fwd[j] = wv[HP + j] + acc2;
                         sum += fabs(fwd[j]);
                     } else {
-                        double acc = wv[HP + j];
+                        double acc = wv[HP + j];                     /* fused multiply-adds: inside the certificate's interval (see k_fir2) */
 #pragma unroll
-                        for (int k = 0; k < np; k++) acc += h[k] * wv[HP - np + k + j];
+                        for (int k = 0; k < np; k++) acc = __builtin_fma(h[k], wv[HP - np + k + j], acc);
                         sum += (acc > 0) ? acc : -acc;
                     }
                 }
@@ -343,7 +373,13 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         const double tot = wave_sum_f64_lane63(ps[t]);
         if ((uint32_t)t < ntr && (tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = tot;
     }
-    if (SPEC) {                                                     /* max |x| of the wave's samples, for search_slack */
+    if (blockIdx.y == 0 && tid < ntr) {                             /* per trial: the largest L1 norm of a unit's coefficients (search_slack) */
+        const uint32_t u = 1u << tid, np = (uint32_t)P >> tid;
+        double mx = 0.0;
+        for (uint32_t un = 0; un < u; un++) { double a = 0.0; for (uint32_t k = 0; k < np; k++) a += fabs(hs[tid][un * np + k]); mx = fmax(mx, a); }
+        p.thsum[(size_t)job * LNN_MAXT + tid] = mx;
+    }
+    {                                                               /* max |x| of the wave's samples, for search_slack */
         double mx = 0.0;
         if (live) {
 #pragma unroll
@@ -425,7 +461,7 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
  * :350-376, which recomputes the same values) and, for the last layer, the value the layer leaves in
  * parcor[P0] (Q2): the last call in reference order -- trials in order, then SetParameter's units -- that
  * wrote it. */
-__global__ void k_select(Plan p, uint32_t layer, uint32_t exact, uint32_t spec)
+__global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
 {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= p.J) return;
@@ -448,20 +484,22 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact, uint32_t spec)
         double m[LNN_MAXT];
         const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
         int ok = 1;
-        /* search_slack: with the fused one-unit forward (spec) trial 0's terms are |x + predict| with predict summed from 0.0,
-         * not the reference's |((x + p0) + p1) + ...|.  Both are floating-point sums of the same np + 1 numbers, each within
-         * gamma_(np+1) (|x| + sum |p_k|) of the exact value, so a term is off by at most 2 gamma_(np+1) max|x| (1 + sum |h_k|)
-         * (taken with a factor 4 and np + 2 here), and so is the mean. */
-        double slack0 = 0.0;
-        if (spec) {
+        /* search_slack: the search kernels' terms are not the reference's |((x + p0) + p1) + ...| bit for bit -- the trial that
+         * doubles as the forward output is |x + predict| with predict summed from 0.0, the others run on fused multiply-adds.
+         * Each is a floating-point evaluation of the same np + 1 numbers' sum, like the reference's, within
+         * gamma_(np+1) (|x| + sum |h_k x_k|) of the exact value: a term is off the reference's by at most
+         * 2 gamma_(np+1) max|x| (1 + sum |h_k|) (taken with a factor 4 and np + 2 here), and so is the mean. */
+        double slack[LNN_MAXT];
+        {
             const uint32_t np_used = ((c.na + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64);
             const double *px = p.txmax + (size_t)job * p.npart;
-            double xmax = 0.0, hsum = 0.0;
+            double xmax = 0.0;
             for (uint32_t i = 0; i < np_used; i++) xmax = fmax(xmax, px[i]);
-            const double *h0 = p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP;
-            for (uint32_t k = 0; k < p.P[layer]; k++) hsum += fabs(h0[k]);
-            slack0 = 4.0 * ((double)p.P[layer] + 2.0) * 1.1102230246251565e-16 * xmax * (1.0 + hsum);
-            if (!(slack0 >= 0.0) || !(slack0 < (double)FLT_MAX)) ok = 0;
+            for (uint32_t t = 0; t < nt; t++) {
+                const double npt = (double)(p.P[layer] / c.trial_u[layer][t]);
+                slack[t] = 4.0 * (npt + 2.0) * 1.1102230246251565e-16 * xmax * (1.0 + p.thsum[(size_t)job * LNN_MAXT + t]);
+                if (!(slack[t] >= 0.0) || !(slack[t] < (double)FLT_MAX)) ok = 0;
+            }
         }
         for (uint32_t t = 0; t < nt; t++) {
             double sm = 0.0;
@@ -473,8 +511,8 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact, uint32_t spec)
             if (m[t] < min_loss) { min_loss = m[t]; best = t; }
         }
         {   /* the smallest mean's upper end must lie below every other mean's lower end */
-            const double hi_best = min_loss * (1.0 + rel) + (best == 0 ? slack0 : 0.0);
-            for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) - (t == 0 ? slack0 : 0.0) > hi_best)) ok = 0;
+            const double hi_best = min_loss * (1.0 + rel) + slack[best];
+            for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) - slack[t] > hi_best)) ok = 0;
         }
         p.uncertain[job] = ok ? 0 : 1;
         if (!ok) atomicAdd(p.ucount, 1u);
