@@ -338,7 +338,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
                         double acc = wv[HP + j];                     /* fused multiply-adds: inside the certificate's interval (see k_fir2) */
 #pragma unroll
                         for (int k = 0; k < np; k++) acc = __builtin_fma(h[k], wv[HP - np + k + j], acc);
-                        sum += (acc > 0) ? acc : -acc;
+                        sum += fabs(acc);
                     }
                 }
             } else {
