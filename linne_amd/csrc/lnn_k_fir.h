@@ -224,7 +224,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
             /* results: |residual| (MODE 0) or x + predict (MODE 1) */
 #pragma unroll
             for (int j = 0; j < FIR_SPL; j++) {
-                if (MODE != 1) { double av = (acc[j] > 0) ? acc[j] : -acc[j]; if (s + j == 0) av = 0.0; acc[j] = av; }
+                if (MODE != 1) { double av = fabs(acc[j]); if (j == 0 && s == 0) av = 0.0; acc[j] = av; }     /* s is a multiple of 8: only j = 0 can be the frame's first sample */
                 else { const double xv = xc[j]; acc[j] = (s + j == 0) ? xv : (xv + acc[j]); }
             }
         }
@@ -232,9 +232,9 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
             /* order-free partial sum of this wave's |residual| values; the exact ordered chain is evaluated later only for
              * jobs whose argmin these sums cannot certify (k_select) */
             double ps = 0.0;
-            if (s < na) {
+            if (s < na) {                                            /* na and s are multiples of 8: a lane's samples are all inside or all outside */
 #pragma unroll
-                for (int j = 0; j < FIR_SPL; j++) if (s + j < na) ps += acc[j];
+                for (int j = 0; j < FIR_SPL; j++) ps += acc[j];
             }
             ps = wave_sum_f64_lane63(ps);
             if ((tid & 63u) == 63u) p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = ps;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
                 double mx = 0.0;
                 if (s < na) {
 #pragma unroll
-                    for (int j = 0; j < FIR_SPL; j++) if (s + j < na) mx = fmax(mx, fabs(xc[j]));
+                    for (int j = 0; j < FIR_SPL; j++) mx = fmax(mx, fabs(xc[j]));
                 }
                 mx = wave_max_f64_lane63(mx);
                 if ((tid & 63u) == 63u) p.txmax[(size_t)job * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = mx;
