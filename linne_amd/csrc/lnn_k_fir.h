@@ -360,12 +360,22 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         }
         ps[t] = sum;
     }
-    if (SPEC && live) {                                             /* forward output of the one-unit trial, straight from the registers */
-        double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+    if (SPEC) {
+        /* forward output of the one-unit trial: a lane's 8 results are 64 bytes of the row, so the wave's 4 KB go through LDS (the
+         * tile image is no longer needed once every lane has its window in registers) and leave as consecutive 16-byte pieces */
+        __syncthreads();
+        double *ob = xs + (size_t)(tid >> 6) * (64 * FIR_SPL);
+        const uint32_t ln = tid & 63u, wbase = s0 + (tid >> 6) * 64 * FIR_SPL;
 #pragma unroll
-        for (int j = 0; j < FIR_SPL; j += 2) {
-            if (s + j + 1 < na) { lnn_d2 v; v.x = fwd[j]; v.y = fwd[j + 1]; *(lnn_d2 *)(dst + j) = v; }
-            else if (s + j < na) dst[j] = fwd[j];
+        for (int j = 0; j < FIR_SPL; j += 2) { lnn_d2 v; v.x = fwd[j]; v.y = fwd[j + 1]; *(lnn_d2 *)(ob + ln * FIR_SPL + j) = v; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                         /* lgkmcnt(0): the wave's own LDS writes have landed */
+        __builtin_amdgcn_wave_barrier();
+        double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S;
+#pragma unroll
+        for (int i = 0; i < FIR_SPL / 2; i++) {
+            const uint32_t e = 2 * ln + 128 * i, g = wbase + e;
+            if (g + 1 < na) *(lnn_d2 *)(dst + g) = *(const lnn_d2 *)(ob + e);
+            else if (g < na) dst[g] = ob[e];
         }
     }
 #pragma unroll
