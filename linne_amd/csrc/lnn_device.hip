@@ -457,7 +457,7 @@ template <int MODE> static void launch_fir(hipStream_t st, const Plan &p, uint32
 /* search of a short layer (P <= 16): register-window kernel */
 static void launch_fir_small_search(hipStream_t st, const Plan &p, uint32_t l, uint32_t cur, uint32_t J, uint32_t tiles, bool spec, uint32_t P)
 {
-    const dim3 grid(J, tiles), blk(FIR_THREADS);
+    const dim3 grid(l == 0 ? J / p.R : J, tiles), blk(FIR_THREADS);      /* layer 0: one block serves the R jobs of a channel-frame */
 #define LNN_FS(PP) do { \
         if (l == 0) { if (spec) hipLaunchKernelGGL((k_fir_small<PP, true, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir_small<PP, true, false>), grid, blk, 0, st, p, l, cur); } \
         else        { if (spec) hipLaunchKernelGGL((k_fir_small<PP, false, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir_small<PP, false, false>), grid, blk, 0, st, p, l, cur); } } while (0)

@@ -291,14 +291,16 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     constexpr int HP = (P < 2) ? 2 : P;                           /* history kept in front of the tile (even, >= P) */
     __shared__ __attribute__((aligned(16))) double xs[HP + FIR_TILE];
     __shared__ __attribute__((aligned(16))) double hs[NT][HP];
-    const uint32_t job = blockIdx.x, tid = threadIdx.x, s0 = blockIdx.y * FIR_TILE;
-    const DevClass &c = job_class(p, job);
+    __shared__ __attribute__((aligned(16))) double obuf[SPEC ? FIR_TILE : 2];      /* store transpose of the fused forward output */
+    /* layer 0: the regulariser passes of a channel-frame read the same input, so one block stages the tile once and serves all
+     * R jobs (grid.x = channel-frames); other layers: grid.x = jobs */
+    const uint32_t nr = L0 ? p.R : 1u, job0 = blockIdx.x * nr, tid = threadIdx.x, s0 = blockIdx.y * FIR_TILE;
+    const DevClass &c = job_class(p, job0);
     const uint32_t na = c.na;
     if (s0 >= na) return;
-    const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
-    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
+    const double *x = p.sig + ((size_t)job0 * 2 + cur) * p.S;
+    const int32_t *xi = p.xint + (size_t)(job0 / p.R) * p.S;
     const uint32_t ntr = c.ntrials[layer];
-    for (uint32_t i = tid; i < NT * P; i += FIR_THREADS) hs[i / P][i % P] = p.tcoef[((size_t)job * LNN_MAXT + i / P) * LNN_MAXP + i % P];
     for (uint32_t i = tid; i < HP + FIR_TILE; i += FIR_THREADS) {
         const int64_t g = (int64_t)s0 - HP + i;
         xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
@@ -311,6 +313,11 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     for (int i = 0; i < HP + FIR_SPL; i += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc - HP + i); wv[i] = v.x; wv[i + 1] = v.y; }
     const bool live = s < na;
     const bool fast = live && (s >= (uint32_t)P) && (s + FIR_SPL - 1 < na) && ((na % (uint32_t)(FIR_SPL * P)) == 0);
+    for (uint32_t rr_ = 0; rr_ < nr; rr_++) {
+    const uint32_t job = job0 + rr_;
+    if (rr_) __syncthreads();                                       /* the previous job's coefficients are no longer read */
+    for (uint32_t i = tid; i < NT * P; i += FIR_THREADS) hs[i / P][i % P] = p.tcoef[((size_t)job * LNN_MAXT + i / P) * LNN_MAXP + i % P];
+    __syncthreads();
     double ps[NT], fwd[FIR_SPL];
 #pragma unroll
     for (int j = 0; j < FIR_SPL; j++) fwd[j] = 0.0;
@@ -361,10 +368,10 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         ps[t] = sum;
     }
     if (SPEC) {
-        /* forward output of the one-unit trial: a lane's 8 results are 64 bytes of the row, so the wave's 4 KB go through LDS (the
-         * tile image is no longer needed once every lane has its window in registers) and leave as consecutive 16-byte pieces */
-        __syncthreads();
-        double *ob = xs + (size_t)(tid >> 6) * (64 * FIR_SPL);
+        /* forward output of the one-unit trial: a lane's 8 results are 64 bytes of the row, so the wave's 4 KB go through LDS and
+         * leave as consecutive 16-byte pieces */
+        double *ob = obuf + (size_t)(tid >> 6) * (64 * FIR_SPL);
+        __builtin_amdgcn_wave_barrier();                            /* (the wave's reads of the previous job's pieces are done: in-order LDS) */
         const uint32_t ln = tid & 63u, wbase = s0 + (tid >> 6) * 64 * FIR_SPL;
 #pragma unroll
         for (int j = 0; j < FIR_SPL; j += 2) { lnn_d2 v; v.x = fwd[j]; v.y = fwd[j + 1]; *(lnn_d2 *)(ob + ln * FIR_SPL + j) = v; }
@@ -397,6 +404,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         }
         mx = wave_max_f64_lane63(mx);
         if ((tid & 63u) == 63u) p.txmax[(size_t)job * p.npart + blockIdx.y * (FIR_THREADS / 64) + (tid >> 6)] = mx;
+    }
     }
 }
 
