@@ -61,7 +61,7 @@ struct LINNEAmdContext {
     /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
     DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_for_encode, sig_valid;
     /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
-    int fwd_loss;                       /* LINNE_AMD_FWD_LOSS (default 1): last layer's forward pass and loss in one kernel (k_fwd_loss) */
+    int fwd_loss;                       /* LINNE_AMD_FWD_LOSS: last layer's forward pass and loss in one kernel (k_fwd_loss); -1 = by batch size */
     int lev_ride;                       /* short Levinson trials ride along with the one-unit trial (LINNE_AMD_LEV_RIDE, default 1) */
     const uint32_t *cur_idx;            /* class index per frame of the call being enqueued (host copy, in the meta ring) */
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
@@ -134,7 +134,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
-    { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : 1; }
+    { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : -1; }
     { const char *sp = getenv("LINNE_AMD_FIR_SMALL"); ctx->fir_small = sp ? atoi(sp) : 1; }
     (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEV_LDS_BUDGET);
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
@@ -539,12 +539,16 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         /* last layer: forward pass + loss in one kernel for the jobs it takes (fwd_loss_takes); the two-kernel form runs only
          * when the chunk holds frames it does not take */
         const uint32_t Plast = hs.P[hs.L - 1];
-        const bool fuse_cfg = ctx->fwd_loss && hs.L > 1 && (Plast == 2u || Plast == 4u || Plast == 8u || Plast == 16u);
+        /* The lanes = jobs kernels need a batch that fills the chip with 64-job waves: below ~24 k jobs (k_fwd_loss: one wave per
+         * 64 jobs) / ~12 k jobs (k_autocorr_hist: one block per 64 jobs and trial) the block-per-job kernels finish sooner --
+         * a single stereo frame takes 2.6 ms with them, 6.2 ms without this rule.  The environment forces either form. */
+        const bool fwd_loss_on = (ctx->fwd_loss < 0) ? (J >= 24576u) : (ctx->fwd_loss != 0);
+        const bool fuse_cfg = fwd_loss_on && hs.L > 1 && (Plast == 2u || Plast == 4u || Plast == 8u || Plast == 16u);
         bool fuse_all = fuse_cfg;
         for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
         p.fused_last = fuse_cfg ? 1u : 0u;
         { const char *e_ = getenv("LINNE_AMD_ROWS16"); p.rows16 = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
-        { const char *e_ = getenv("LINNE_AMD_HIST"); p.hist = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
+        { const char *e_ = getenv("LINNE_AMD_HIST"); p.hist = (e_ ? (atoi(e_) != 0) : (J >= 12288u)) ? 1u : 0u; }
         bool hist_all[LNN_MAXL];                                /* per layer: every frame of the chunk is k_autocorr_hist's (host copy of hist_takes) */
         for (uint32_t l = 0; l < hs.L; l++) {
             uint32_t nt = 0; for (uint32_t u = 1; u <= hs.P[l] && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
