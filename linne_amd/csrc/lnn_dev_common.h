@@ -33,7 +33,7 @@ struct DevClass {
  * block of its own.  Run i = rows [row_begin[i], row_begin[i+1]) = blocks [blk_begin[i], blk_begin[i+1]) of 64 rows.
  * More than LNN_MAXRUN runs in a chunk: one run over everything (blocks may then mix classes: slower, same results). */
 #define LNN_MAXRUN 8
-struct RowRuns { uint32_t n; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_begin[LNN_MAXRUN + 1]; };
+struct RowRuns { uint32_t n; uint32_t mixed; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_begin[LNN_MAXRUN + 1]; };   /* mixed: the one-run fallback */
 
 struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;

@@ -422,7 +422,8 @@ static void build_runs(RowRuns *rr, const uint32_t *idx, uint32_t F, uint32_t rp
         rr->blk_begin[n + 1] = rr->blk_begin[n] + ((g - f) * rpf + 63u) / 64u;
         n++; f = g;
     }
-    if (n == 0) { n = 1; rr->row_begin[1] = F * rpf; rr->blk_begin[1] = (F * rpf + 63u) / 64u; }
+    rr->mixed = 0;
+    if (n == 0) { n = 1; rr->mixed = 1; rr->row_begin[1] = F * rpf; rr->blk_begin[1] = (F * rpf + 63u) / 64u; }
     rr->n = n;
 }
 
@@ -548,7 +549,9 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
         p.fused_last = fuse_cfg ? 1u : 0u;
         { const char *e_ = getenv("LINNE_AMD_ROWS16"); p.rows16 = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
+        build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         { const char *e_ = getenv("LINNE_AMD_HIST"); p.hist = (e_ ? (atoi(e_) != 0) : (J >= 12288u)) ? 1u : 0u; }
+        if (p.runs[1].mixed) p.hist = 0;                        /* more class runs than RowRuns holds: blocks may mix classes, which only the general kernels serve */
         bool hist_all[LNN_MAXL];                                /* per layer: every frame of the chunk is k_autocorr_hist's (host copy of hist_takes) */
         for (uint32_t l = 0; l < hs.L; l++) {
             uint32_t nt = 0; for (uint32_t u = 1; u <= hs.P[l] && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
@@ -558,7 +561,6 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 if (!(c.ntrials[l] == nt && (c.na % (16u << (nt - 1))) == 0 && (c.na >> (nt - 1)) >= 32u)) hist_all[l] = false;
             }
         }
-        build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount;
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
         uint8_t *a = abase;

@@ -443,3 +443,28 @@ def test_long_layer_autocorrelation_forms_agree(product, oracle, monkeypatch, hi
     x = music(2, 5 * block + 1001, 16, seed=91 + preset)
     mine = product.encode_whole(x, 16, 44100, block, preset, True)
     assert mine == oracle.encode_whole(x, 16, 44100, block, preset, True)
+
+
+@pytest.mark.parametrize("hist", ["0", "1"])
+def test_batch_with_more_length_runs_than_the_run_table_holds(ctx, oracle, monkeypatch, hist):
+    """a batch whose frame lengths alternate (12 runs of 3 classes, all of them lengths the lanes = jobs autocorrelation
+    kernels would take): the run table falls back to one run, blocks mix classes, and the general kernels must serve every
+    row -- also when the large-batch form is forced"""
+    monkeypatch.setenv("LINNE_AMD_HIST", hist)
+    nch, bits, block, preset = 2, 16, 10240, 7
+    lens = [10240, 8192, 6144] * 4
+    frames = np.zeros((len(lens), nch, block), dtype=np.int32)
+    for f, n in enumerate(lens):
+        frames[f, :, :n] = music(nch, n, bits, seed=300 + f)
+    ns = np.array(lens, dtype=np.uint32)
+    shape = ctx.shape(nch, bits, block, preset, True)
+    res, prm, st = ctx.encode_frames_host(shape, frames, ns)
+    for f, n in enumerate(lens):
+        enc = oracle.encoder(nch, bits, 44100, block, preset, True)
+        tap, ores = enc.hotpath(frames[f][:, :n])
+        enc.close()
+        _check_taps(tap, prm[f], st[f], preset, nch, f"frame {f} n={n}")
+        assert np.array_equal(ores, res[f][:, :n]), f"frame {f}: residual"
+    dec = ctx.decode_frames_host(shape, res, prm, ns)
+    for f, n in enumerate(lens):
+        assert np.array_equal(dec[f][:, :n], frames[f][:, :n])
