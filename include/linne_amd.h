@@ -148,6 +148,12 @@ int LINNEAmd_SlotWait(struct LINNEAmdSlot *slot);
  * search could not decide and that therefore ran the exact ordered sums (synchronises; -1 on error). */
 int64_t LINNEAmd_GetLastFallbackCount(struct LINNEAmdContext *ctx);
 
+/* Telemetry of the certified search (linne_network.c:338-341): over all (job, layer) searches of the last EncodeFramesDevice
+ * call that the certificate decided, the smallest gap between the winning trial's upper bound and the runner-up's lower bound,
+ * relative to the winning mean (synchronises; a huge value when no search had two trials; -1 on error).  LINNE_AMD_EXACT=1 in
+ * the environment of ContextCreate makes every search take the exact ordered chains instead (for diffing the two paths). */
+double LINNEAmd_GetLastMinMargin(struct LINNEAmdContext *ctx);
+
 /* blocks until everything enqueued on the context's stream has finished */
 int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
 

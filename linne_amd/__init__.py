@@ -40,7 +40,7 @@ AMD_SYMBOLS = [
     "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
-    "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
+    "LINNEAmd_GetLastMinMargin", "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
     "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
 ]
 
@@ -80,6 +80,8 @@ def _load():
     L.LINNEAmd_Synchronize.argtypes = [C.c_void_p]
     L.LINNEAmd_GetLastFallbackCount.restype = C.c_int64
     L.LINNEAmd_GetLastFallbackCount.argtypes = [C.c_void_p]
+    L.LINNEAmd_GetLastMinMargin.restype = C.c_double
+    L.LINNEAmd_GetLastMinMargin.argtypes = [C.c_void_p]
     L.LINNEAmd_GetLastTimingMs.restype = C.c_double
     L.LINNEAmd_GetLastTimingMs.argtypes = [C.c_void_p, C.c_int]
     L.LINNEAmd_EnableTiming.argtypes = [C.c_void_p, C.c_int]
@@ -148,6 +150,9 @@ class Context:
 
     def last_fallback_count(self):
         return int(lib.LINNEAmd_GetLastFallbackCount(self.h))
+
+    def last_min_margin(self):
+        return float(lib.LINNEAmd_GetLastMinMargin(self.h))
 
     def synchronize(self):
         self._check(lib.LINNEAmd_Synchronize(self.h), "Synchronize")

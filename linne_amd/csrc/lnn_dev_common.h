@@ -31,8 +31,10 @@ struct DevClass {
 /* Rows of a chunk (channel-frames, or jobs) cut into runs of one length class, so that the kernels that put 64 rows on
  * the lanes of a wave see blocks of one class and may take their wave-uniform fast paths; a ragged last frame gets a
  * block of its own.  Run i = rows [row_begin[i], row_begin[i+1]) = blocks [blk_begin[i], blk_begin[i+1]) of 64 rows.
- * More than LNN_MAXRUN runs in a chunk: one run over everything (blocks may then mix classes: slower, same results). */
-#define LNN_MAXRUN 8
+ * The host hands the frames of a call to the kernels sorted by class (Plan.frame_map leads back to the caller's order), so a
+ * chunk never has more runs than there are classes.  Only with the sort switched off (LINNE_AMD_SORT=0, a test knob) can a
+ * chunk exceed LNN_MAXRUN runs: then one run covers everything (blocks may mix classes: slower, same results). */
+#define LNN_MAXRUN LNN_MAXCLS
 struct RowRuns { uint32_t n; uint32_t mixed; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_begin[LNN_MAXRUN + 1]; };   /* mixed: the one-run fallback */
 
 struct Plan {
@@ -45,7 +47,7 @@ struct Plan {
     double regs[LNN_MAXR];
     double scale;                       /* 2^-(bits-1), exact */
     const int32_t *pcm; int32_t *resid; int32_t *prm; double *stats;
-    const uint32_t *cls_of_frame; const DevClass *cls; const double *sintab; const double *wtab;
+    const uint32_t *cls_of_frame; const uint32_t *frame_map; const DevClass *cls; const double *sintab; const double *wtab;
     int32_t *xint, *xtmp;               /* [F*C][S]                    */
     double *sig;                        /* [J][2][S]                   */
     double *acorr;                      /* [J][MAXT][ACW]              */
@@ -58,6 +60,8 @@ struct Plan {
     double *thsum;                      /* [J][MAXT] per trial: the largest L1 norm of a unit's coefficients (search_slack)      */
     uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
     uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
+    unsigned long long *min_margin;     /* bits of the smallest certified relative gap of the call (k_select)        */
+    uint32_t force_exact;               /* LINNE_AMD_EXACT: flag every search as uncertain              */
     double *lparams;                    /* [J][MAXL][MAXP]             */
     uint32_t *lunits;                   /* [J][MAXL]                   */
     double *jloss, *jtail;              /* [J]                         */

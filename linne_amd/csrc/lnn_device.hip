@@ -57,9 +57,9 @@ struct LINNEAmdContext {
     hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub;
     hipStream_t side; hipEvent_t side_done; int has_side;     /* block-type statistics run beside the analysis */
     hipEvent_t fork_ev, join_ev;        /* side stream: the general autocorrelation kernel for the few frames the lanes = jobs kernels do not take */
-    DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_nsmp; uint64_t nsmp_cap;
+    DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_map;   /* class index per sorted row, then the sorted row's frame (same buffer) */ uint32_t *d_nsmp; uint64_t nsmp_cap;
     /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
-    DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_for_encode, sig_valid;
+    DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_valid;
     /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
     int fwd_loss;                       /* LINNE_AMD_FWD_LOSS: last layer's forward pass and loss in one kernel (k_fwd_loss); -1 = by batch size */
     int lev_ride;                       /* short Levinson trials ride along with the one-unit trial (LINNE_AMD_LEV_RIDE, default 1) */
@@ -70,6 +70,7 @@ struct LINNEAmdContext {
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
     int prod_ok;                        /* set per batch by build_classes, bit l: in layer l every class has all its trials and even unit lengths (k_autocorr_prod) */
     int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
+    int force_exact;                    /* LINNE_AMD_EXACT=1: every unit-count search runs the exact ordered chains (diff against the certified search) */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
 };
 
@@ -115,7 +116,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     if ((e = hipMalloc(&ctx->arena, scratch_bytes)) != hipSuccess) { CC_FAIL("hipMalloc(arena)"); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
     ctx->arena_bytes = scratch_bytes;
     if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
-    if ((e = hipMalloc((void **)&ctx->d_ucount, sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
+    if ((e = hipMalloc((void **)&ctx->d_ucount, 4 * sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
     {
         const char *env = getenv("LINNE_AMD_STREAMS");
         int ns = env ? atoi(env) : 1;
@@ -132,6 +133,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
                 && hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming) == hipSuccess;
     }
+    { const char *ex = getenv("LINNE_AMD_EXACT"); ctx->force_exact = ex ? atoi(ex) : 0; }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
     { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : -1; }
@@ -199,6 +201,15 @@ extern "C" int64_t LINNEAmd_GetLastFallbackCount(struct LINNEAmdContext *ctx)
     if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess
             || hipMemcpy(&v, ctx->d_ucount, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (int64_t)v;
+}
+
+extern "C" double LINNEAmd_GetLastMinMargin(struct LINNEAmdContext *ctx)
+{
+    if (!ctx) return -1.0;
+    double v = -1.0;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess
+            || hipMemcpy(&v, ctx->d_ucount + 2, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1.0;
+    return v;
 }
 
 extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
@@ -280,15 +291,15 @@ static int shape_info(const struct LINNEAmdShape *s, HostShape *h)
     return LNN_OK;
 }
 
-/* next buffer of the pinned metadata ring, holding at least 2 * F words; waits for the copy that last read it */
+/* next buffer of the pinned metadata ring, holding at least 4 * F words; waits for the copy that last read it */
 static int meta_acquire(LINNEAmdContext *ctx, uint32_t F, int *m_out)
 {
     const int m = ctx->meta_next;
     ctx->meta_next = (m + 1) % LNN_META;
     if (ctx->meta_used[m]) { HIPCHK(ctx, hipEventSynchronize(ctx->meta_ev[m])); ctx->meta_used[m] = 0; }
     if (!ctx->meta_ev[m]) HIPCHK(ctx, hipEventCreateWithFlags(&ctx->meta_ev[m], hipEventDisableTiming));
-    if (ctx->meta_cap[m] < 2ull * F) {
-        const uint64_t cap = 2ull * (F < 4096u ? 4096u : F);
+    if (ctx->meta_cap[m] < 4ull * F) {
+        const uint64_t cap = 4ull * (F < 4096u ? 4096u : F);
         if (ctx->meta_h[m]) { HIPCHK(ctx, hipHostFree(ctx->meta_h[m])); ctx->meta_h[m] = NULL; ctx->meta_cap[m] = 0; }
         HIPCHK(ctx, hipHostMalloc((void **)&ctx->meta_h[m], sizeof(uint32_t) * cap, hipHostMallocDefault));
         ctx->meta_cap[m] = cap;
@@ -297,26 +308,51 @@ static int meta_acquire(LINNEAmdContext *ctx, uint32_t F, int *m_out)
     return LNN_OK;
 }
 
-/* Builds the per-length classes of a batch (tables are host libm values).  The tables stay resident and
- * are uploaded again only when the shape or the set of frame lengths changes; the per-frame class index and length go
- * through a pinned ring, so a call with resident tables enqueues without synchronising the host. */
+/* frame lengths of a decode call: the synthesis kernels need nothing but each frame's length (any number of distinct
+ * lengths: a stream written by EncodeBlock calls of varying num_samples, linne_decoder.c:671-742), so no class tables
+ * are built and the encode side's resident tables stay valid */
+static int upload_lengths(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const uint32_t *h_num_samples, uint32_t F)
+{
+    const uint32_t S = shape->num_samples_per_block;
+    int m, ret;
+    if ((ret = meta_acquire(ctx, F, &m)) != LNN_OK) return ret;
+    uint32_t *nsm = ctx->meta_h[m];
+    for (uint32_t f = 0; f < F; f++) {
+        const uint32_t n = h_num_samples ? h_num_samples[f] : S;
+        if (n == 0 || n > S) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
+        nsm[f] = n;
+    }
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_nsmp, &ctx->nsmp_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_nsmp, nsm, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(ctx->meta_ev[m], ctx->stream));
+    ctx->meta_used[m] = 1;
+    return LNN_OK;
+}
+
+/* Builds the per-length classes of an encode batch (tables are host libm values) and the class-sorted
+ * order the kernels work in: sorted row i is the caller's frame map[i]; rows of one class are contiguous (stable: the
+ * caller's order inside a class), so that whatever the order of lengths in the batch -- many tracks back to back, each
+ * with its ragged tail -- a chunk has at most one run per class and the lanes = rows kernels see class-homogeneous
+ * blocks.  The tables stay resident and are uploaded again only when the shape or the set of frame lengths changes;
+ * the per-frame class index and the map go through a pinned ring, so a call with resident tables enqueues without
+ * synchronising the host. */
 static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const HostShape *hs,
-        const uint32_t *h_num_samples, uint32_t F, int for_encode)
+        const uint32_t *h_num_samples, uint32_t F)
 {
     DevClass cls[LNN_MAXCLS];
-    uint32_t ncls = 0;
+    uint32_t ncls = 0, count[LNN_MAXCLS + 1];
     const uint32_t S = shape->num_samples_per_block;
     int m;
     { const int r_ = meta_acquire(ctx, F, &m); if (r_ != LNN_OK) return r_; }
-    uint32_t *idx = ctx->meta_h[m], *nsm = ctx->meta_h[m] + F;
+    uint32_t *idx = ctx->meta_h[m], *map = ctx->meta_h[m] + F, *raw = ctx->meta_h[m] + 2 * (size_t)F;
     ctx->cur_idx = idx;
     memset(cls, 0, sizeof(cls));
+    memset(count, 0, sizeof(count));
     ctx->na_max = 0;
     uint64_t sin_total = 0, wt_total = 0;
     for (uint32_t f = 0; f < F; f++) {
         const uint32_t n = h_num_samples ? h_num_samples[f] : S;
         if (n == 0 || n > S) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
-        nsm[f] = n;
         uint32_t k = 0;
         for (; k < ncls; k++) if (cls[k].n == n) break;
         if (k == ncls) {
@@ -328,27 +364,34 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
             if (na > S) na = S;
             c.na = na;
             c.sin_off = (uint32_t)sin_total; sin_total += n;
-            if (for_encode) {
-                if (na & 1u) { snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
-                for (uint32_t l = 0; l < hs->L; l++) {
-                    const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
-                    uint32_t nt = 0;
-                    for (uint32_t u = 1; u <= maxu; u <<= 1) {
-                        if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
-                        c.trial_u[l][nt] = u;
-                        c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
-                        c.wt_off[l][nt] = (uint32_t)wt_total;
-                        { const uint32_t pu = hs->P[l] / u; wt_total += na / u + (pu > 4 ? pu : 4); wt_total = (wt_total + 3u) & ~(uint64_t)3u; }   /* tables start 32-byte aligned */
-                        nt++;
-                    }
-                    c.ntrials[l] = nt;
+            if (na & 1u) { snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
+            for (uint32_t l = 0; l < hs->L; l++) {
+                const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
+                uint32_t nt = 0;
+                for (uint32_t u = 1; u <= maxu; u <<= 1) {
+                    if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
+                    c.trial_u[l][nt] = u;
+                    c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
+                    c.wt_off[l][nt] = (uint32_t)wt_total;
+                    { const uint32_t pu = hs->P[l] / u; wt_total += na / u + (pu > 4 ? pu : 4); wt_total = (wt_total + 3u) & ~(uint64_t)3u; }   /* tables start 32-byte aligned */
+                    nt++;
                 }
+                c.ntrials[l] = nt;
             }
         }
         if (cls[k].na > ctx->na_max) ctx->na_max = cls[k].na;
-        idx[f] = k;
+        raw[f] = k;
+        count[k + 1]++;
     }
-    if (for_encode) {       /* short layers by products (k_autocorr_prod): all trials present and every unit length even, in every class */
+    {   /* stable counting sort by class (LINNE_AMD_SORT=0: the caller's order, for tests of the mixed-run fallback) */
+        const char *e_ = getenv("LINNE_AMD_SORT");
+        if (e_ && atoi(e_) == 0) { for (uint32_t f = 0; f < F; f++) { idx[f] = raw[f]; map[f] = f; } }
+        else {
+            for (uint32_t k = 0; k < ncls; k++) count[k + 1] += count[k];
+            for (uint32_t f = 0; f < F; f++) { const uint32_t pos = count[raw[f]]++; idx[pos] = raw[f]; map[pos] = f; }
+        }
+    }
+    {       /* short layers by products (k_autocorr_prod): all trials present and every unit length even, in every class */
         const char *e_ = getenv("LINNE_AMD_L0_PRODUCTS");
         ctx->prod_ok = 0;
         for (uint32_t l = 0; l < hs->L; l++) {
@@ -360,48 +403,44 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
         }
     }
     int ret;
-    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
-    if ((ret = ensure_buf(ctx, (void **)&ctx->d_nsmp, &ctx->nsmp_cap, sizeof(uint32_t) * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
-    const bool resident = ctx->sig_valid && ctx->sig_for_encode == for_encode && memcmp(&ctx->sig_shape, shape, sizeof(*shape)) == 0
-            && memcmp(ctx->sig_cls, cls, sizeof(cls)) == 0;
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * 2 * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
+    const bool resident = ctx->sig_valid && memcmp(&ctx->sig_shape, shape, sizeof(*shape)) == 0 && memcmp(ctx->sig_cls, cls, sizeof(cls)) == 0;
     if (!resident) {
         hipError_t e = hipSuccess;
         double *tab = NULL, *wt = NULL;
         ctx->sig_valid = 0;
-        if (for_encode) {
-            tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
-            wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
-            if (!tab || !wt) { free(tab); free(wt); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
-            for (uint32_t k = 0; k < ncls; k++) {
-                const uint32_t n = cls[k].n;
-                for (uint32_t s = 0; s < n; s++) tab[cls[k].sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
-                /* Welch weights per trial over one padded unit (lpc.c:199-204): w[loc] = (div * h) * (n-1-h), h = min(loc, n-1-loc);
-                 * zero in the zero zone; the (never written) middle of an odd unit is handled on the device (Q1) */
-                for (uint32_t l = 0; l < hs->L; l++)
-                    for (uint32_t t = 0; t < cls[k].ntrials[l]; t++) {
-                        const uint32_t u = cls[k].trial_u[l][t], nu = cls[k].na / u;
-                        const double div = cls[k].trial_div[l][t];
-                        double *w = wt + cls[k].wt_off[l][t];
-                        for (uint32_t loc = 0; loc < nu; loc++) {
-                            const uint32_t h = (loc < (nu >> 1)) ? loc : (nu - 1 - loc);
-                            w[loc] = div * (double)h * (double)(nu - 1 - h);
-                        }
+        tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
+        wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
+        if (!tab || !wt) { free(tab); free(wt); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
+        for (uint32_t k = 0; k < ncls; k++) {
+            const uint32_t n = cls[k].n;
+            for (uint32_t s = 0; s < n; s++) tab[cls[k].sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
+            /* Welch weights per trial over one padded unit (lpc.c:199-204): w[loc] = (div * h) * (n-1-h), h = min(loc, n-1-loc);
+             * zero in the zero zone; the (never written) middle of an odd unit is handled on the device (Q1) */
+            for (uint32_t l = 0; l < hs->L; l++)
+                for (uint32_t t = 0; t < cls[k].ntrials[l]; t++) {
+                    const uint32_t u = cls[k].trial_u[l][t], nu = cls[k].na / u;
+                    const double div = cls[k].trial_div[l][t];
+                    double *w = wt + cls[k].wt_off[l][t];
+                    for (uint32_t loc = 0; loc < nu; loc++) {
+                        const uint32_t h = (loc < (nu >> 1)) ? loc : (nu - 1 - loc);
+                        w[loc] = div * (double)h * (double)(nu - 1 - h);
                     }
-            }
-            ret = ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1));
-            if (ret == LNN_OK) ret = ensure_buf(ctx, (void **)&ctx->d_wt, &ctx->wt_cap, sizeof(double) * (wt_total ? wt_total : 1));
-            if (ret != LNN_OK) { free(tab); free(wt); return ret; }
-            e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_wt, wt, sizeof(double) * wt_total, hipMemcpyHostToDevice, ctx->stream);
+                }
         }
+        ret = ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1));
+        if (ret == LNN_OK) ret = ensure_buf(ctx, (void **)&ctx->d_wt, &ctx->wt_cap, sizeof(double) * (wt_total ? wt_total : 1));
+        if (ret != LNN_OK) { free(tab); free(wt); return ret; }
+        e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_wt, wt, sizeof(double) * wt_total, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          /* cls is on the stack, tab/wt are freed here */
         free(tab); free(wt);
         if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "class table upload: %s", hipGetErrorString(e)); return LNN_NG; }
-        memcpy(ctx->sig_cls, cls, sizeof(cls)); ctx->sig_shape = *shape; ctx->sig_for_encode = for_encode; ctx->sig_valid = 1;
+        memcpy(ctx->sig_cls, cls, sizeof(cls)); ctx->sig_shape = *shape; ctx->sig_valid = 1;
     }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_clsidx, idx, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->d_nsmp, nsm, sizeof(uint32_t) * F, hipMemcpyHostToDevice, ctx->stream));
+    ctx->d_map = ctx->d_clsidx + F;
+    HIPCHK(ctx, hipMemcpyAsync(ctx->d_clsidx, idx, sizeof(uint32_t) * 2 * (size_t)F, hipMemcpyHostToDevice, ctx->stream));    /* class index and map, back to back */
     HIPCHK(ctx, hipEventRecord(ctx->meta_ev[m], ctx->stream));
     ctx->meta_used[m] = 1;
     return LNN_OK;
@@ -478,7 +517,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 1)) != LNN_OK) return ret;
+    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames)) != LNN_OK) return ret;
 
     const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
     const uint64_t per_frame = frame_scratch_bytes(shape, &hs);
@@ -507,6 +546,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     }
     ctx->nspans = 0;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount, 0, sizeof(uint32_t), ctx->stream));
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount + 2, 0x7F, 2 * sizeof(uint32_t), ctx->stream));      /* min margin: a huge double (0x7F7F...) */
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     const bool use_sub = ctx->nsub > 0;
     if (use_sub) {
@@ -518,7 +558,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         ps.C = C; ps.S = S; ps.bits = shape->bits_per_sample; ps.L = hs.L; ps.R = hs.R; ps.F = num_frames;
         for (uint32_t l = 0; l < hs.L; l++) ps.P[l] = hs.P[l];
         ps.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
-        ps.pcm = d_pcm; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
+        ps.pcm = d_pcm; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.frame_map = ctx->d_map; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
         hipStream_t ss = ctx->stream;
         if (ctx->has_side && use_sub) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
         const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps); span_end(ctx, sp_, ss);
@@ -535,8 +575,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
         for (uint32_t r = 0; r < hs.R; r++) p.regs[r] = hs.regs[r];
         p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
-        p.pcm = d_pcm + (size_t)f0 * C * S; p.resid = d_residual + (size_t)f0 * C * S;
-        p.prm = d_params + (size_t)f0 * C * LINNE_AMD_PARAM_WORDS; p.stats = d_stats + (size_t)f0 * C * LINNE_AMD_STAT_WORDS;
+        p.pcm = d_pcm; p.resid = d_residual; p.prm = d_params; p.stats = d_stats;      /* the caller's arrays: rows of the class-sorted chunk reach them through frame_map */
         /* last layer: forward pass + loss in one kernel for the jobs it takes (fwd_loss_takes); the two-kernel form runs only
          * when the chunk holds frames it does not take */
         const uint32_t Plast = hs.P[hs.L - 1];
@@ -561,7 +600,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 if (!(c.ntrials[l] == nt && (c.na % (16u << (nt - 1))) == 0 && (c.na >> (nt - 1)) >= 32u)) hist_all[l] = false;
             }
         }
-        p.cls_of_frame = ctx->d_clsidx + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount;
+        p.cls_of_frame = ctx->d_clsidx + f0; p.frame_map = ctx->d_map + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount; p.min_margin = (unsigned long long *)(ctx->d_ucount + 2); p.force_exact = ctx->force_exact ? 1u : 0u;
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
         uint8_t *a = abase;
 #define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
@@ -658,7 +697,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames, 0)) != LNN_OK) return ret;
+    if ((ret = upload_lengths(ctx, shape, h_num_samples, num_frames)) != LNN_OK) return ret;
     DecPlan p; memset(&p, 0, sizeof(p));
     p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
     for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }

@@ -14,8 +14,9 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
     const uint32_t cf = blockIdx.x, tid = threadIdx.x;
     const DevClass &c = p.cls[p.cls_of_frame[cf / p.C]];
     const uint32_t n = c.n, S = p.S;
-    int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
-    double *st = p.stats + (size_t)cf * LINNE_AMD_STAT_WORDS;
+    const size_t ocf = (size_t)p.frame_map[cf / p.C] * p.C + cf % p.C;     /* the caller's channel-frame behind row cf of the class-sorted chunk */
+    int32_t *rec = p.prm + ocf * LINNE_AMD_PARAM_WORDS;
+    double *st = p.stats + ocf * LINNE_AMD_STAT_WORDS;
 
     if (tid == 0) {     /* linne_network.c:618-626 */
         double min_loss = (double)FLT_MAX; uint32_t best = 0;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
     for (uint32_t l = 0; l < p.L; l++) {
         const uint32_t units = s_units[l], np = p.P[l] / units, ns = n / units, rs = s_rshift[l];
         const uint32_t half = 1u << ((rs - 1u) & 31u);
-        int32_t *out = (l + 1 == p.L) ? (p.resid + (size_t)cf * S) : dst;
+        int32_t *out = (l + 1 == p.L) ? (p.resid + ocf * S) : dst;
         for (uint32_t s0 = 0; s0 < n; s0 += 4 * FIN_THREADS) {
             __syncthreads();
             for (uint32_t i = tid; i < LNN_MAXP + 4 * FIN_THREADS; i += FIN_THREADS) {

@@ -530,8 +530,17 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
         }
         {   /* the smallest mean's upper end must lie below every other mean's lower end */
             const double hi_best = min_loss * (1.0 + rel) + slack[best];
-            for (uint32_t t = 0; t < nt; t++) if (t != best && !(m[t] * (1.0 - rel) - slack[t] > hi_best)) ok = 0;
+            double gap = (double)FLT_MAX;
+            for (uint32_t t = 0; t < nt; t++) if (t != best) {
+                const double lo = m[t] * (1.0 - rel) - slack[t];
+                if (!(lo > hi_best)) ok = 0;
+                gap = fmin(gap, lo - hi_best);
+            }
+            /* telemetry (LINNEAmd_GetLastMinMargin): the smallest certified gap of the call, relative to the winning mean --
+             * how far real material stays from the certificate's bound.  Non-negative doubles order like their bit patterns. */
+            if (ok && nt > 1 && min_loss > 0.0) atomicMin(p.min_margin, (unsigned long long)__double_as_longlong(gap / min_loss));
         }
+        if (p.force_exact) ok = 0;                              /* LINNE_AMD_EXACT=1: every search takes the ordered chains */
         p.uncertain[job] = ok ? 0 : 1;
         if (!ok) atomicAdd(p.ucount, 1u);
     }

@@ -44,9 +44,10 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
     const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;     /* one block per (frame, channel) */
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
-    const int32_t *in = p.pcm + (size_t)f * C * S;
+    const uint32_t fo = p.frame_map[f];                      /* the caller's frame behind row f of the class-sorted chunk */
+    const int32_t *in = p.pcm + (size_t)fo * C * S;
     int32_t *src = p.xint + ((size_t)f * C + ch) * S, *dst = p.xtmp + ((size_t)f * C + ch) * S;
-    int32_t *rec = p.prm + ((size_t)f * C + ch) * LINNE_AMD_PARAM_WORDS;
+    int32_t *rec = p.prm + ((size_t)fo * C + ch) * LINNE_AMD_PARAM_WORDS;
 
     /* copy with zero padding (linne_encoder.c:613-621); LR -> MS on channels 0/1 (linne_utility.c:120-132): each of
      * the two blocks derives its own channel from L and R */
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(STAT_THREADS) void k_stats(Plan p)
     const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
-    const int32_t *x = p.pcm + ((size_t)f * C + ch) * S;
+    const uint32_t fo = p.frame_map[f];
+    const int32_t *x = p.pcm + ((size_t)fo * C + ch) * S;
     const uint32_t P0 = p.P[0];                              /* 2 or 4 */
     const double *sinw = p.sintab + c.sin_off;
     double r = 0.0;
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(STAT_THREADS) void k_stats(Plan p)
     __syncthreads();
     if (tid == 0) {
         double a[8], pc[8], rl[8];
-        double *st = p.stats + ((size_t)f * C + ch) * LINNE_AMD_STAT_WORDS;
+        double *st = p.stats + ((size_t)fo * C + ch) * LINNE_AMD_STAT_WORDS;
         for (uint32_t i = 0; i <= P0; i++) rl[i] = sh_r[i];
         const double r0 = rl[0] * (1.0 + 0.0);
         const int zero = (n < P0) || (fabs(r0) < (double)FLT_EPSILON);

@@ -45,3 +45,29 @@ def ctx():
     c = linne_amd.Context(0, use_torch_stream=False)
     yield c
     c.close()
+
+
+@pytest.fixture
+def ctx_env():
+    """context manager: a fresh Context created AND used under the given environment (some knobs are read by
+    LINNEAmd_ContextCreate, others per call); the environment is restored afterwards"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def make(env, scratch_bytes=0):
+        import linne_amd
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        c = None
+        try:
+            c = linne_amd.Context(0, scratch_bytes=scratch_bytes, use_torch_stream=False)
+            yield c
+        finally:
+            if c is not None:
+                c.close()
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+    return make

@@ -1,295 +1,13 @@
-"""ctypes bindings of the two checkers used by the tests (TEST INFRASTRUCTURE):
-
-* ``Oracle``   -- oracle/liblinne_oracle.so, this repo's CPU restatement (oracle/linne_oracle.c)
-* ``Reference`` -- oracle/_ref/liblinne_ref.so, the real reference compiled by oracle/Makefile from
-  /root/reference (present only where that build ran; the .so travels to the GPU box, the sources do not)
-
-Nothing in linne_amd/ imports this module.
-"""
-import ctypes as C
+"""Test-side names of the checkers and of the public-API binding (see oracle/bindings.py and linne_amd/api.py)."""
 import os
-import numpy as np
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_SO = os.path.join(ROOT, "oracle", "liblinne_oracle.so")
-REF_SO = os.path.join(ROOT, "oracle", "_ref", "liblinne_ref.so")
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
 
-MAX_CH, MAX_LAYERS, MAX_PARAMS = 8, 3, 128
-PRESET_LAYERS = {0: (2, 32), 1: (2, 32), 2: (4, 64, 8), 3: (4, 64, 8), 4: (4, 64, 8),
-                 5: (4, 128, 16), 6: (4, 128, 16), 7: (4, 128, 16)}
-
-
-class EncodeParameter(C.Structure):
-    _fields_ = [("num_channels", C.c_uint32), ("bits_per_sample", C.c_uint32), ("sampling_rate", C.c_uint32),
-                ("num_samples_per_block", C.c_uint32), ("preset", C.c_uint32), ("ch_process_method", C.c_uint32)]
-
-
-class ChannelTap(C.Structure):
-    _fields_ = [("preem_prev", C.c_int32 * 2), ("preem_coef", C.c_int32 * 2),
-                ("num_units", C.c_uint32 * MAX_LAYERS), ("rshift", C.c_uint32 * MAX_LAYERS),
-                ("coef", (C.c_int32 * MAX_PARAMS) * MAX_LAYERS),
-                ("coef_double", (C.c_double * MAX_PARAMS) * MAX_LAYERS),
-                ("pass_loss", C.c_double * 4), ("best_pass", C.c_uint32),
-                ("est_r0", C.c_double), ("est_parcor", C.c_double * (MAX_PARAMS + 2)),
-                ("est_length", C.c_double), ("parcor_tail", C.c_double)]
-
-
-class FrameTap(C.Structure):
-    _fields_ = [("block_type", C.c_uint32), ("num_samples", C.c_uint32), ("num_analyze_samples", C.c_uint32),
-                ("ch", ChannelTap * MAX_CH)]
-
-
-def _planar_ptrs(x):
-    """x: int32 array [ch][n] (C-contiguous rows) -> (int32_t*[ch], keepalive)"""
-    x = np.ascontiguousarray(x, dtype=np.int32)
-    ptrs = (C.POINTER(C.c_int32) * x.shape[0])()
-    for ch in range(x.shape[0]):
-        ptrs[ch] = x[ch].ctypes.data_as(C.POINTER(C.c_int32))
-    return ptrs, x
-
-
-def oracle_available():
-    return os.path.exists(ORACLE_SO)
-
-
-def reference_available():
-    return os.path.exists(REF_SO)
-
-
-class Oracle:
-    def __init__(self):
-        L = C.CDLL(ORACLE_SO)
-        L.oracle_encoder_create.restype = C.c_void_p
-        L.oracle_encoder_create.argtypes = [C.POINTER(EncodeParameter)]
-        L.oracle_encoder_destroy.argtypes = [C.c_void_p]
-        L.oracle_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
-                                          C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
-        L.oracle_encode_whole.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
-        L.oracle_encode_frame_hotpath.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
-        L.oracle_decode_whole.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int]
-        L.oracle_decode_frame_hotpath.argtypes = [C.POINTER(EncodeParameter), C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
-        L.oracle_crc16.restype = C.c_uint16
-        L.oracle_crc16.argtypes = [C.c_void_p, C.c_uint64]
-        L.oracle_rice_encode.restype = C.c_uint32
-        L.oracle_rice_encode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
-        L.oracle_rice_decode.restype = C.c_uint32
-        L.oracle_rice_decode.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
-        L.oracle_huffman_code.restype = C.c_uint32
-        L.oracle_huffman_code.argtypes = [C.c_uint32, C.POINTER(C.c_uint32)]
-        L.oracle_bench_encode.restype = C.c_double
-        L.oracle_bench_encode.argtypes = [C.POINTER(EncodeParameter), C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
-        self.L = L
-
-    @staticmethod
-    def param(nch, bits, rate, block, preset, ms):
-        return EncodeParameter(nch, bits, rate, block, preset, int(ms))
-
-    def encode_whole(self, x, bits, rate, block, preset, ms):
-        x = np.ascontiguousarray(x, dtype=np.int32)
-        p = self.param(x.shape[0], bits, rate, block, preset, ms)
-        enc = self.L.oracle_encoder_create(C.byref(p))
-        assert enc, "oracle_encoder_create failed"
-        ptrs, keep = _planar_ptrs(x)
-        cap = x.size * 4 * 2 + 65536
-        out = np.zeros(cap, dtype=np.uint8)
-        osz = C.c_uint32(0)
-        ret = self.L.oracle_encode_whole(enc, ptrs, x.shape[1], out.ctypes.data, cap, C.byref(osz))
-        self.L.oracle_encoder_destroy(enc)
-        assert ret == 0, f"oracle_encode_whole -> {ret}"
-        return out[:osz.value].tobytes()
-
-    def decode_whole(self, data, check_crc=1):
-        buf = np.frombuffer(data, dtype=np.uint8)
-        hdr = np.zeros(9, dtype=np.uint32)
-        nch = int.from_bytes(data[12:14], "big")
-        ns = int.from_bytes(data[14:18], "big")
-        out = np.zeros((nch, ns), dtype=np.int32)
-        ret = self.L.oracle_decode_whole(buf.ctypes.data, len(data), out.ctypes.data, nch, ns, hdr.ctypes.data, check_crc)
-        return ret, out, hdr
-
-    class Encoder:
-        """stateful block encoder (keeps the reference's cross-block buffer state, quirks Q1/Q2)"""
-
-        def __init__(self, oracle, nch, bits, rate, block, preset, ms):
-            self.o = oracle
-            self.p = Oracle.param(nch, bits, rate, block, preset, ms)
-            self.h = oracle.L.oracle_encoder_create(C.byref(self.p))
-            assert self.h
-            self.nch, self.block = nch, block
-
-        def close(self):
-            if self.h:
-                self.o.L.oracle_encoder_destroy(self.h)
-                self.h = None
-
-        def __del__(self):
-            self.close()
-
-        def encode_block(self, x):
-            """x [ch][n] -> (bytes, FrameTap, residual[ch][n] or None)"""
-            x = np.ascontiguousarray(x, dtype=np.int32)
-            n = x.shape[1]
-            ptrs, keep = _planar_ptrs(x)
-            cap = x.size * 4 * 2 + 65536
-            out = np.zeros(cap, dtype=np.uint8)
-            osz = C.c_uint32(0)
-            tap = FrameTap()
-            res = np.zeros((self.nch, self.block), dtype=np.int32)
-            ret = self.o.L.oracle_encode_block(self.h, ptrs, n, out.ctypes.data, cap, C.byref(osz), C.byref(tap), res.ctypes.data)
-            assert ret == 0, ret
-            return out[:osz.value].tobytes(), tap, res[:, :n]
-
-        def hotpath(self, x):
-            x = np.ascontiguousarray(x, dtype=np.int32)
-            n = x.shape[1]
-            tap = FrameTap()
-            res = np.zeros_like(x)
-            ret = self.o.L.oracle_encode_frame_hotpath(self.h, x.ctypes.data, n, n, C.byref(tap), res.ctypes.data)
-            assert ret == 0, ret
-            return tap, res
-
-    def encoder(self, nch, bits, rate, block, preset, ms):
-        return Oracle.Encoder(self, nch, bits, rate, block, preset, ms)
-
-    def decode_hotpath(self, taps, residual, bits, block, preset, ms):
-        """taps: sequence of ChannelTap (one per channel); residual [ch][n] -> pcm [ch][n]"""
-        d = np.ascontiguousarray(residual, dtype=np.int32).copy()
-        nch, n = d.shape
-        p = self.param(nch, bits, 44100, block, preset, ms)
-        arr = (ChannelTap * nch)(*taps)
-        ret = self.L.oracle_decode_frame_hotpath(C.byref(p), arr, d.ctypes.data, n, n)
-        assert ret == 0
-        return d
-
-
-# --- the real reference -------------------------------------------------------------------------
-
-class _RefHeader(C.Structure):
-    _fields_ = [("format_version", C.c_uint32), ("codec_version", C.c_uint32), ("num_channels", C.c_uint16),
-                ("num_samples", C.c_uint32), ("sampling_rate", C.c_uint32), ("bits_per_sample", C.c_uint16),
-                ("num_samples_per_block", C.c_uint32), ("preset", C.c_uint8), ("ch_process_method", C.c_int)]
-
-
-class _RefEncodeParameter(C.Structure):
-    _fields_ = [("num_channels", C.c_uint16), ("bits_per_sample", C.c_uint16), ("sampling_rate", C.c_uint32),
-                ("num_samples_per_block", C.c_uint16), ("preset", C.c_uint8), ("ch_process_method", C.c_int),
-                ("enable_learning", C.c_uint8), ("num_afmethod_iterations", C.c_uint8)]
-
-
-class _RefEncoderConfig(C.Structure):
-    _fields_ = [("max_num_channels", C.c_uint32), ("max_num_samples_per_block", C.c_uint32),
-                ("max_num_layers", C.c_uint32), ("max_num_parameters_per_layer", C.c_uint32)]
-
-
-class _RefDecoderConfig(C.Structure):
-    _fields_ = [("max_num_channels", C.c_uint32), ("max_num_layers", C.c_uint32),
-                ("max_num_parameters_per_layer", C.c_uint32), ("check_crc", C.c_uint8)]
-
-
-class LinneApi:
-    """Binding of the public LINNE C API (include/linne_encoder.h, include/linne_decoder.h) as exported by
-    any shared library that implements it -- the real reference or this repo's drop-in."""
-
-    def __init__(self, so_path):
-        L = C.CDLL(so_path)
-        L.LINNEEncoder_Create.restype = C.c_void_p
-        L.LINNEEncoder_Create.argtypes = [C.POINTER(_RefEncoderConfig), C.c_void_p, C.c_int32]
-        L.LINNEEncoder_CalculateWorkSize.restype = C.c_int32
-        L.LINNEEncoder_CalculateWorkSize.argtypes = [C.POINTER(_RefEncoderConfig)]
-        L.LINNEEncoder_Destroy.argtypes = [C.c_void_p]
-        L.LINNEEncoder_SetEncodeParameter.argtypes = [C.c_void_p, C.POINTER(_RefEncodeParameter)]
-        L.LINNEEncoder_EncodeHeader.argtypes = [C.POINTER(_RefHeader), C.c_void_p, C.c_uint32]
-        L.LINNEEncoder_EncodeBlock.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
-        L.LINNEEncoder_EncodeWhole.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
-        L.LINNEDecoder_Create.restype = C.c_void_p
-        L.LINNEDecoder_Create.argtypes = [C.POINTER(_RefDecoderConfig), C.c_void_p, C.c_int32]
-        L.LINNEDecoder_CalculateWorkSize.restype = C.c_int32
-        L.LINNEDecoder_CalculateWorkSize.argtypes = [C.POINTER(_RefDecoderConfig)]
-        L.LINNEDecoder_Destroy.argtypes = [C.c_void_p]
-        L.LINNEDecoder_DecodeHeader.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(_RefHeader)]
-        L.LINNEDecoder_SetHeader.argtypes = [C.c_void_p, C.POINTER(_RefHeader)]
-        L.LINNEDecoder_DecodeBlock.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32,
-                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-        L.LINNEDecoder_DecodeWhole.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
-        self.L = L
-
-    Header, EncodeParameter, EncoderConfig, DecoderConfig = _RefHeader, _RefEncodeParameter, _RefEncoderConfig, _RefDecoderConfig
-
-    def new_encoder(self, nch, bits, rate, block, preset, ms, max_block=None):
-        cfg = _RefEncoderConfig(max(nch, 1), max_block or block, 5, 128)
-        # The reference mallocs its work area and never clears the LPC calculator's buffers; what the first
-        # block's raw/compress decision reads there (oracle quirk Q2) is heap garbage unless the caller
-        # supplies the memory.  Tests hand it zero-filled memory, which is also what a fresh process gets
-        # from a large malloc.
-        wsize = self.L.LINNEEncoder_CalculateWorkSize(C.byref(cfg))
-        assert wsize > 0
-        work = np.zeros(wsize + 64, dtype=np.uint8)
-        enc = self.L.LINNEEncoder_Create(C.byref(cfg), work.ctypes.data, wsize + 64)
-        assert enc, "LINNEEncoder_Create failed"
-        self._work = getattr(self, "_work", {})
-        self._work[enc] = work
-        par = _RefEncodeParameter(nch, bits, rate, block, preset, int(ms), 0, 0)
-        ret = self.L.LINNEEncoder_SetEncodeParameter(enc, C.byref(par))
-        if ret != 0:
-            self.L.LINNEEncoder_Destroy(enc)
-            raise RuntimeError(f"SetEncodeParameter -> {ret}")
-        return enc
-
-    def encode_whole(self, x, bits, rate, block, preset, ms):
-        x = np.ascontiguousarray(x, dtype=np.int32)
-        enc = self.new_encoder(x.shape[0], bits, rate, block, preset, ms)
-        ptrs, keep = _planar_ptrs(x)
-        cap = x.size * 4 * 2 + 65536
-        out = np.zeros(cap, dtype=np.uint8)
-        osz = C.c_uint32(0)
-        ret = self.L.LINNEEncoder_EncodeWhole(enc, ptrs, x.shape[1], out.ctypes.data, cap, C.byref(osz))
-        self.L.LINNEEncoder_Destroy(enc)
-        assert ret == 0, f"EncodeWhole -> {ret}"
-        return out[:osz.value].tobytes()
-
-    def encode_blocks(self, x, bits, rate, block, preset, ms):
-        """header + one EncodeBlock call per block, as tools/linne_codec/linne_codec.c:123-161 does"""
-        x = np.ascontiguousarray(x, dtype=np.int32)
-        nch, ns = x.shape
-        enc = self.new_encoder(nch, bits, rate, block, preset, ms)
-        hdr = _RefHeader(1, 2, nch, ns, rate, bits, block, preset, int(ms))
-        cap = x.size * 4 * 2 + 65536
-        out = np.zeros(cap, dtype=np.uint8)
-        ret = self.L.LINNEEncoder_EncodeHeader(C.byref(hdr), out.ctypes.data, cap)
-        assert ret == 0
-        off, prog = 30, 0
-        while prog < ns:
-            n = min(block, ns - prog)
-            ptrs, keep = _planar_ptrs(x[:, prog:prog + n])
-            osz = C.c_uint32(0)
-            ret = self.L.LINNEEncoder_EncodeBlock(enc, ptrs, n, out.ctypes.data + off, cap - off, C.byref(osz))
-            assert ret == 0, ret
-            off += osz.value
-            prog += n
-        self.L.LINNEEncoder_Destroy(enc)
-        return out[:off].tobytes()
-
-    def decode_whole(self, data, check_crc=1):
-        buf = np.frombuffer(data, dtype=np.uint8)
-        nch = int.from_bytes(data[12:14], "big")
-        ns = int.from_bytes(data[14:18], "big")
-        cfg = _RefDecoderConfig(max(nch, 1), 5, 128, check_crc)
-        dec = self.L.LINNEDecoder_Create(C.byref(cfg), None, 0)
-        assert dec
-        out = np.zeros((max(nch, 1), max(ns, 1)), dtype=np.int32)
-        ptrs, keep = _planar_ptrs(out)
-        ret = self.L.LINNEDecoder_DecodeWhole(dec, buf.ctypes.data, len(data), ptrs, out.shape[0], out.shape[1])
-        self.L.LINNEDecoder_Destroy(dec)
-        return ret, keep
-
-
-def Reference():
-    return LinneApi(REF_SO)
-
-
-def fnv1a64(b):
-    h = 0xcbf29ce484222325
-    for byte in b:
-        h ^= byte
-        h = (h * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
-    return "%016x" % h
+from bindings import (MAX_CH, MAX_LAYERS, MAX_PARAMS, ORACLE_SO, PRESET_LAYERS, REF_SO, ChannelTap, EncodeParameter,  # noqa: E402,F401
+                      FrameTap, Oracle, Reference, fnv1a64, oracle_available, reference_available)
+from linne_amd.api import (LinneApi, _planar_ptrs, _RefDecoderConfig, _RefEncodeParameter, _RefEncoderConfig,  # noqa: E402,F401
+                           _RefHeader)

@@ -468,3 +468,65 @@ def test_batch_with_more_length_runs_than_the_run_table_holds(ctx, oracle, monke
     dec = ctx.decode_frames_host(shape, res, prm, ns)
     for f, n in enumerate(lens):
         assert np.array_equal(dec[f][:, :n], frames[f][:, :n])
+
+
+def test_decode_whole_of_a_stream_with_many_distinct_block_lengths(product, reference):
+    """a valid .lnn written by EncodeBlock calls of varying num_samples (linne_encoder.c:774-862 accepts any length up to the
+    block size): 48 distinct block lengths in one DecodeWhole group.  The decoder takes the lengths from the stream
+    (linne_decoder.c:671-742) and must not care how many different ones there are"""
+    import ctypes as C
+    from refs import _planar_ptrs, _RefHeader
+    nch, bits, block, preset = 2, 16, 4096, 7
+    lens = [4096 - 8 * i - (i % 3) for i in range(48)]
+    total = sum(lens)
+    x = music(nch, total, bits, seed=123)
+    enc = reference.new_encoder(nch, bits, 44100, block, preset, True)
+    hdr = _RefHeader(1, 2, nch, total, 44100, bits, block, preset, 1)
+    out = np.zeros(total * nch * 8 + 65536, dtype=np.uint8)
+    assert reference.L.LINNEEncoder_EncodeHeader(C.byref(hdr), out.ctypes.data, out.size) == 0
+    off, prog = 30, 0
+    for n in lens:
+        ptrs, keep = _planar_ptrs(x[:, prog:prog + n])
+        osz = C.c_uint32(0)
+        assert reference.L.LINNEEncoder_EncodeBlock(enc, ptrs, n, out.ctypes.data + off, out.size - off, C.byref(osz)) == 0
+        off += osz.value
+        prog += n
+    reference.L.LINNEEncoder_Destroy(enc)
+    stream = out[:off].tobytes()
+    ret, want = reference.decode_whole(stream)
+    assert ret == 0 and np.array_equal(want, x)
+    ret, got = product.decode_whole(stream)
+    assert ret == 0 and np.array_equal(got, x)
+
+
+def test_corrupt_streams_decode_to_the_reference_pcm(product):
+    """CRC check off: wherever the reference decoder accepts a damaged stream (returns OK), this decoder must return OK too
+    and deliver the same PCM -- whatever unit counts, shifts, coefficients and residuals the damage produced
+    (linne_decoder.c:430-526, linne_lpc_synthesize.c:8-83 with wrap-around int32 arithmetic).  The reference's verdicts
+    come from tests/golden/corrupt_decode.json (tests/golden/make_corrupt_golden.py ran oracle/_ref in child processes:
+    some damaged streams crash it); streams it rejects must be rejected here with a result code as well."""
+    import hashlib
+    import json
+    import os
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_corrupt_golden", os.path.join(sys_path, "make_corrupt_golden.py"))
+    gen = importlib.util.module_from_spec(spec); spec.loader.exec_module(gen)
+    gold = json.load(open(os.path.join(sys_path, "corrupt_decode.json")))
+    x, rng = gen.stream_and_damage()
+    good = product.encode_whole(x, 16, 44100, 2048, 7, True)
+    assert hashlib.sha256(good).hexdigest() == gold["good_sha256"]
+    compared = 0
+    for trial, want in enumerate(gold["trials"]):
+        bad = gen.damaged(good, rng)
+        ret, got = product.decode_whole(bad, check_crc=0)
+        assert ret in range(8)
+        if want.get("crashed"):
+            continue
+        if want["ret"] == 0:
+            assert ret == 0, f"trial {trial}: the reference decodes this stream, the product returns {ret}"
+            assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).hexdigest() == want["sha256"], f"trial {trial}: PCM of the damaged stream differs from the reference decoder's"
+            compared += 1
+        else:
+            assert ret != 0, f"trial {trial}: the reference rejects this stream ({want['ret']}), the product accepts it"
+    assert compared >= 40

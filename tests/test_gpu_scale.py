@@ -1,0 +1,251 @@
+"""GPU parity at the batch sizes the launch rules pick BY THEMSELVES (-m gpu).
+
+EncodeFramesDevice chooses its kernel forms by batch size (lnn_device.hip: k_autocorr_hist / k_autocorr_sub from 12 288
+jobs, k_fwd_loss from 24 576 jobs; DecodeFramesDevice: k_synth_small / k_synth_big from 6 144 channel-frames), cuts a call
+into equal chunks when the scratch arena is small, and can rotate chunks over two streams.  The tests in
+test_gpu_parity.py reach those forms by forcing them onto a few frames; here the batch is big enough that nothing is
+forced: many full 64-row blocks per class run, a ragged tail, several chunks, two streams, and the many-tracks shape of
+BASELINE configs[3] (full ... tail, full ... tail in ONE call).  A sample of the output -- first 64 frames, last 64 incl.
+the tail, random frames in between -- is compared with the oracle bit for bit (params, stats, residual:
+libs/linne_encoder/src/linne_encoder.c:594-752), the whole batch through decode(encode(x)) == x.
+"""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import linne_amd
+from signals import music
+from test_gpu_parity import _check_taps
+
+pytestmark = pytest.mark.gpu
+
+NCH, BITS, BLOCK, PRESET = 2, 16, 10240, 7
+NBIG = 3200                     # J = 3200 * 2 * 4 = 25 600 jobs: above both thresholds; 6 400 channel-frames: above decode's
+TAIL = 9280
+
+
+@pytest.fixture(scope="module")
+def big(oracle):
+    """3200 stereo frames of one long 'music' track, the last one a 9280-sample tail, + a cache of oracle results"""
+    x = music(NCH, (NBIG - 1) * BLOCK + TAIL, BITS, seed=2026)
+    frames = np.zeros((NBIG, NCH, BLOCK), dtype=np.int32)
+    flat = np.zeros((NCH, NBIG * BLOCK), dtype=np.int32)
+    flat[:, :x.shape[1]] = x
+    frames[:] = flat.reshape(NCH, NBIG, BLOCK).transpose(1, 0, 2)
+    ns = np.full(NBIG, BLOCK, dtype=np.uint32)
+    ns[-1] = TAIL
+    return {"frames": frames, "ns": ns, "cache": {}}
+
+
+def sample_indices(F, seed, nmid=128):
+    rng = np.random.default_rng(seed)
+    idx = set(range(min(64, F))) | set(range(max(0, F - 64), F))
+    if F > 128:
+        idx |= set(int(i) for i in rng.choice(np.arange(64, F - 64), size=min(nmid, F - 128), replace=False))
+    return sorted(idx)
+
+
+def oracle_taps(oracle, frames, ns, indices, cache=None, preset=PRESET, nch=NCH, bits=BITS, block=BLOCK, ms=True):
+    """oracle hot path of the sampled frames on the host's cores (ctypes releases the GIL)"""
+    cache = {} if cache is None else cache
+    todo = [f for f in indices if (f, int(ns[f])) not in cache]
+
+    def one(f):
+        enc = oracle.encoder(nch, bits, 44100, block, preset, ms)
+        tap, res = enc.hotpath(frames[f][:, :int(ns[f])])
+        enc.close()
+        return f, tap, res
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        for f, tap, res in ex.map(one, todo):
+            cache[(f, int(ns[f]))] = (tap, res)
+    return {f: cache[(f, int(ns[f]))] for f in indices}
+
+
+def compare_sample(want, ns, res, prm, st, where, preset=PRESET, nch=NCH):
+    for f, (tap, ores) in want.items():
+        n = int(ns[f])
+        _check_taps(tap, prm[f], st[f], preset, nch, f"{where} frame {f} n={n}")
+        assert np.array_equal(ores, res[f][:, :n]), f"{where} frame {f}: residual"
+        assert not res[f][:, n:].any(), f"{where} frame {f}: residual beyond the frame's length"
+
+
+def run_batch(c, frames, ns, check_decode=True, preset=PRESET, nch=NCH, bits=BITS, block=BLOCK):
+    import torch
+    shape = c.shape(nch, bits, block, preset, True)
+    pcm = torch.from_numpy(frames).cuda()
+    res, prm, st = c.encode_frames(shape, pcm, ns)
+    c.synchronize()
+    c.launches = {k: c.last_launches(k) for k in (1, 3, 20, 21, 22, 23)}        # (the decode call below resets the spans)
+    out = (res.cpu().numpy(), prm.cpu().numpy(), st.cpu().numpy())
+    if check_decode:
+        dec = c.decode_frames(shape, res, prm, ns)
+        c.synchronize()
+        back = dec.cpu().numpy()
+        for f in np.flatnonzero(ns < block):
+            back[f, :, int(ns[f]):] = frames[f, :, int(ns[f]):]
+        assert np.array_equal(back, frames), "decode(encode(x)) != x"
+    del pcm, res, prm, st
+    torch.cuda.empty_cache()
+    return out
+
+
+def kinds_that_ran(c, kinds):
+    return {k for k in kinds if c.launches.get(k, 0) > 0}
+
+
+def test_large_batch_picks_the_lanes_kernels_by_itself(oracle, big):
+    """3200 stereo frames + tail in ONE chunk: k_autocorr_hist<128,0/1>, k_autocorr_sub, autocorr_rows, k_fwd_loss,
+    k_synth_small/big are what the batch-size rules select; nothing is forced"""
+    for v in ("LINNE_AMD_HIST", "LINNE_AMD_FWD_LOSS", "LINNE_AMD_ROWS16", "LINNE_AMD_L0_PRODUCTS", "LINNE_AMD_DECODE_KERNEL", "LINNE_AMD_SORT"):
+        assert v not in os.environ
+    c = linne_amd.Context(0, scratch_bytes=8 << 30, use_torch_stream=False)
+    try:
+        c.enable_timing(True)
+        res, prm, st = run_batch(c, big["frames"], big["ns"], check_decode=False)
+        ran = kinds_that_ran(c, (20, 21, 22, 23, 3))
+        assert {20, 21, 22, 23} <= ran, f"the lanes = jobs kernels did not run: {ran}"
+        assert c.launches[21] == 1, "expected one chunk"
+        assert c.last_fallback_count() == 0
+        margin = c.last_min_margin()
+        assert 0.0 < margin < 1e300
+        print(f"min certified margin over {NBIG * NCH * 4 * 3} searches: {margin:.3e}")
+        c.enable_timing(False)
+        idx = sample_indices(NBIG, seed=1)
+        compare_sample(oracle_taps(oracle, big["frames"], big["ns"], idx, big["cache"]), big["ns"], res, prm, st, "one chunk")
+        big["one_chunk"] = (res, prm, st)
+        run_batch(c, big["frames"], big["ns"], check_decode=True)           # the decode kernels of the large batch
+    finally:
+        c.close()
+
+
+def test_multi_chunk_loop(oracle, big):
+    """the same call through an arena that holds a fifth of it: chunks with f0 > 0 (small forms by batch size), every frame
+    equal to the one-chunk result, sample equal to the oracle"""
+    c = linne_amd.Context(0, scratch_bytes=int(1.3 * (1 << 30)), use_torch_stream=False)
+    try:
+        c.enable_timing(True)
+        res, prm, st = run_batch(c, big["frames"], big["ns"], check_decode=False)
+        assert c.launches[1] >= 3, f"expected >= 3 chunks, got {c.launches[1]}"
+        c.enable_timing(False)
+    finally:
+        c.close()
+    idx = sample_indices(NBIG, seed=1)
+    compare_sample(oracle_taps(oracle, big["frames"], big["ns"], idx, big["cache"]), big["ns"], res, prm, st, "multi-chunk")
+    if "one_chunk" in big:
+        a = big["one_chunk"]
+        assert np.array_equal(a[0], res) and np.array_equal(a[1], prm) and np.array_equal(a[2], st, equal_nan=True)
+
+
+def test_multi_chunk_loop_with_the_large_batch_forms(oracle, big, monkeypatch):
+    """several chunks AND the lanes = jobs kernels in every one of them (forced: a chunk of this size would not pick them)"""
+    monkeypatch.setenv("LINNE_AMD_HIST", "1")
+    monkeypatch.setenv("LINNE_AMD_FWD_LOSS", "1")
+    F = 900
+    frames, ns = big["frames"][-F:], big["ns"][-F:]
+    c = linne_amd.Context(0, scratch_bytes=int(0.6 * (1 << 30)), use_torch_stream=False)
+    try:
+        c.enable_timing(True)
+        res, prm, st = run_batch(c, frames, ns, check_decode=False)
+        assert c.launches[1] >= 3 and c.launches[21] == c.launches[1] and c.launches[20] == c.launches[1], c.launches
+        c.enable_timing(False)
+    finally:
+        c.close()
+    off = NBIG - F
+    idx = sample_indices(F, seed=3, nmid=64)
+    want = oracle_taps(oracle, big["frames"], big["ns"], [off + f for f in idx], big["cache"])
+    compare_sample({f - off: v for f, v in want.items()}, ns, res, prm, st, "multi-chunk, forced forms")
+
+
+def test_two_streams(oracle, big, monkeypatch):
+    """LINNE_AMD_STREAMS=2: chunks rotate over two streams with their own halves of the arena"""
+    monkeypatch.setenv("LINNE_AMD_STREAMS", "2")
+    c = linne_amd.Context(0, scratch_bytes=8 << 30, use_torch_stream=False)
+    try:
+        c.enable_timing(True)
+        res, prm, st = run_batch(c, big["frames"], big["ns"], check_decode=False)
+        assert c.launches[1] >= 2, "expected the call to split over the two streams"
+        c.enable_timing(False)
+    finally:
+        c.close()
+    idx = sample_indices(NBIG, seed=1)
+    compare_sample(oracle_taps(oracle, big["frames"], big["ns"], idx, big["cache"]), big["ns"], res, prm, st, "two streams")
+    if "one_chunk" in big:
+        a = big["one_chunk"]
+        assert np.array_equal(a[0], res) and np.array_equal(a[1], prm) and np.array_equal(a[2], st, equal_nan=True)
+
+
+def many_tracks(big, ntracks, per_track, tail):
+    """BASELINE configs[3] in small: ntracks tracks of (per_track - 1) full frames + one tail frame, back to back"""
+    F = ntracks * per_track
+    frames = big["frames"][:F].copy()
+    ns = np.full(F, BLOCK, dtype=np.uint32)
+    for t in range(ntracks):
+        f = t * per_track + per_track - 1
+        ns[f] = tail
+        frames[f, :, tail:] = 0
+    return frames, ns
+
+
+def test_many_tracks_in_one_call_keep_the_fast_kernels(oracle, big):
+    """64 tracks x (50 full + tail 2000) in ONE EncodeFramesDevice call (tools/linne_codec/linne_codec.c:133-161 per track):
+    the host sorts the frames by length class, so the batch has two class runs and the lanes = jobs kernels serve the full
+    frames exactly as in the single-track run; bytes equal the oracle's on a sample that holds every tail"""
+    ntracks, per = 64, 51
+    frames, ns = many_tracks(big, ntracks, per, 2000)
+    F = ntracks * per
+    c = linne_amd.Context(0, scratch_bytes=8 << 30, use_torch_stream=False)
+    try:
+        c.enable_timing(True)
+        res, prm, st = run_batch(c, frames, ns, check_decode=True)
+        ran = kinds_that_ran(c, (20, 21, 22, 23))
+        assert ran == {20, 21, 22, 23}, f"many-track batch fell off the fast path: {c.launches}"
+        assert c.launches[21] == 1
+        c.enable_timing(False)
+    finally:
+        c.close()
+    tails = [t * per + per - 1 for t in range(ntracks)]
+    rng = np.random.default_rng(5)
+    idx = sorted(set(tails) | set(int(i) for i in rng.choice(F, size=96, replace=False)) | set(range(8)))
+    cache = {}
+    compare_sample(oracle_taps(oracle, frames, ns, idx, cache), ns, res, prm, st, "many tracks")
+
+
+@pytest.mark.parametrize("forced", [False, True])
+def test_unsorted_alternating_lengths_take_the_mixed_run_fallback(ctx_env, oracle, forced):
+    """LINNE_AMD_SORT=0 (test knob): frame lengths alternate, more runs than the run table holds, blocks mix classes.  The
+    general kernels must serve every row -- also with k_fwd_loss / autocorr_rows forced on (LINNE_AMD_FWD_LOSS=1,
+    LINNE_AMD_ROWS16=1, LINNE_AMD_L0_PRODUCTS=0), which a batch of this size would not pick"""
+    env = {"LINNE_AMD_SORT": "0"}
+    if forced:
+        env.update({"LINNE_AMD_FWD_LOSS": "1", "LINNE_AMD_ROWS16": "1", "LINNE_AMD_L0_PRODUCTS": "0", "LINNE_AMD_HIST": "1"})
+    lens = [10240, 8192, 6144] * 6                              # 18 runs > LNN_MAXRUN = 16
+    frames = np.zeros((len(lens), NCH, BLOCK), dtype=np.int32)
+    for f, n in enumerate(lens):
+        frames[f, :, :n] = music(NCH, n, BITS, seed=700 + f)
+    ns = np.array(lens, dtype=np.uint32)
+    with ctx_env(env) as c:
+        res, prm, st = run_batch(c, frames, ns, check_decode=True)
+    compare_sample(oracle_taps(oracle, frames, ns, list(range(len(lens)))), ns, res, prm, st, f"unsorted, forced={forced}")
+    # and the same batch in sorted order (default): same bytes
+    with ctx_env({k: v for k, v in env.items() if k != "LINNE_AMD_SORT"}) as c:
+        r2 = run_batch(c, frames, ns, check_decode=False)
+    assert np.array_equal(r2[0], res) and np.array_equal(r2[1], prm) and np.array_equal(r2[2], st, equal_nan=True)
+
+
+def test_exact_search_everywhere_equals_the_certified_search(ctx_env, big):
+    """LINNE_AMD_EXACT=1 sends every unit-count search through the ordered unfused chains (k_fir2<0>); the certified
+    order-free search must give the same bytes on every frame (linne_network.c:338-341)"""
+    F = 192
+    frames, ns = big["frames"][-F:], big["ns"][-F:]
+    with ctx_env({}) as c:
+        a = run_batch(c, frames, ns, check_decode=False)
+        assert c.last_fallback_count() == 0
+        margin = c.last_min_margin()
+    with ctx_env({"LINNE_AMD_EXACT": "1"}) as c:
+        b = run_batch(c, frames, ns, check_decode=False)
+        assert c.last_fallback_count() == F * NCH * 4 * 3
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    assert margin > 0.0
