@@ -21,7 +21,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 import torch
@@ -99,11 +98,74 @@ def host_cores():
     return max(1, n)
 
 
+def _checkers():
+    """the CPU checkers under oracle/ (test infrastructure): imported only by the cpu_baseline / sample-parity legs"""
+    odir = os.path.join(ROOT, "oracle")
+    if odir not in sys.path:
+        sys.path.insert(0, odir)
+    from bindings import Oracle, REF_SO, EncodeParameter, reference_available
+    return Oracle, REF_SO, EncodeParameter, reference_available
+
+
+def sample_parity(frames, nsm, res, prm, st, shape, bits, block, preset, ms, nsample_mid=128):
+    """Outside the timed region: a sample of the timed batch's output -- the first 64 frames, the last 64 (with the ragged
+    tail) and `nsample_mid` random ones in between -- serialised with the host stage (LINNEAmd_PackFrames) and compared byte
+    for byte with the CPU reference's EncodeBlock of the same frames (oracle/_ref when built, else the oracle port; a fresh
+    handle per frame on both sides).  Equal blocks mean equal pre-emphasis, unit counts, shifts, coefficients and residuals
+    (libs/linne_encoder/src/linne_encoder.c:594-752).  decode(encode(x)) == x cannot show that: it holds for any coefficients."""
+    import ctypes as C
+    from concurrent.futures import ThreadPoolExecutor
+    from linne_amd.api import LinneApi
+    Oracle, REF_SO, EncodeParameter, reference_available = _checkers()
+    F, nch, _ = frames.shape
+    rng = np.random.default_rng(12345)
+    idx = set(range(min(64, F))) | set(range(max(0, F - 64), F))
+    if F > 128:
+        idx |= set(int(i) for i in rng.choice(np.arange(64, F - 64), size=min(nsample_mid, F - 128), replace=False))
+    idx = sorted(idx)
+    sel = torch.as_tensor(idx, device=frames.device)
+    h_pcm, h_res, h_prm, h_st = (t.index_select(0, sel).cpu().numpy() for t in (frames, res, prm, st))
+    use_ref = reference_available()
+    api = LinneApi(REF_SO) if use_ref else None
+    orc = None if use_ref else Oracle()
+
+    def want(k):
+        n = int(nsm[idx[k]])
+        x = np.ascontiguousarray(h_pcm[k][:, :n])
+        if use_ref:
+            enc = api.new_encoder(nch, bits, 44100, block, preset, ms)
+            out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
+            osz = C.c_uint32(0)
+            ptrs = (C.POINTER(C.c_int32) * nch)(*[x[ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
+            r = api.L.LINNEEncoder_EncodeBlock(enc, ptrs, n, out.ctypes.data, out.size, C.byref(osz))
+            api.L.LINNEEncoder_Destroy(enc)
+            assert r == 0
+            return out[:osz.value].tobytes()
+        enc = orc.encoder(nch, bits, 44100, block, preset, ms)
+        b, _, _ = enc.encode_block(x)
+        enc.close()
+        return b
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=host_cores()) as ex:
+        wanted = list(ex.map(want, range(len(idx))))
+    bad = []
+    for k, f in enumerate(idx):
+        n = np.array([nsm[f]], dtype=np.uint32)
+        got, _ = linne_amd.pack_frames(shape, h_pcm[k:k + 1], h_res[k:k + 1], h_prm[k:k + 1], h_st[k:k + 1], n, 0.0, 1)
+        if got[0] != wanted[k]:
+            bad.append(f)
+    return {"ok": not bad, "frames_compared": len(idx), "mismatching_frames": bad[:16], "checker": "reference" if use_ref else "port",
+            "what": "LINNEAmd_PackFrames(GPU params/residual/stats) == CPU EncodeBlock bytes, per frame, fresh handle each",
+            "seconds": time.perf_counter() - t0}
+
+
 def cpu_baseline(frames_host, bits, block, preset, ms, budget_frames_per_thread):
     """reference CPU encoder (EncodeBlock incl. its entropy stage) on the first frames of the workload, one handle
     per thread over disjoint frames"""
-    from refs import LinneApi, Oracle, REF_SO, EncodeParameter, reference_available
     import ctypes as C
+    from linne_amd.api import LinneApi
+    Oracle, REF_SO, EncodeParameter, reference_available = _checkers()
     cores = host_cores()
     F, nch, _ = frames_host.shape
     per = min(budget_frames_per_thread, max(1, F // cores))
@@ -158,7 +220,7 @@ def end_to_end(x_host, bits, rate, block, preset, ms):
     LINNEDecoder_DecodeWhole of liblinne_amd.so, PCIe and the host entropy stage included; second of two runs on the
     same handles (the first pays the one-time set-up of the GPU context and the pinned staging slots)"""
     import ctypes as C
-    from refs import LinneApi, _planar_ptrs, _RefDecoderConfig
+    from linne_amd.api import LinneApi, _planar_ptrs, _RefDecoderConfig
     api = LinneApi(linne_amd.LIB_PATH)
     L = api.L
     nch, ns = x_host.shape
@@ -199,8 +261,11 @@ def main():
     ap.add_argument("--channels", type=int, default=2, help="other BASELINE configs, e.g. configs[4]: --channels 8 --bits 24 --rate 96000")
     ap.add_argument("--bits", type=int, default=16)
     ap.add_argument("--rate", type=int, default=44100)
-    ap.add_argument("--end-to-end", action="store_true", help="also time EncodeWhole/DecodeWhole on host buffers (launches smaller batches: "
-                    "keep it off when collecting the per-kernel rocprof summary of the timed region)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the EncodeWhole/DecodeWhole leg on host buffers (it launches smaller "
+                    "batches: skip it when collecting the per-kernel rocprof summary of the timed region)")
+    ap.add_argument("--no-sample-parity", action="store_true", help="skip the sampled comparison of the timed batch's output with the CPU reference")
+    ap.add_argument("--tracks", type=int, default=1, help="tracks per GPU in ONE batch, each --minutes long with its own ragged tail "
+                    "(BASELINE configs[3]: --tracks 1024 --minutes 3 on 8 GPUs = 128 per GPU)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,9 +287,15 @@ def main():
 
     nch, bits, block, rate, ms = args.channels, args.bits, 10240, args.rate, args.channels >= 2
     ns_total = int(round(args.minutes * 60 * rate))
-    track = synth_track(ns_total, nch, bits, seed=rank, device=dev)
-    frames, nsm = frames_from_track(track, block)
-    del track
+    parts, nparts = [], []
+    for t in range(args.tracks):                       # several tracks: one batch, every track with its own ragged tail
+        track = synth_track(ns_total, nch, bits, seed=rank * args.tracks + t, device=dev)
+        fr, nn = frames_from_track(track, block)
+        parts.append(fr); nparts.append(nn)
+        del track
+    frames = parts[0] if args.tracks == 1 else torch.cat(parts, dim=0)
+    nsm = np.concatenate(nparts)
+    del parts
     F = frames.shape[0]
     ctx = linne_amd.Context(local, scratch_bytes=int(args.scratch_gib * (1 << 30)))
     shape = ctx.shape(nch, bits, block, args.preset, ms)
@@ -334,7 +405,13 @@ def main():
             nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))
             cpu = cpu_baseline(frames[:nf].cpu().numpy(), bits, block, args.preset, ms, args.cpu_frames_per_thread)
         e2e = None
-        if args.end_to_end and world == 1:
+        parity = None
+        if not args.no_sample_parity and world == 1:
+            try:
+                parity = sample_parity(frames, nsm, res, prm, st, shape, bits, block, args.preset, ms)
+            except Exception as exc:
+                parity = {"ok": False, "error": repr(exc)}
+        if not args.no_end_to_end and world == 1 and args.tracks == 1:
             try:
                 x_host = np.ascontiguousarray(frames.permute(1, 0, 2).reshape(nch, -1)[:, :ns_total].cpu().numpy())
                 e2e = end_to_end(x_host, bits, rate, block, args.preset, ms)
@@ -347,21 +424,26 @@ def main():
             "value": enc_fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": enc_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"encode -m {args.preset}: {args.minutes:g} min {rate / 1000:g} kHz int{bits} {nch}-channel per GPU = {F} frames of {block} samples "
+            "config": {"workload": f"encode -m {args.preset}: {args.tracks} x {args.minutes:g} min {rate / 1000:g} kHz int{bits} {nch}-channel per GPU = {F} frames of {block} samples "
                                    f"(tail {int(nsm[-1])}), MS {'on' if ms else 'off'}, PCM resident in HBM; decode = inverse hot path on the encode output",
-                       "frames_per_gpu": F, "channels": nch, "preset": args.preset, "sharding": f"{world} independent track(s), one per GPU"},
+                       "frames_per_gpu": F, "channels": nch, "preset": args.preset, "tracks_per_gpu": args.tracks, "sharding": f"{world * args.tracks} independent track(s), {args.tracks} per GPU"},
             "decode_frames_per_s": dec_fps, "decode_ms_per_step": dec_s / args.steps * 1e3, "decode_bit_exact": ok,
+            "encode_sample_parity": (parity or {}).get("ok"), "encode_sample_parity_detail": parity,
             "encode_channel_frames_per_s": enc_fps * nch,
             "kernel_ms_per_step": breakdown,
             "roofline": roofline, "valu_f64": valu, "cpu_baseline": cpu, "end_to_end_api": e2e,
         }
         if cpu:
-            line["speedup_vs_cpu_baseline"] = enc_fps / cpu["value"]
+            # like for like: the reference's EncodeBlock starts from host memory and includes its entropy coder, so the honest
+            # ratio is the drop-in API's EncodeWhole (host planes -> .lnn bytes); the HBM-resident hot path alone is given beside it
+            if e2e and e2e.get("encode_whole_frames_per_s"):
+                line["speedup_end_to_end_vs_cpu_baseline"] = e2e["encode_whole_frames_per_s"] / cpu["value"]
+            line["hot_path_resident_over_cpu_encodeblock"] = enc_fps / cpu["value"]
         print(json.dumps(line), flush=True)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
-    if not ok:
+    if not ok or (rank == 0 and world == 1 and not args.no_sample_parity and parity is not None and not parity.get("ok")):
         sys.exit(2)
 
 

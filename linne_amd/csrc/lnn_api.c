@@ -498,7 +498,7 @@ LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint
  * entropy-decoded, then scatter the PCM into the caller's planes ---- */
 struct dgroup {
     uint32_t nblk, ncomp;
-    uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn; int *rets;
+    uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn, *cons; int *rets;
 };
 struct unpack_job {
     const struct LINNEDecoder *dec; const uint8_t *data; struct dgroup *g; int32_t *sdata, *sprm; int32_t **buffer;
@@ -511,16 +511,16 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
     const uint32_t C = sh->num_channels, S = sh->num_samples_per_block;
     const uint64_t CS = (uint64_t)C * S;
     int32_t *tmp = NULL, tprm[LINNE_MAX_NUM_CHANNELS * LINNE_AMD_PARAM_WORDS];
-    uint32_t f, ch, consumed;
+    uint32_t f, ch;
     for (f = first; f < first + count; f++) {
         if (g->cidx[f] != 0xFFFFFFFFu) {            /* COMPRESS by its header: residual and parameters go to the slot */
             g->rets[f] = lnn_parse_block(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
-                    &g->types[f], &g->ns[f], &consumed, j->sdata + g->cidx[f] * CS, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS);
+                    &g->types[f], &g->ns[f], &g->cons[f], j->sdata + g->cidx[f] * CS, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS);
             continue;
         }
         if (!tmp && !(tmp = malloc(sizeof(int32_t) * CS))) { g->rets[f] = LNN_NG; continue; }
         g->rets[f] = lnn_parse_block(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
-                &g->types[f], &g->ns[f], &consumed, tmp, tprm);
+                &g->types[f], &g->ns[f], &g->cons[f], tmp, tprm);
         if (g->rets[f] == LNN_OK)                   /* RAW / SILENT carry PCM: straight to the caller's planes */
             for (ch = 0; ch < C; ch++) memcpy(j->buffer[ch] + g->prog[f], tmp + (size_t)ch * S, sizeof(int32_t) * g->ns[f]);
     }
@@ -543,12 +543,12 @@ static int dgroup_alloc(struct dgroup *g, uint32_t n)
     memset(g, 0, sizeof(*g));
     g->offs = malloc(sizeof(*g->offs) * n); g->avail = malloc(sizeof(*g->avail) * n); g->room = malloc(sizeof(uint32_t) * n);
     g->types = malloc(sizeof(uint32_t) * n); g->ns = malloc(sizeof(uint32_t) * n); g->prog = malloc(sizeof(uint32_t) * n);
-    g->cidx = malloc(sizeof(uint32_t) * n); g->cn = malloc(sizeof(uint32_t) * n); g->rets = malloc(sizeof(int) * n);
-    return (g->offs && g->avail && g->room && g->types && g->ns && g->prog && g->cidx && g->cn && g->rets) ? 0 : -1;
+    g->cidx = malloc(sizeof(uint32_t) * n); g->cn = malloc(sizeof(uint32_t) * n); g->rets = malloc(sizeof(int) * n); g->cons = malloc(sizeof(uint32_t) * n);
+    return (g->offs && g->avail && g->room && g->types && g->ns && g->prog && g->cidx && g->cn && g->rets && g->cons) ? 0 : -1;
 }
 static void dgroup_free(struct dgroup *g)
 {
-    free(g->offs); free(g->avail); free(g->room); free(g->types); free(g->ns); free(g->prog); free(g->cidx); free(g->cn); free(g->rets);
+    free(g->offs); free(g->avail); free(g->room); free(g->types); free(g->ns); free(g->prog); free(g->cidx); free(g->cn); free(g->rets); free(g->cons);
 }
 
 LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint8_t *data, uint32_t data_size,
@@ -608,7 +608,17 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
             t0 = now_s();
             lnn_parallel_for(g->nblk, threads, unpack_blocks, &uj);
             t_parse += now_s() - t0;
-            for (f = 0; f < g->nblk; f++) if (g->rets[f] != LNN_OK) { ret = g->rets[f]; g->nblk = f; scanning = 0; break; }    /* first failing block wins */
+            for (f = 0; f < g->nblk; f++) {
+                if (g->rets[f] != LNN_OK) { ret = g->rets[f]; g->nblk = f; scanning = 0; break; }    /* first failing block wins */
+                /* The scan above trusted the blocks' size fields (that is what lets the host threads parse a group in parallel);
+                 * the reference steps by the bytes its bit reader actually consumed (linne_decoder.c:725-733).  They differ only
+                 * in a damaged stream (CRC check off): the blocks behind such a block were located wrongly -- drop them and scan
+                 * on from where the reference would. */
+                if (f + 1 < g->nblk ? (g->offs[f] + g->cons[f] != g->offs[f + 1]) : (g->offs[f] + g->cons[f] != off)) {
+                    g->nblk = f + 1; off = g->offs[f] + g->cons[f];
+                    break;
+                }
+            }
             g->ncomp = 0;
             for (f = 0; f < g->nblk; f++) {
                 if (g->types[f] == LNN_BLOCK_COMPRESS) g->cn[g->ncomp++] = g->ns[f];

@@ -405,13 +405,16 @@ static int rice_encode(struct bitw *w, const int32_t *data, uint32_t n, struct r
     return 0;
 }
 
-/* returns 0, or -1 for a header no encoder writes (partition order beyond the maximum, a parameter step whose gamma code
- * is longer than 32 digits): only a damaged stream read with the CRC check off gets here */
+/* returns 0, or -1 where the reference's own behaviour is undefined (a partition order of 32 or more: `1 << order`,
+ * linne_coder.c:313; a parameter step whose gamma code is longer than 32 digits: a 33-bit read): only a damaged stream read
+ * with the CRC check off gets here.  Orders 11 .. 31, which no encoder writes, ARE defined in the reference -- 2^order
+ * partitions of n >> order samples (possibly none), each with its parameter step -- and are decoded the same way here
+ * (tests/golden/corrupt_decode.json). */
 static int rice_decode(struct bitr *r, int32_t *data, uint32_t n)
 {
-    const uint32_t order = br_get(r, RICE_LOG2_PARTS), ns = (order <= RICE_LOG2_PARTS) ? (n >> order) : 0u;
+    const uint32_t order = br_get(r, RICE_LOG2_PARTS), ns = (order <= 31u) ? (n >> order) : 0u;
     uint32_t part, s, k2 = 0;
-    if (order > RICE_LOG2_PARTS) return -1;
+    if (order > 31u) return -1;
     for (part = 0; part < (1u << order); part++) {
         if (br_pos_over(r)) return 0;
         if (part == 0) k2 = br_get(r, 5);

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Generates tests/golden/corrupt_decode.json: what the REAL reference decoder (oracle/_ref, CRC check off) makes of 60
 deterministically damaged copies of one .lnn stream -- its result code and, where it returns OK, the sha256 of the PCM.
-The reference has undefined behaviour on some damaged streams (it can crash), so every trial runs in a child process;
-crashed trials are recorded as such and skipped by the test.  Run here (needs oracle/_ref); the fixture travels.
+The reference has undefined behaviour on some damaged streams (reads past the end of the data, shifts by 32 or more, wild
+partition orders), so every trial runs in a child process: oracle/_ref/ref_decode_san, the reference decoder built with
+AddressSanitizer + UBSan.  A sanitizer report marks the trial "undefined" (skipped by the test); the others carry the result
+code and an FNV-1a-64 of the decoded planes.  Run here (needs oracle/_ref); the fixture travels.
 
     python tests/golden/make_corrupt_golden.py
 """
@@ -35,19 +37,18 @@ def damaged(good, rng):
     return bytes(bad)
 
 
-CHILD = r"""
-import sys, hashlib, json
-sys.path.insert(0, %r)
-import numpy as np
-from refs import Reference
-data = open(sys.argv[1], 'rb').read()
-ret, pcm = Reference().decode_whole(data, check_crc=0)
-print(json.dumps({"ret": int(ret), "sha256": hashlib.sha256(np.ascontiguousarray(pcm).tobytes()).hexdigest()}))
-"""
+def fnv_planes(pcm):
+    """FNV-1a-64 over the int32 planes, little-endian bytes, channel after channel (what oracle/ref_decode_san.c prints)"""
+    import numpy as np
+    h = 0xcbf29ce484222325
+    for byte in np.ascontiguousarray(pcm, dtype="<i4").tobytes():
+        h = ((h ^ byte) * 0x100000001b3) & 0xFFFFFFFFFFFFFFFF
+    return "%016x" % h
 
 
 def main():
     from refs import Reference
+    san = os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle", "_ref", "ref_decode_san")
     x, rng = stream_and_damage()
     good = Reference().encode_whole(x, 16, 44100, 2048, 7, True)
     out = {"good_sha256": hashlib.sha256(good).hexdigest(), "trials": []}
@@ -55,15 +56,17 @@ def main():
     for t in range(NTRIALS):
         bad = damaged(good, rng)
         open(tmp, "wb").write(bad)
-        r = subprocess.run([sys.executable, "-c", CHILD % os.path.dirname(HERE), tmp], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
-        if r.returncode != 0:
-            out["trials"].append({"ret": None, "crashed": True})
-        else:
-            out["trials"].append(json.loads(r.stdout.strip().splitlines()[-1]))
+        # the reference decoder under ASan + UBSan (shift exponents, bounds): a sanitizer report = the result is undefined
+        r = subprocess.run([san, tmp], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+        if r.returncode != 0 or not r.stdout.startswith("ret "):
+            out["trials"].append({"defined": False, "why": ([l for l in r.stderr.strip().splitlines() if "ERROR" in l or "runtime error" in l] or ["crash"])[0][:200]})
+            continue
+        parts = r.stdout.split()
+        out["trials"].append({"defined": True, "ret": int(parts[1]), "fnv": parts[3]})
     os.remove(tmp)
     json.dump(out, open(os.path.join(HERE, "corrupt_decode.json"), "w"), indent=1)
     ok = sum(1 for t in out["trials"] if t.get("ret") == 0)
-    print(f"{ok} of {NTRIALS} damaged streams decode OK in the reference, {sum(1 for t in out['trials'] if t.get('crashed'))} crash it")
+    print(f"{ok} of {NTRIALS} damaged streams decode OK with defined behaviour, {sum(1 for t in out['trials'] if not t['defined'])} are undefined in the reference")
 
 
 if __name__ == "__main__":

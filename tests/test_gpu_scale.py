@@ -190,10 +190,10 @@ def many_tracks(big, ntracks, per_track, tail):
 
 
 def test_many_tracks_in_one_call_keep_the_fast_kernels(oracle, big):
-    """64 tracks x (50 full + tail 2000) in ONE EncodeFramesDevice call (tools/linne_codec/linne_codec.c:133-161 per track):
+    """64 tracks x (49 full + tail 2000) in ONE EncodeFramesDevice call (tools/linne_codec/linne_codec.c:133-161 per track):
     the host sorts the frames by length class, so the batch has two class runs and the lanes = jobs kernels serve the full
     frames exactly as in the single-track run; bytes equal the oracle's on a sample that holds every tail"""
-    ntracks, per = 64, 51
+    ntracks, per = 64, 50
     frames, ns = many_tracks(big, ntracks, per, 2000)
     F = ntracks * per
     c = linne_amd.Context(0, scratch_bytes=8 << 30, use_torch_stream=False)
