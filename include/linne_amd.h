@@ -144,6 +144,32 @@ int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_sam
 int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
 int LINNEAmd_SlotWait(struct LINNEAmdSlot *slot);
 
+/* Several GPUs from ONE process (the "direct per-GPU H2D/D2H" transport).  The reference has nothing like
+ * it: its caller loops over blocks in one thread (tools/linne_codec/linne_codec.c:133-161).  Frames are independent on this path
+ * (linne_encoder.c:637), so a batch on host memory is cut into groups of group_frames frames (0 = a default that gives every
+ * device a few throughput-sized groups), group g goes to device g mod G, one host thread per device drives that device's staging
+ * slots -- H2D and D2H on each GPU's own PCIe link, two or three groups in flight per device -- and the results land in the
+ * caller's arrays in the caller's frame order.  No data ever moves between GPUs.
+ *   devices == NULL / num_devices == 0: LINNE_AMD_DEVICES="0,1,..." if set, else every visible device.  The same device may be
+ *   listed more than once (two contexts on one GPU: what the one-GPU tests do).
+ * The whole-stream API functions (LINNEEncoder_EncodeWhole / LINNEDecoder_DecodeWhole) fan out the same way when
+ * LINNE_AMD_DEVICES names several devices; their .lnn bytes do not depend on it. */
+struct LINNEAmdMulti;
+struct LINNEAmdMulti *LINNEAmd_MultiCreate(const int *devices, uint32_t num_devices, uint64_t scratch_bytes_per_device);
+void LINNEAmd_MultiDestroy(struct LINNEAmdMulti *multi);
+uint32_t LINNEAmd_MultiNumDevices(const struct LINNEAmdMulti *multi);
+int LINNEAmd_MultiDevice(const struct LINNEAmdMulti *multi, uint32_t index);                       /* HIP device id of member `index`, -1 if out of range */
+struct LINNEAmdContext *LINNEAmd_MultiContext(struct LINNEAmdMulti *multi, uint32_t index);       /* the member's context (timing, telemetry) */
+const char *LINNEAmd_MultiGetLastError(const struct LINNEAmdMulti *multi);
+/* pcm / residual [F][C][S], params [F][C][LINNE_AMD_PARAM_WORDS], stats [F][C][LINNE_AMD_STAT_WORDS] on the host;
+ * rice_plan (may be NULL) [F][C][LINNE_AMD_RICE_PLAN_BYTES].  Synchronous.  Returns LINNEApiResult. */
+int LINNEAmd_MultiEncodeFramesHost(struct LINNEAmdMulti *multi, const struct LINNEAmdShape *shape, const int32_t *pcm,
+        const uint32_t *num_samples, uint32_t num_frames, int32_t *residual, int32_t *params, double *stats, uint8_t *rice_plan,
+        uint32_t group_frames);
+/* in place: data holds the residual on entry, PCM on return */
+int LINNEAmd_MultiDecodeFramesHost(struct LINNEAmdMulti *multi, const struct LINNEAmdShape *shape, int32_t *data,
+        const uint32_t *num_samples, uint32_t num_frames, const int32_t *params, uint32_t group_frames);
+
 /* Number of (job, layer) unit-count searches of the last EncodeFramesDevice call that the certified order-free
  * search could not decide and that therefore ran the exact ordered sums (synchronises; -1 on error). */
 int64_t LINNEAmd_GetLastFallbackCount(struct LINNEAmdContext *ctx);

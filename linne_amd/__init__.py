@@ -40,7 +40,8 @@ AMD_SYMBOLS = [
     "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
-    "LINNEAmd_GetLastMinMargin", "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
+    "LINNEAmd_GetLastMinMargin", "LINNEAmd_MultiCreate", "LINNEAmd_MultiDestroy", "LINNEAmd_MultiNumDevices", "LINNEAmd_MultiDevice",
+    "LINNEAmd_MultiContext", "LINNEAmd_MultiGetLastError", "LINNEAmd_MultiEncodeFramesHost", "LINNEAmd_MultiDecodeFramesHost", "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
     "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
 ]
 
@@ -92,6 +93,19 @@ def _load():
     L.LINNEAmd_PackFramesPlanned.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     L.LINNEAmd_RicePlanDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.LINNEAmd_MultiCreate.restype = C.c_void_p
+    L.LINNEAmd_MultiCreate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    L.LINNEAmd_MultiDestroy.argtypes = [C.c_void_p]
+    L.LINNEAmd_MultiNumDevices.restype = C.c_uint32
+    L.LINNEAmd_MultiNumDevices.argtypes = [C.c_void_p]
+    L.LINNEAmd_MultiDevice.argtypes = [C.c_void_p, C.c_uint32]
+    L.LINNEAmd_MultiContext.restype = C.c_void_p
+    L.LINNEAmd_MultiContext.argtypes = [C.c_void_p, C.c_uint32]
+    L.LINNEAmd_MultiGetLastError.restype = C.c_char_p
+    L.LINNEAmd_MultiGetLastError.argtypes = [C.c_void_p]
+    L.LINNEAmd_MultiEncodeFramesHost.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_uint32]
+    L.LINNEAmd_MultiDecodeFramesHost.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
     return L
 
 
@@ -218,6 +232,62 @@ class Context:
         ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
         self._check(lib.LINNEAmd_DecodeFramesHost(self.h, C.byref(shape), d.ctypes.data, ns.ctypes.data if ns is not None else None,
                                                   d.shape[0], prm.ctypes.data), "DecodeFramesHost")
+        return d
+
+
+class Multi:
+    """Several GPUs from one process (include/linne_amd.h LINNEAmd_Multi*): groups of frames fan out round-robin over per-GPU
+    contexts, each GPU fed over its own PCIe link; host numpy arrays in and out, the caller's frame order kept."""
+
+    def __init__(self, devices=None, scratch_bytes=0):
+        if devices:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            self.h = lib.LINNEAmd_MultiCreate(arr, len(devices), int(scratch_bytes))
+        else:
+            self.h = lib.LINNEAmd_MultiCreate(None, 0, int(scratch_bytes))
+        if not self.h:
+            raise LinneAmdError(f"LINNEAmd_MultiCreate({devices}) failed: no usable HIP device (there is no CPU fallback)")
+
+    @property
+    def num_devices(self):
+        return int(lib.LINNEAmd_MultiNumDevices(self.h))
+
+    def close(self):
+        if getattr(self, "h", None) and lib is not None:
+            lib.LINNEAmd_MultiDestroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, ret, what):
+        if ret != 0:
+            raise LinneAmdError(f"{what} -> {ret}: {lib.LINNEAmd_MultiGetLastError(self.h).decode()}")
+
+    def encode_frames_host(self, shape, pcm, num_samples=None, group_frames=0, want_plan=False, out=None):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int32)
+        F, Cn, S = pcm.shape
+        if out is None:
+            res = np.empty_like(pcm)
+            prm = np.zeros((F, Cn, PARAM_WORDS), dtype=np.int32)
+            st = np.zeros((F, Cn, STAT_WORDS), dtype=np.float64)
+        else:
+            res, prm, st = out
+        plan = np.zeros((F, Cn, RICE_PLAN_BYTES), dtype=np.uint8) if want_plan else None
+        ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+        self._check(lib.LINNEAmd_MultiEncodeFramesHost(self.h, C.byref(shape), pcm.ctypes.data, ns.ctypes.data if ns is not None else None, F,
+                                                       res.ctypes.data, prm.ctypes.data, st.ctypes.data,
+                                                       plan.ctypes.data if plan is not None else None, int(group_frames)), "MultiEncodeFramesHost")
+        return (res, prm, st, plan) if want_plan else (res, prm, st)
+
+    def decode_frames_host(self, shape, residual, params, num_samples=None, group_frames=0, in_place=False):
+        d = np.ascontiguousarray(residual, dtype=np.int32)
+        if not in_place:
+            d = d.copy()
+        prm = np.ascontiguousarray(params, dtype=np.int32)
+        ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+        self._check(lib.LINNEAmd_MultiDecodeFramesHost(self.h, C.byref(shape), d.ctypes.data, ns.ctypes.data if ns is not None else None,
+                                                       d.shape[0], prm.ctypes.data, int(group_frames)), "MultiDecodeFramesHost")
         return d
 
 

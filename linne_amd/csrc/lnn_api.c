@@ -66,31 +66,53 @@ static uint32_t default_group(uint32_t num_frames)
     if (n > 4096) n = 4096;
     return (uint32_t)n;
 }
-static void drop_slots(struct LINNEAmdSlot **slot)
+/* The GPUs of a handle: LINNE_AMD_DEVICES="0,1,..." (whole streams fan out over them: group g of frames goes to device
+ * g mod G), else LINNE_AMD_DEVICE (one device), else device 0.  Block-at-a-time calls use the first one. */
+struct lnn_gpus {
+    uint32_t ndev; int device[LNN_MAX_DEVICES];
+    struct LINNEAmdContext *ctx[LNN_MAX_DEVICES];
+    struct LINNEAmdSlot *slot[LNN_MAX_DEVICES][LNN_SLOTS];      /* whole-stream staging (pinned + device), created at the first Whole call */
+    struct LINNEAmdShape slot_shape; uint32_t slot_frames;
+};
+static void drop_slots(struct lnn_gpus *g)
 {
-    uint32_t i;
-    for (i = 0; i < LNN_SLOTS; i++) { if (slot[i]) LINNEAmd_SlotDestroy(slot[i]); slot[i] = NULL; }
+    uint32_t d, i;
+    for (d = 0; d < LNN_MAX_DEVICES; d++)
+        for (i = 0; i < LNN_SLOTS; i++) { if (g->slot[d][i]) LINNEAmd_SlotDestroy(g->slot[d][i]); g->slot[d][i] = NULL; }
 }
-/* (re)creates the staging slots of a handle for `frames` frames per slot; keeps what already fits */
-static int want_slots(struct LINNEAmdContext *ctx, struct LINNEAmdSlot **slot, struct LINNEAmdShape *have_shape, uint32_t *have_frames,
-        const struct LINNEAmdShape *shape, uint32_t frames, uint32_t count, int for_encode)
+/* (re)creates the staging slots of a handle for `frames` frames per slot, `count` per device; keeps what already fits */
+static int want_slots(struct lnn_gpus *g, const struct LINNEAmdShape *shape, uint32_t frames, uint32_t count, int for_encode)
 {
-    uint32_t i;
-    if (memcmp(have_shape, shape, sizeof(*shape)) != 0 || *have_frames < frames) { drop_slots(slot); *have_shape = *shape; *have_frames = frames; }
-    for (i = 0; i < count && i < LNN_SLOTS; i++)
-        if (!slot[i] && !(slot[i] = LINNEAmd_SlotCreate(ctx, shape, *have_frames, for_encode))) return LNN_NG;
+    uint32_t d, i;
+    if (memcmp(&g->slot_shape, shape, sizeof(*shape)) != 0 || g->slot_frames < frames) { drop_slots(g); g->slot_shape = *shape; g->slot_frames = frames; }
+    for (d = 0; d < g->ndev; d++)
+        for (i = 0; i < count && i < LNN_SLOTS; i++)
+            if (!g->slot[d][i] && !(g->slot[d][i] = LINNEAmd_SlotCreate(g->ctx[d], shape, g->slot_frames, for_encode))) return (int)d + 1;
+    return 0;
+}
+/* opens the first device (block-at-a-time calls) or all of them (whole streams) */
+static int open_gpus(struct lnn_gpus *g, const char *who, int all)
+{
+    uint32_t d;
+    if (g->ndev == 0) {
+        g->ndev = lnn_parse_device_list(getenv("LINNE_AMD_DEVICES"), g->device, LNN_MAX_DEVICES);
+        if (g->ndev == 0) { const char *e = getenv("LINNE_AMD_DEVICE"); g->device[0] = e ? atoi(e) : 0; g->ndev = 1; }
+    }
+    for (d = 0; d < (all ? g->ndev : 1u); d++) {
+        if (g->ctx[d]) continue;
+        g->ctx[d] = LINNEAmd_ContextCreate(g->device[d], 256ull << 20);
+        if (!g->ctx[d]) {
+            fprintf(stderr, "liblinne_amd: %s: no usable HIP device %d (LINNE_AMD_DEVICES / LINNE_AMD_DEVICE); the prediction path has no CPU fallback\n", who, g->device[d]);
+            return LNN_NG;
+        }
+    }
     return LNN_OK;
 }
-static int default_device(void)
+static void close_gpus(struct lnn_gpus *g)
 {
-    const char *e = getenv("LINNE_AMD_DEVICE");
-    return e ? atoi(e) : 0;
-}
-static struct LINNEAmdContext *open_context(const char *who)
-{
-    struct LINNEAmdContext *ctx = LINNEAmd_ContextCreate(default_device(), 256ull << 20);
-    if (!ctx) fprintf(stderr, "liblinne_amd: %s: no usable HIP device (LINNE_AMD_DEVICE=%d); the prediction path has no CPU fallback\n", who, default_device());
-    return ctx;
+    uint32_t d;
+    drop_slots(g);
+    for (d = 0; d < LNN_MAX_DEVICES; d++) if (g->ctx[d]) { LINNEAmd_ContextDestroy(g->ctx[d]); g->ctx[d] = NULL; }
 }
 
 static void put_be16(uint8_t *p, uint32_t v) { p[0] = (uint8_t)(v >> 8); p[1] = (uint8_t)v; }
@@ -117,12 +139,10 @@ struct LINNEEncoder {
     void *work;
     struct LINNEAmdShape shape;
     struct lnn_layers layers;
-    struct LINNEAmdContext *ctx;        /* GPU resources: outside the work area, released by Destroy */
+    struct lnn_gpus gpus;               /* GPU resources: outside the work area, released by Destroy */
     double parcor_state;                /* oracle quirk Q2, carried from block to block */
     int32_t *pcm, *residual, *params;   /* one-frame staging, inside the work area */
     double *stats;
-    struct LINNEAmdSlot *slot[LNN_SLOTS];   /* whole-stream staging (pinned + device), created at the first EncodeWhole */
-    struct LINNEAmdShape slot_shape; uint32_t slot_frames;
 };
 
 LINNEApiResult LINNEEncoder_EncodeHeader(const struct LINNEHeader *header, uint8_t *data, uint32_t data_size)
@@ -197,8 +217,7 @@ struct LINNEEncoder *LINNEEncoder_Create(const struct LINNEEncoderConfig *config
 void LINNEEncoder_Destroy(struct LINNEEncoder *encoder)
 {
     if (encoder == NULL) return;
-    drop_slots(encoder->slot);
-    if (encoder->ctx) { LINNEAmd_ContextDestroy(encoder->ctx); encoder->ctx = NULL; }
+    close_gpus(&encoder->gpus);
     if (encoder->alloced_by_own == 1) free(encoder->work);
 }
 
@@ -236,10 +255,9 @@ LINNEApiResult LINNEEncoder_SetEncodeParameter(struct LINNEEncoder *encoder, con
     return LINNE_APIRESULT_OK;
 }
 
-static LINNEApiResult encoder_device(struct LINNEEncoder *enc)
+static LINNEApiResult encoder_device(struct LINNEEncoder *enc, int all)
 {
-    if (enc->ctx == NULL) enc->ctx = open_context("LINNEEncoder");
-    return enc->ctx ? LINNE_APIRESULT_OK : LINNE_APIRESULT_NG;
+    return open_gpus(&enc->gpus, "LINNEEncoder", all) == LNN_OK ? LINNE_APIRESULT_OK : LINNE_APIRESULT_NG;
 }
 static void report(const struct LINNEAmdContext *ctx, const char *what, int ret)
 {
@@ -254,15 +272,15 @@ LINNEApiResult LINNEEncoder_EncodeBlock(struct LINNEEncoder *encoder, const int3
     if (encoder == NULL || input == NULL || num_samples == 0 || data == NULL || data_size == 0 || output_size == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if (encoder->set_parameter != 1) return LINNE_APIRESULT_PARAMETER_NOT_SET;
     if (num_samples > encoder->header.num_samples_per_block) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
-    if (encoder_device(encoder) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
+    if (encoder_device(encoder, 0) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
     S = encoder->shape.num_samples_per_block; C = encoder->shape.num_channels;
     for (ch = 0; ch < C; ch++) {
         if (input[ch] == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
         memcpy(encoder->pcm + (size_t)ch * S, input[ch], sizeof(int32_t) * num_samples);
         if (num_samples < S) memset(encoder->pcm + (size_t)ch * S + num_samples, 0, sizeof(int32_t) * (S - num_samples));
     }
-    ret = LINNEAmd_EncodeFramesHost(encoder->ctx, &encoder->shape, encoder->pcm, &num_samples, 1, encoder->residual, encoder->params, encoder->stats);
-    if (ret != LNN_OK) { report(encoder->ctx, "EncodeFramesHost", ret); return (LINNEApiResult)ret; }
+    ret = LINNEAmd_EncodeFramesHost(encoder->gpus.ctx[0], &encoder->shape, encoder->pcm, &num_samples, 1, encoder->residual, encoder->params, encoder->stats);
+    if (ret != LNN_OK) { report(encoder->gpus.ctx[0], "EncodeFramesHost", ret); return (LINNEApiResult)ret; }
     ret = LINNEAmd_PackFrames(&encoder->shape, encoder->pcm, &num_samples, 1, encoder->residual, encoder->params, encoder->stats,
             data, data_size, output_size, &encoder->parcor_state, 1);
     return (LINNEApiResult)ret;
@@ -291,7 +309,8 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
         uint8_t *data, uint32_t data_size, uint32_t *output_size)
 {
     LINNEApiResult r;
-    uint32_t S, C, F, f, ch, group, ngroups, nslots, submitted = 0, packed = 0;
+    uint32_t S, C, F, f, ch, group, ngroups, nslots, window, ndev, submitted = 0, packed = 0;
+    struct lnn_gpus *gp;
     uint64_t off = LINNE_HEADER_SIZE;
     uint32_t *nsm = NULL, *sizes = NULL;
     const uint32_t threads = default_threads();
@@ -303,42 +322,45 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
     if ((r = LINNEEncoder_EncodeHeader(&encoder->header, data, data_size)) != LINNE_APIRESULT_OK) return r;
     S = encoder->shape.num_samples_per_block; C = encoder->shape.num_channels;
     for (ch = 0; ch < C; ch++) if (input[ch] == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
-    if (encoder_device(encoder) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
+    if (encoder_device(encoder, 1) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
+    gp = &encoder->gpus; ndev = gp->ndev;
     t_begin = now_s();
     F = (uint32_t)(((uint64_t)num_samples + S - 1) / S);
-    group = default_group(F); if (group > F) group = F;
+    group = default_group((F + ndev - 1) / ndev); if (group > F) group = F;
     ngroups = (F + group - 1) / group;
-    nslots = (ngroups < LNN_SLOTS) ? ngroups : LNN_SLOTS;
-    if (F > 32) (void)LINNEAmd_ReserveScratch(encoder->ctx, 2ull << 30);
-    if (want_slots(encoder->ctx, encoder->slot, &encoder->slot_shape, &encoder->slot_frames, &encoder->shape, group, nslots, 1) != LNN_OK) {
-        report(encoder->ctx, "SlotCreate", LNN_NG); return LINNE_APIRESULT_NG;
+    /* group g goes to device g mod ndev, slot (g / ndev) mod nslots of that device: ndev * nslots groups in flight */
+    nslots = (ngroups + ndev - 1) / ndev; if (nslots > LNN_SLOTS) nslots = LNN_SLOTS;
+    window = ndev * nslots;
+    if (F > 32) for (f = 0; f < ndev; f++) (void)LINNEAmd_ReserveScratch(gp->ctx[f], 2ull << 30);
+    if ((ret = want_slots(gp, &encoder->shape, group, nslots, 1)) != 0) {
+        report(gp->ctx[ret - 1], "SlotCreate", LNN_NG); return LINNE_APIRESULT_NG;
     }
-    nsm = malloc(sizeof(uint32_t) * (size_t)group * LNN_SLOTS); sizes = malloc(sizeof(uint32_t) * group);
+    nsm = malloc(sizeof(uint32_t) * (size_t)group * window); sizes = malloc(sizeof(uint32_t) * group);
     if (!nsm || !sizes) { ret = LNN_NG; goto done; }
     t_setup = now_s() - t_begin;
     while (packed < ngroups) {
-        while (submitted < ngroups && submitted - packed < nslots) {
-            struct LINNEAmdSlot *sl = encoder->slot[submitted % nslots];
+        while (submitted < ngroups && submitted - packed < window) {
+            struct LINNEAmdSlot *sl = gp->slot[submitted % ndev][(submitted / ndev) % nslots];
             struct fill_job fj;
             const uint32_t base = submitted * group, cnt = (F - base < group) ? (F - base) : group;
-            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.nsm = nsm + (size_t)(submitted % nslots) * group;
+            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.nsm = nsm + (size_t)(submitted % window) * group;
             fj.C = C; fj.S = S; fj.num_samples = num_samples; fj.base = base;
             t0 = now_s();
             lnn_parallel_for(cnt, threads, fill_frames, &fj);
             t_fill += now_s() - t0; t0 = now_s();
             ret = LINNEAmd_SlotEncodeSubmit(sl, fj.nsm, cnt);
             t_submit += now_s() - t0;
-            if (ret != LNN_OK) { report(encoder->ctx, "SlotEncodeSubmit", ret); goto done; }
+            if (ret != LNN_OK) { report(gp->ctx[submitted % ndev], "SlotEncodeSubmit", ret); goto done; }
             submitted++;
         }
         {
-            struct LINNEAmdSlot *sl = encoder->slot[packed % nslots];
+            struct LINNEAmdSlot *sl = gp->slot[packed % ndev][(packed / ndev) % nslots];
             const uint32_t base = packed * group, cnt = (F - base < group) ? (F - base) : group;
             t0 = now_s();
             ret = LINNEAmd_SlotWait(sl);
             t_wait += now_s() - t0; t0 = now_s();
-            if (ret != LNN_OK) { report(encoder->ctx, "SlotWait", ret); goto done; }
-            ret = LINNEAmd_PackFramesPlanned(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % nslots) * group, cnt,
+            if (ret != LNN_OK) { report(gp->ctx[packed % ndev], "SlotWait", ret); goto done; }
+            ret = LINNEAmd_PackFramesPlanned(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % window) * group, cnt,
                     LINNEAmd_SlotData(sl), LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), LINNEAmd_SlotRicePlan(sl),
                     data + off, data_size - off, sizes, &encoder->parcor_state, threads);
             t_pack += now_s() - t0;
@@ -348,10 +370,10 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
         }
     }
     *output_size = (uint32_t)off;
-    if (trace_on()) fprintf(stderr, "liblinne_amd: EncodeWhole %u frames, %u threads: setup %.1f ms, fill %.1f, submit %.1f, wait %.1f, pack %.1f, total %.1f ms\n",
-            F, threads, t_setup * 1e3, t_fill * 1e3, t_submit * 1e3, t_wait * 1e3, t_pack * 1e3, (now_s() - t_begin) * 1e3);
+    if (trace_on()) fprintf(stderr, "liblinne_amd: EncodeWhole %u frames, %u GPU(s), %u threads: setup %.1f ms, fill %.1f, submit %.1f, wait %.1f, pack %.1f, total %.1f ms\n",
+            F, ndev, threads, t_setup * 1e3, t_fill * 1e3, t_submit * 1e3, t_wait * 1e3, t_pack * 1e3, (now_s() - t_begin) * 1e3);
 done:
-    for (f = 0; f < LNN_SLOTS; f++) if (encoder->slot[f]) (void)LINNEAmd_SlotWait(encoder->slot[f]);
+    for (ch = 0; ch < LNN_MAX_DEVICES; ch++) for (f = 0; f < LNN_SLOTS; f++) if (encoder->gpus.slot[ch][f]) (void)LINNEAmd_SlotWait(encoder->gpus.slot[ch][f]);
     free(nsm); free(sizes);
     return (LINNEApiResult)ret;
 }
@@ -364,11 +386,9 @@ struct LINNEDecoder {
     void *work;
     struct LINNEAmdShape shape;
     struct lnn_layers layers;
-    struct LINNEAmdContext *ctx;
+    struct lnn_gpus gpus;
     int32_t *samples; uint64_t samples_cap;     /* one-frame staging (heap: the block size is unknown at Create) */
     int32_t *params;                            /* inside the work area */
-    struct LINNEAmdSlot *slot[LNN_SLOTS];       /* whole-stream staging, created at the first DecodeWhole */
-    struct LINNEAmdShape slot_shape; uint32_t slot_frames;
 };
 
 LINNEApiResult LINNEDecoder_DecodeHeader(const uint8_t *data, uint32_t data_size, struct LINNEHeader *header)
@@ -429,8 +449,7 @@ struct LINNEDecoder *LINNEDecoder_Create(const struct LINNEDecoderConfig *config
 void LINNEDecoder_Destroy(struct LINNEDecoder *decoder)
 {
     if (decoder == NULL) return;
-    drop_slots(decoder->slot);
-    if (decoder->ctx) { LINNEAmd_ContextDestroy(decoder->ctx); decoder->ctx = NULL; }
+    close_gpus(&decoder->gpus);
     free(decoder->samples); decoder->samples = NULL;
     if (decoder->alloced_by_own) free(decoder->work);
 }
@@ -455,10 +474,9 @@ LINNEApiResult LINNEDecoder_SetHeader(struct LINNEDecoder *decoder, const struct
     return LINNE_APIRESULT_OK;
 }
 
-static LINNEApiResult decoder_device(struct LINNEDecoder *dec)
+static LINNEApiResult decoder_device(struct LINNEDecoder *dec, int all)
 {
-    if (dec->ctx == NULL) dec->ctx = open_context("LINNEDecoder");
-    return dec->ctx ? LINNE_APIRESULT_OK : LINNE_APIRESULT_NG;
+    return open_gpus(&dec->gpus, "LINNEDecoder", all) == LNN_OK ? LINNE_APIRESULT_OK : LINNE_APIRESULT_NG;
 }
 
 LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint8_t *data, uint32_t data_size,
@@ -483,9 +501,9 @@ LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint
             &type, &n, &consumed, decoder->samples, decoder->params);
     if (ret != LNN_OK) return (LINNEApiResult)ret;
     if (type == LNN_BLOCK_COMPRESS) {
-        if (decoder_device(decoder) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
-        ret = LINNEAmd_DecodeFramesHost(decoder->ctx, &decoder->shape, decoder->samples, &n, 1, decoder->params);
-        if (ret != LNN_OK) { report(decoder->ctx, "DecodeFramesHost", ret); return (LINNEApiResult)ret; }
+        if (decoder_device(decoder, 0) != LINNE_APIRESULT_OK) return LINNE_APIRESULT_NG;
+        ret = LINNEAmd_DecodeFramesHost(decoder->gpus.ctx[0], &decoder->shape, decoder->samples, &n, 1, decoder->params);
+        if (ret != LNN_OK) { report(decoder->gpus.ctx[0], "DecodeFramesHost", ret); return (LINNEApiResult)ret; }
     }
     for (ch = 0; ch < C; ch++) memcpy(buffer[ch], decoder->samples + (size_t)ch * S, sizeof(int32_t) * n);
     *decode_size = consumed;
@@ -557,9 +575,10 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     LINNEApiResult r;
     struct LINNEHeader h;
     const struct LINNEHeader *hd;
-    struct dgroup grp[LNN_SLOTS];
+    struct dgroup grp[LNN_MAX_DEVICES * LNN_SLOTS];
     struct unpack_job uj;
-    uint32_t group, f, produced = 0, consumed_groups = 0, progress = 0, i, ngalloc = 0;
+    struct lnn_gpus *gp = &decoder->gpus;
+    uint32_t group, f, produced = 0, consumed_groups = 0, progress = 0, i, ngalloc = 0, ndev = 1, window = LNN_SLOTS;
     const uint32_t threads = default_threads();
     uint64_t off;
     double t_begin = now_s(), t_parse = 0, t_submit = 0, t_wait = 0, t_scatter = 0, t0;
@@ -573,14 +592,17 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     {
         const uint32_t S = decoder->shape.num_samples_per_block;
         const uint32_t F = (uint32_t)(((uint64_t)hd->num_samples + S - 1) / S);
-        group = default_group(F); if (group > F) group = F ? F : 1;
+        /* group g of blocks goes to device g mod ndev, slot (g / ndev) mod LNN_SLOTS of that device */
+        if (gp->ndev == 0) { gp->ndev = lnn_parse_device_list(getenv("LINNE_AMD_DEVICES"), gp->device, LNN_MAX_DEVICES); if (gp->ndev == 0) { const char *e = getenv("LINNE_AMD_DEVICE"); gp->device[0] = e ? atoi(e) : 0; gp->ndev = 1; } }
+        ndev = gp->ndev; window = ndev * LNN_SLOTS;
+        group = default_group((F + ndev - 1) / ndev); if (group > F) group = F ? F : 1;
     }
-    for (ngalloc = 0; ngalloc < LNN_SLOTS; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
+    for (ngalloc = 0; ngalloc < window; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;
     off = LINNE_HEADER_SIZE;
     while (scanning || consumed_groups < produced) {
-        if (scanning && produced - consumed_groups < LNN_SLOTS && progress < hd->num_samples && off < data_size) {
-            struct dgroup *g = &grp[produced % LNN_SLOTS];
+        if (scanning && produced - consumed_groups < window && progress < hd->num_samples && off < data_size) {
+            struct dgroup *g = &grp[produced % window];
             struct LINNEAmdSlot *sl;
             uint32_t scan_progress = progress, ncomp = 0;
             g->nblk = 0;
@@ -598,12 +620,13 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
                 off += (uint64_t)bsize + 6;
             }
             if (ncomp) {
-                if (decoder_device(decoder) != LINNE_APIRESULT_OK) { ret = LNN_NG; goto done; }
-                if (want_slots(decoder->ctx, decoder->slot, &decoder->slot_shape, &decoder->slot_frames, &decoder->shape, group, LNN_SLOTS, 0) != LNN_OK) {
-                    report(decoder->ctx, "SlotCreate", LNN_NG); ret = LNN_NG; goto done;
+                int wret;
+                if (decoder_device(decoder, 1) != LINNE_APIRESULT_OK) { ret = LNN_NG; goto done; }
+                if ((wret = want_slots(gp, &decoder->shape, group, LNN_SLOTS, 0)) != 0) {
+                    report(gp->ctx[wret - 1], "SlotCreate", LNN_NG); ret = LNN_NG; goto done;
                 }
             }
-            sl = decoder->slot[produced % LNN_SLOTS];
+            sl = gp->slot[produced % ndev][(produced / ndev) % LNN_SLOTS];
             uj.g = g; uj.sdata = sl ? LINNEAmd_SlotData(sl) : NULL; uj.sprm = sl ? LINNEAmd_SlotParams(sl) : NULL;
             t0 = now_s();
             lnn_parallel_for(g->nblk, threads, unpack_blocks, &uj);
@@ -629,21 +652,21 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
                 t0 = now_s();
                 dret = LINNEAmd_SlotDecodeSubmit(sl, g->cn, g->ncomp);
                 t_submit += now_s() - t0;
-                if (dret != LNN_OK) { report(decoder->ctx, "SlotDecodeSubmit", dret); ret = dret; goto done; }
+                if (dret != LNN_OK) { report(gp->ctx[produced % ndev], "SlotDecodeSubmit", dret); ret = dret; goto done; }
             }
             produced++;
             continue;
         }
         scanning = 0;
         if (consumed_groups < produced) {
-            struct dgroup *g = &grp[consumed_groups % LNN_SLOTS];
-            struct LINNEAmdSlot *sl = decoder->slot[consumed_groups % LNN_SLOTS];
+            struct dgroup *g = &grp[consumed_groups % window];
+            struct LINNEAmdSlot *sl = gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % LNN_SLOTS];
             if (g->ncomp) {
                 int dret;
                 t0 = now_s();
                 dret = LINNEAmd_SlotWait(sl);
                 t_wait += now_s() - t0;
-                if (dret != LNN_OK) { report(decoder->ctx, "SlotWait", dret); ret = dret; goto done; }
+                if (dret != LNN_OK) { report(gp->ctx[consumed_groups % ndev], "SlotWait", dret); ret = dret; goto done; }
                 uj.g = g; uj.sdata = LINNEAmd_SlotData(sl); uj.sprm = NULL;
                 t0 = now_s();
                 lnn_parallel_for(g->nblk, threads, scatter_blocks, &uj);
@@ -656,7 +679,7 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     if (trace_on()) fprintf(stderr, "liblinne_amd: DecodeWhole %u threads: parse %.1f ms, submit %.1f, wait %.1f, scatter %.1f, total %.1f ms\n",
             threads, t_parse * 1e3, t_submit * 1e3, t_wait * 1e3, t_scatter * 1e3, (now_s() - t_begin) * 1e3);
 done:
-    for (i = 0; i < LNN_SLOTS; i++) if (decoder->slot[i]) (void)LINNEAmd_SlotWait(decoder->slot[i]);
+    for (f = 0; f < LNN_MAX_DEVICES; f++) for (i = 0; i < LNN_SLOTS; i++) if (gp->slot[f][i]) (void)LINNEAmd_SlotWait(gp->slot[f][i]);
     for (i = 0; i < ngalloc; i++) dgroup_free(&grp[i]);
     return (LINNEApiResult)ret;
 }

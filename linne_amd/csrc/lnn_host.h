@@ -16,6 +16,10 @@ struct lnn_layers {
     uint32_t num_regs; double regs[4];
 };
 
+#define LNN_MAX_DEVICES 16
+/* "0,1,2" -> device list (lnn_multi.c); returns the count, 0 when text is NULL or empty */
+uint32_t lnn_parse_device_list(const char *text, int *devices, uint32_t max);
+
 void lnn_tables_init(void);
 uint16_t lnn_crc16(const uint8_t *data, uint64_t size);
 int lnn_shape_layers(const struct LINNEAmdShape *shape, struct lnn_layers *out);

@@ -1,10 +1,26 @@
-"""Multi-GPU plumbing: one process per GPU, frames (or whole tracks) sharded with NO data-path collective.
+"""Multi-GPU data path, one process per GPU.
 
-Frames are independent on the prediction path: frame f goes to rank f mod world, each rank
-analyses its shard on its own GPU, and the only exchanges are control-plane ones -- a barrier around the timed
-region, a MAX over the ranks' elapsed times, and (for whole streams) a gather of the serialised blocks to rank 0,
-which interleaves them back into stream order.  torch.distributed is used for exactly that (backend "nccl" = RCCL
-on the GPU box, "gloo" in CPU tests).
+Frames are independent on the prediction path (libs/linne_encoder/src/linne_encoder.c:637: a block carries nothing over
+from the one before), so N GPUs never exchange anything DURING the analysis.  What `north_star` asks RCCL for is the step
+before and after it, when the batch lives on one GPU:
+
+    root GPU holds PCM [F][C][S]  --scatter-->  every rank analyses its chunks  --gather-->  root holds residual + params
+
+`ChunkExchange` is that exchange.  The batch is cut into chunks of `chunk_frames` frames; chunk c belongs to rank
+c mod G (round-robin).  Transfers are point-to-point `isend` / `irecv` issued in batches (`torch.distributed.
+batch_isend_irecv`: on the "nccl" backend -- RCCL on ROCm -- one batch is one ncclGroupStart / ncclSend / ncclRecv /
+ncclGroupEnd; xGMI is point-to-point, the root talks to its seven peers over seven separate links, and nothing here is a
+ring or an all-reduce).  The schedule is software-pipelined: while a rank analyses chunk k it already receives chunk k + 1
+and sends the results of chunk k - 1, so after the first chunk the links are hidden behind the kernels.  Both ends issue
+their operations in the same order per pair (S0 S1 R0 S2 R1 ... on the root, R0 R1 S0 R2 S1 ... on a peer), which is what
+RCCL needs to match them.  The root analyses its own chunks straight from / into the caller's tensors.
+
+The same class runs on "gloo" with CPU tensors (tests/test_sharding_gloo.py drives it with two ranks); the process
+function is whatever turns a chunk of inputs into a chunk of outputs -- LINNEAmd_EncodeFramesDevice on the GPU box.
+
+Serialising the gathered frames to .lnn happens on the root IN STREAM ORDER (linne_amd.pack_frames): the RAW / COMPRESS
+decision carries the reference's quirk Q2 from block to block (lnn_entropy.c lnn_decide_block_type), so it is replayed over
+the gathered statistics sequentially and the bytes equal the single-stream encoder's whatever the sharding.
 """
 import time
 
@@ -12,6 +28,119 @@ import time
 def shard_round_robin(num_items, rank, world):
     """indices of the items rank `rank` owns"""
     return list(range(rank, num_items, world))
+
+
+def chunk_ranges(num_frames, chunk_frames):
+    """[(first, count)] of the chunks of a batch"""
+    return [(f0, min(chunk_frames, num_frames - f0)) for f0 in range(0, num_frames, chunk_frames)]
+
+
+class ChunkExchange:
+    """Pipelined scatter -> process -> gather of frame chunks between a root rank and its peers.
+
+    in_specs / out_specs: [(trailing_shape, dtype)] of the per-frame arrays that travel out to the ranks and back, e.g.
+    encode: in = [((C, S), int32)], out = [((C, S), int32), ((C, 160), int32), ((C, 8), float64)].
+    """
+
+    def __init__(self, dist, num_frames, chunk_frames, in_specs, out_specs, device, root=0):
+        import torch
+        self.dist, self.torch = dist, torch
+        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.root, self.device = root, device
+        self.num_frames, self.chunk_frames = int(num_frames), int(chunk_frames)
+        self.chunks = chunk_ranges(self.num_frames, self.chunk_frames)
+        self.in_specs, self.out_specs = list(in_specs), list(out_specs)
+        self.rounds = (len(self.chunks) + self.world - 1) // self.world
+        self.bytes_per_frame_out = sum(self._nbytes(s, d) for s, d in self.in_specs)
+        self.bytes_per_frame_back = sum(self._nbytes(s, d) for s, d in self.out_specs)
+        if self.rank != root:       # double buffers of one chunk each
+            mk = lambda specs: [[torch.empty((self.chunk_frames,) + tuple(s), dtype=d, device=device) for s, d in specs] for _ in range(2)]
+            self.in_buf, self.out_buf = mk(self.in_specs), mk(self.out_specs)
+
+    def _nbytes(self, shape, dtype):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        return n * self.torch.empty((), dtype=dtype).element_size()
+
+    def chunk_of(self, rnd, rank):
+        c = rnd * self.world + rank
+        return c if c < len(self.chunks) else None
+
+    def _post(self, ops):
+        return self.dist.batch_isend_irecv(ops) if ops else []
+
+    def run(self, process, num_samples, root_inputs=None, root_outputs=None):
+        """process(inputs_chunk, num_samples_chunk, outputs_chunk) fills the output views from the input views.
+        On the root, root_inputs / root_outputs are the whole-batch tensors [F, ...]; elsewhere they are ignored."""
+        dist, P2POp = self.dist, (self.dist.P2POp if self.dist is not None else None)
+        R, G = self.rounds, self.world
+        if self.rank == self.root:
+            pending = []
+
+            def sends(rnd):
+                ops = []
+                for r in range(G):
+                    c = self.chunk_of(rnd, r)
+                    if r == self.root or c is None:
+                        continue
+                    f0, cnt = self.chunks[c]
+                    ops += [P2POp(dist.isend, t[f0:f0 + cnt], r) for t in root_inputs]
+                return self._post(ops)
+
+            def recvs(rnd):
+                ops = []
+                for r in range(G):
+                    c = self.chunk_of(rnd, r)
+                    if r == self.root or c is None:
+                        continue
+                    f0, cnt = self.chunks[c]
+                    ops += [P2POp(dist.irecv, t[f0:f0 + cnt], r) for t in root_outputs]
+                return self._post(ops)
+
+            if G > 1 and R > 0:
+                pending += sends(0)
+            for k in range(R):
+                if G > 1 and k + 1 < R:
+                    pending += sends(k + 1)
+                c = self.chunk_of(k, self.root)
+                if c is not None:
+                    f0, cnt = self.chunks[c]
+                    process([t[f0:f0 + cnt] for t in root_inputs], num_samples[f0:f0 + cnt], [t[f0:f0 + cnt] for t in root_outputs])
+                if G > 1:
+                    pending += recvs(k)
+            for w in pending:
+                w.wait()
+            return
+        # ---- a peer: R0 R1 S0 R2 S1 ...
+        me, root = self.rank, self.root
+        recv_work, send_work = {}, {}
+
+        def post_recv(rnd):
+            c = self.chunk_of(rnd, me)
+            if c is None:
+                return
+            cnt = self.chunks[c][1]
+            recv_work[rnd] = self._post([P2POp(dist.irecv, t[:cnt], root) for t in self.in_buf[rnd % 2]])
+
+        post_recv(0)
+        for k in range(R):
+            c = self.chunk_of(k, me)
+            if c is None:
+                break
+            post_recv(k + 1)
+            for w in recv_work.pop(k):
+                w.wait()
+            for w in send_work.pop(k - 2, []):          # the results buffer of round k - 2 is about to be overwritten
+                w.wait()
+            f0, cnt = self.chunks[c]
+            outs = [t[:cnt] for t in self.out_buf[k % 2]]
+            process([t[:cnt] for t in self.in_buf[k % 2]], num_samples[f0:f0 + cnt], outs)
+            send_work[k] = self._post([P2POp(dist.isend, t, root) for t in outs])
+        for ws in send_work.values():
+            for w in ws:
+                w.wait()
 
 
 def barrier_and_sync(dist=None, cuda_sync=None):
@@ -39,18 +168,3 @@ def reduce_max(value, dist=None, tensor_factory=None):
     t = tensor_factory([value]) if tensor_factory else torch.tensor([value], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t[0])
-
-
-def gather_stream(local_blocks, num_items, dist):
-    """rank 0 receives every rank's serialised blocks (python objects over the control plane) and returns them in item
-    order; other ranks return None"""
-    world, rank = dist.get_world_size(), dist.get_rank()
-    gathered = [None] * world if rank == 0 else None
-    dist.gather_object(local_blocks, gathered, dst=0)
-    if rank != 0:
-        return None
-    out = [None] * num_items
-    for r in range(world):
-        for k, idx in enumerate(shard_round_robin(num_items, r, world)):
-            out[idx] = gathered[r][k]
-    return out

@@ -249,3 +249,58 @@ def test_exact_search_everywhere_equals_the_certified_search(ctx_env, big):
         assert c.last_fallback_count() == F * NCH * 4 * 3
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
     assert margin > 0.0
+
+
+@pytest.mark.parametrize("devices,group", [([0, 0], 0), ([0, 0, 0], 37), ([0], 100)])
+def test_fan_out_over_several_contexts_in_one_process(oracle, big, devices, group):
+    """LINNEAmd_MultiEncodeFramesHost / MultiDecodeFramesHost (direct per-GPU H2D/D2H): groups of frames go round-
+    robin to per-device contexts, one host thread each.  A one-GPU box lists device 0 several times (separate contexts,
+    arenas and streams): every frame must equal the single-context result and the oracle's, in the caller's order, with a
+    ragged tail in the last group and group sizes that do not divide the batch"""
+    F = 700
+    frames, ns = big["frames"][-F:], big["ns"][-F:]
+    m = linne_amd.Multi(devices, scratch_bytes=1 << 30)
+    try:
+        assert m.num_devices == len(devices)
+        res, prm, st, plan = m.encode_frames_host(m_shape(), frames, ns, group_frames=group, want_plan=True)
+        back = m.decode_frames_host(m_shape(), res, prm, ns, group_frames=group)
+    finally:
+        m.close()
+    back[-1, :, TAIL:] = frames[-1, :, TAIL:]
+    assert np.array_equal(back, frames)
+    off = NBIG - F
+    idx = sample_indices(F, seed=6, nmid=32)
+    want = oracle_taps(oracle, big["frames"], big["ns"], [off + f for f in idx], big["cache"])
+    compare_sample({f - off: v for f, v in want.items()}, ns, res, prm, st, f"fan-out {devices}")
+    c = linne_amd.Context(0, scratch_bytes=2 << 30, use_torch_stream=False)
+    try:
+        r1 = run_batch(c, frames, ns, check_decode=False)
+    finally:
+        c.close()
+    assert np.array_equal(r1[0], res) and np.array_equal(r1[1], prm) and np.array_equal(r1[2], st, equal_nan=True)
+    # the Rice plan came along: packing with it gives the same blocks as the host's own search
+    a, _ = linne_amd.pack_frames(m_shape(), frames[:8], res[:8], prm[:8], st[:8], ns[:8], 0.0, 2)
+    b, _ = linne_amd.pack_frames(m_shape(), frames[:8], res[:8], prm[:8], st[:8], ns[:8], 0.0, 2, plan=plan[:8])
+    assert a == b
+
+
+def m_shape():
+    return linne_amd.Shape(NCH, BITS, BLOCK, PRESET, 1)
+
+
+@pytest.mark.parametrize("devices,group", [("0,0", "3"), ("0,0,0", "2")])
+def test_whole_stream_api_over_several_devices(product, oracle, monkeypatch, devices, group):
+    """LINNE_AMD_DEVICES=0,0: EncodeWhole / DecodeWhole rotate their frame groups over the listed devices (here two or three
+    contexts on the one GPU); the .lnn bytes equal the oracle's -- Q2's state threads through the groups in stream order -- with
+    SILENT / RAW blocks and a ragged tail in the stream, and decode restores the input"""
+    from signals import waveform
+    monkeypatch.setenv("LINNE_AMD_DEVICES", devices)
+    monkeypatch.setenv("LINNE_AMD_GROUP", group)
+    block = 2048
+    parts = [music(2, 11 * block, 16, seed=31), np.zeros((2, 2 * block), dtype=np.int32), waveform("white_noise", 2, 3 * block, 16, seed=2),
+             music(2, 7 * block + 555, 16, seed=32)]
+    x = np.concatenate(parts, axis=1)
+    mine = product.encode_whole(x, 16, 44100, block, 7, True)
+    assert mine == oracle.encode_whole(x, 16, 44100, block, 7, True)
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
