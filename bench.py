@@ -248,6 +248,102 @@ def end_to_end(x_host, bits, rate, block, preset, ms):
     return res
 
 
+
+def leg_direct_h2d(ctx, shape, frames, nsm, res_ref, steps, chunk_frames, barrier, world, red):
+    """Transport "direct": every rank's shard starts in (pinned) HOST memory and its results end there -- H2D of chunk k + 1 and
+    D2H of chunk k - 1 on two copy streams beside the kernels of chunk k, each GPU on its own PCIe link, nothing between GPUs
+    (the competitor of the RCCL scatter).  Whole-job frames/s incl. both transfers."""
+    F, nch, S = frames.shape
+    dev = frames.device
+    chunks = [(f0, min(chunk_frames, F - f0)) for f0 in range(0, F, chunk_frames)]
+    B = chunks[0][1]
+    pin = lambda shp, dt: torch.empty(shp, dtype=dt, pin_memory=True)
+    h_in = pin((F, nch, S), torch.int32); h_in.copy_(frames)
+    h_res = pin((F, nch, S), torch.int32)
+    h_prm = pin((F, nch, linne_amd.PARAM_WORDS), torch.int32)
+    h_st = pin((F, nch, linne_amd.STAT_WORDS), torch.float64)
+    d_in = [torch.empty((B, nch, S), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_res = [torch.empty((B, nch, S), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_prm = [torch.zeros((B, nch, linne_amd.PARAM_WORDS), dtype=torch.int32, device=dev) for _ in range(2)]
+    d_st = [torch.zeros((B, nch, linne_amd.STAT_WORDS), dtype=torch.float64, device=dev) for _ in range(2)]
+    s_in, s_out, cur = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.current_stream(dev)
+
+    def step():
+        in_free, out_done = [None, None], [None, None]
+        for k, (f0, cnt) in enumerate(chunks):
+            b = k & 1
+            with torch.cuda.stream(s_in):
+                if in_free[b] is not None:
+                    s_in.wait_event(in_free[b])
+                d_in[b][:cnt].copy_(h_in[f0:f0 + cnt], non_blocking=True)
+                e_in = torch.cuda.Event(); e_in.record(s_in)
+            cur.wait_event(e_in)
+            if out_done[b] is not None:
+                cur.wait_event(out_done[b])
+            ctx.encode_frames(shape, d_in[b][:cnt], nsm[f0:f0 + cnt], out=(d_res[b][:cnt], d_prm[b][:cnt], d_st[b][:cnt]))
+            e_k = torch.cuda.Event(); e_k.record(cur)
+            in_free[b] = e_k
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(e_k)
+                h_res[f0:f0 + cnt].copy_(d_res[b][:cnt], non_blocking=True)
+                h_prm[f0:f0 + cnt].copy_(d_prm[b][:cnt], non_blocking=True)
+                h_st[f0:f0 + cnt].copy_(d_st[b][:cnt], non_blocking=True)
+                e_o = torch.cuda.Event(); e_o.record(s_out)
+            out_done[b] = e_o
+
+    step()
+    barrier()
+    same = bool(torch.equal(h_res, res_ref.cpu()))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = red(time.perf_counter() - t0)
+    per_frame = nch * (S * 4 * 2 + linne_amd.PARAM_WORDS * 4 + linne_amd.STAT_WORDS * 8)
+    return {"frames_per_s": F * world * steps / dt, "ms_per_step": dt / steps * 1e3, "chunk_frames": B, "chunks_per_step": len(chunks),
+            "pcie_gb_per_s_per_gpu_each_way": F * steps * per_frame / 2 / dt / 1e9, "results_equal_resident_path": same,
+            "what": "pinned host PCM -> H2D -> encode hot path -> D2H residual+params+stats, per GPU on its own PCIe link, double-buffered"}
+
+
+def leg_rccl(dist, ctx, shape, frames, nsm, res_ref, prm_ref, steps, chunk_frames, barrier, world, rank, red):
+    """Transport "rccl": north_star's N > 1 data path.  Rank 0 holds the whole batch (world x this rank's track) in its HBM;
+    chunks of frames go round-robin to the ranks by RCCL point-to-point send / recv (batched: ncclGroupStart ... ncclGroupEnd),
+    every rank analyses its chunks, residual + params + stats come back the same way (linne_amd.sharding.ChunkExchange,
+    software-pipelined: the links work while the kernels run).  Whole-job frames/s incl. scatter and gather."""
+    from linne_amd.sharding import ChunkExchange
+    F, nch, S = frames.shape
+    dev = frames.device
+    Ftot = F * world
+    nsm_all = np.tile(nsm, world)
+    ex = ChunkExchange(dist if world > 1 else None, Ftot, chunk_frames, [((nch, S), torch.int32)],
+                       [((nch, S), torch.int32), ((nch, linne_amd.PARAM_WORDS), torch.int32), ((nch, linne_amd.STAT_WORDS), torch.float64)], dev, root=0)
+    if rank == 0:
+        all_pcm = frames.repeat(world, 1, 1) if world > 1 else frames
+        outs = [torch.empty((Ftot, nch, S), dtype=torch.int32, device=dev), torch.zeros((Ftot, nch, linne_amd.PARAM_WORDS), dtype=torch.int32, device=dev),
+                torch.zeros((Ftot, nch, linne_amd.STAT_WORDS), dtype=torch.float64, device=dev)]
+        ins = [all_pcm]
+    else:
+        ins, outs = None, None
+
+    def process(i, n, o):
+        ctx.encode_frames(shape, i[0], n, out=tuple(o))
+
+    ex.run(process, nsm_all, ins, outs)
+    barrier()
+    same = None
+    if rank == 0:           # every copy of the track, wherever it was analysed, must equal the resident path's result
+        same = all(bool(torch.equal(outs[0][g * F:(g + 1) * F], res_ref)) and bool(torch.equal(outs[1][g * F:(g + 1) * F], prm_ref)) for g in range(world))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ex.run(process, nsm_all, ins, outs)
+    barrier()
+    dt = red(time.perf_counter() - t0)
+    moved = (ex.bytes_per_frame_out + ex.bytes_per_frame_back) * Ftot * (world - 1) / max(1, world)
+    return {"frames_per_s": Ftot * steps / dt, "ms_per_step": dt / steps * 1e3, "rccl_ranks": world, "chunk_frames": chunk_frames,
+            "chunks_per_step": len(ex.chunks), "root_link_gb_per_s": moved * steps / dt / 1e9, "results_equal_resident_path": same,
+            "what": "rank 0's HBM -> ncclSend/ncclRecv scatter of int32 [chunk][C][S] -> encode hot path on every rank -> gather of residual+params+stats to rank 0; pipelined"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -264,6 +360,10 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the EncodeWhole/DecodeWhole leg on host buffers (it launches smaller "
                     "batches: skip it when collecting the per-kernel rocprof summary of the timed region)")
     ap.add_argument("--no-sample-parity", action="store_true", help="skip the sampled comparison of the timed batch's output with the CPU reference")
+    ap.add_argument("--tracks-total", type=int, default=0, help="STRONG scaling: this many tracks in the whole job, split evenly over the GPUs "
+                    "(BASELINE configs[3]: --tracks-total 1024 --minutes 3); overrides --tracks")
+    ap.add_argument("--no-transports", action="store_true", help="skip the transport legs (direct per-GPU H2D/D2H; RCCL scatter/gather from rank 0)")
+    ap.add_argument("--chunk-frames", type=int, default=0, help="frames per pipeline chunk of the transport legs (default: a quarter of the shard)")
     ap.add_argument("--tracks", type=int, default=1, help="tracks per GPU in ONE batch, each --minutes long with its own ragged tail "
                     "(BASELINE configs[3]: --tracks 1024 --minutes 3 on 8 GPUs = 128 per GPU)")
     args = ap.parse_args()
@@ -277,12 +377,20 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     backend = os.environ.get("BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only for one-GPU rehearsals
+    dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
+        tmo = datetime.timedelta(seconds=300)            # a transport leg that hangs becomes an error, not a dead job
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=tmo)
+    scaling = "weak"
+    if args.tracks_total:
+        assert args.tracks_total % world == 0, "--tracks-total must be a multiple of the GPU count"
+        args.tracks = args.tracks_total // world
+        scaling = "strong"
     red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     nch, bits, block, rate, ms = args.channels, args.bits, 10240, args.rate, args.channels >= 2
@@ -361,6 +469,29 @@ def main():
         dist.all_reduce(okt, op=dist.ReduceOp.MIN)
         ok = bool(okt.item())
 
+    def red_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    transports = None
+    if not args.no_transports:
+        transports = {}
+        chunk = args.chunk_frames or (F + 3) // 4
+        tsteps = max(1, min(args.steps, 3))
+        try:
+            transports["direct_h2d"] = leg_direct_h2d(ctx, shape, frames, nsm, res, tsteps, chunk, barrier, world, red_max)
+        except Exception as exc:
+            transports["direct_h2d"] = {"error": repr(exc)}
+        if world > 1:
+            try:
+                transports["rccl_scatter_gather"] = leg_rccl(dist, ctx, shape, frames, nsm, res, prm, tsteps, chunk, barrier, world, rank, red_max)
+            except Exception as exc:
+                transports["rccl_scatter_gather"] = {"error": repr(exc)}
+        torch.cuda.empty_cache()
+
     if rank == 0:
         total_frames = F * world * args.steps
         enc_fps = total_frames / enc_s
@@ -422,7 +553,7 @@ def main():
         line = {
             "metric": "frames/sec encode (-m 7) + decode, 44.1 kHz stereo, bit-exact; 1/2/4/8 GPU",
             "value": enc_fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": enc_s / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": enc_s / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"encode -m {args.preset}: {args.tracks} x {args.minutes:g} min {rate / 1000:g} kHz int{bits} {nch}-channel per GPU = {F} frames of {block} samples "
                                    f"(tail {int(nsm[-1])}), MS {'on' if ms else 'off'}, PCM resident in HBM; decode = inverse hot path on the encode output",
@@ -432,6 +563,10 @@ def main():
             "encode_channel_frames_per_s": enc_fps * nch,
             "kernel_ms_per_step": breakdown,
             "roofline": roofline, "valu_f64": valu, "cpu_baseline": cpu, "end_to_end_api": e2e,
+            "transports": transports,
+            "transports_note": "value = the hot path with every rank's shard resident in its own HBM (contract: inputs resident when the timed "
+                               "region starts); transports = the same work with the data starting elsewhere: in pinned host memory of each rank "
+                               "(direct_h2d) or in rank 0's HBM (rccl_scatter_gather, N > 1), transfers inside the timed region",
         }
         if cpu:
             # like for like: the reference's EncodeBlock starts from host memory and includes its entropy coder, so the honest

@@ -59,7 +59,7 @@ struct LINNEAmdContext {
     hipEvent_t fork_ev, join_ev;        /* side stream: the general autocorrelation kernel for the few frames the lanes = jobs kernels do not take */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_map;   /* class index per sorted row, then the sorted row's frame (same buffer) */ uint32_t *d_nsmp; uint64_t nsmp_cap;
     /* what the resident class tables were built for: a call with the same shape and frame lengths re-uses them */
-    DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_valid;
+    DevClass sig_cls[LNN_MAXCLS]; struct LINNEAmdShape sig_shape; int sig_valid; uint32_t sig_ncls; uint64_t sig_sin_total, sig_wt_total;
     /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
     int fwd_loss;                       /* LINNE_AMD_FWD_LOSS: last layer's forward pass and loss in one kernel (k_fwd_loss); -1 = by batch size */
     int lev_ride;                       /* short Levinson trials ride along with the one-unit trial (LINNE_AMD_LEV_RIDE, default 1) */
@@ -329,116 +329,151 @@ static int upload_lengths(LINNEAmdContext *ctx, const struct LINNEAmdShape *shap
     return LNN_OK;
 }
 
+/* one length class: analysis length, the unit counts each layer may try, their Welch divisors (host libm, lpc.c:199) and
+ * the offsets of its tables; returns LNN_INVALID_FORMAT for a length the device path does not take */
+static int make_class(LINNEAmdContext *ctx, const HostShape *hs, uint32_t S, uint32_t n, uint64_t *sin_total, uint64_t *wt_total, DevClass *out)
+{
+    DevClass c; memset(&c, 0, sizeof(c));
+    c.n = n;
+    uint32_t na = ((n + 7u) / 8u) * 8u;             /* linne_encoder.c:652-654 */
+    if (na < hs->maxP) na = hs->maxP;
+    if (na > S) na = S;
+    c.na = na;
+    c.sin_off = (uint32_t)*sin_total; *sin_total += n;
+    if (na & 1u) { snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
+    for (uint32_t l = 0; l < hs->L; l++) {
+        const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
+        uint32_t nt = 0;
+        for (uint32_t u = 1; u <= maxu; u <<= 1) {
+            if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
+            c.trial_u[l][nt] = u;
+            c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
+            c.wt_off[l][nt] = (uint32_t)*wt_total;
+            { const uint32_t pu = hs->P[l] / u; *wt_total += na / u + (pu > 4 ? pu : 4); *wt_total = (*wt_total + 3u) & ~(uint64_t)3u; }   /* tables start 32-byte aligned */
+            nt++;
+        }
+        c.ntrials[l] = nt;
+    }
+    *out = c;
+    return LNN_OK;
+}
+
 /* Builds the per-length classes of an encode batch (tables are host libm values) and the class-sorted
  * order the kernels work in: sorted row i is the caller's frame map[i]; rows of one class are contiguous (stable: the
  * caller's order inside a class), so that whatever the order of lengths in the batch -- many tracks back to back, each
  * with its ragged tail -- a chunk has at most one run per class and the lanes = rows kernels see class-homogeneous
- * blocks.  The tables stay resident and are uploaded again only when the shape or the set of frame lengths changes;
- * the per-frame class index and the map go through a pinned ring, so a call with resident tables enqueues without
- * synchronising the host. */
+ * blocks.  The class tables are CUMULATIVE: a length seen in an earlier call of the same shape keeps its slot, so a caller
+ * that alternates between batches with and without a ragged tail (a pipelined stream, chunk after chunk) uploads tables
+ * once per new length and never again; only then does the call synchronise the host.  The per-frame class index and the
+ * map go through a pinned ring. */
 static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape, const HostShape *hs,
         const uint32_t *h_num_samples, uint32_t F)
 {
-    DevClass cls[LNN_MAXCLS];
-    uint32_t ncls = 0, count[LNN_MAXCLS + 1];
+    uint32_t count[LNN_MAXCLS + 1];
+    uint32_t lens[LNN_MAXCLS], slot_of[LNN_MAXCLS], nlen = 0;
     const uint32_t S = shape->num_samples_per_block;
-    int m;
+    int m, ret;
     { const int r_ = meta_acquire(ctx, F, &m); if (r_ != LNN_OK) return r_; }
     uint32_t *idx = ctx->meta_h[m], *map = ctx->meta_h[m] + F, *raw = ctx->meta_h[m] + 2 * (size_t)F;
     ctx->cur_idx = idx;
-    memset(cls, 0, sizeof(cls));
-    memset(count, 0, sizeof(count));
-    ctx->na_max = 0;
-    uint64_t sin_total = 0, wt_total = 0;
-    for (uint32_t f = 0; f < F; f++) {
-        const uint32_t n = h_num_samples ? h_num_samples[f] : S;
-        if (n == 0 || n > S) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
-        uint32_t k = 0;
-        for (; k < ncls; k++) if (cls[k].n == n) break;
-        if (k == ncls) {
-            if (ncls == LNN_MAXCLS) { snprintf(ctx->err, sizeof(ctx->err), "more than %d distinct frame lengths in one batch", LNN_MAXCLS); return LNN_INVALID_ARGUMENT; }
-            DevClass &c = cls[ncls++];
-            c.n = n;
-            uint32_t na = ((n + 7u) / 8u) * 8u;             /* linne_encoder.c:652-654 */
-            if (na < hs->maxP) na = hs->maxP;
-            if (na > S) na = S;
-            c.na = na;
-            c.sin_off = (uint32_t)sin_total; sin_total += n;
-            if (na & 1u) { snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
-            for (uint32_t l = 0; l < hs->L; l++) {
-                const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
-                uint32_t nt = 0;
-                for (uint32_t u = 1; u <= maxu; u <<= 1) {
-                    if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
-                    c.trial_u[l][nt] = u;
-                    c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
-                    c.wt_off[l][nt] = (uint32_t)wt_total;
-                    { const uint32_t pu = hs->P[l] / u; wt_total += na / u + (pu > 4 ? pu : 4); wt_total = (wt_total + 3u) & ~(uint64_t)3u; }   /* tables start 32-byte aligned */
-                    nt++;
+    /* pass 1: the distinct lengths of this call (raw[f] = index into lens[]) */
+    {
+        uint32_t last_n = 0, last_k = 0;
+        for (uint32_t f = 0; f < F; f++) {
+            const uint32_t n = h_num_samples ? h_num_samples[f] : S;
+            if (n == 0 || n > S) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n); return LNN_INVALID_ARGUMENT; }
+            uint32_t k = last_k;
+            if (n != last_n || nlen == 0) {
+                for (k = 0; k < nlen; k++) if (lens[k] == n) break;
+                if (k == nlen) {
+                    if (nlen == LNN_MAXCLS) { snprintf(ctx->err, sizeof(ctx->err), "more than %d distinct frame lengths in one batch", LNN_MAXCLS); return LNN_INVALID_ARGUMENT; }
+                    lens[nlen++] = n;
                 }
-                c.ntrials[l] = nt;
+                last_n = n; last_k = k;
             }
-        }
-        if (cls[k].na > ctx->na_max) ctx->na_max = cls[k].na;
-        raw[f] = k;
-        count[k + 1]++;
-    }
-    {   /* stable counting sort by class (LINNE_AMD_SORT=0: the caller's order, for tests of the mixed-run fallback) */
-        const char *e_ = getenv("LINNE_AMD_SORT");
-        if (e_ && atoi(e_) == 0) { for (uint32_t f = 0; f < F; f++) { idx[f] = raw[f]; map[f] = f; } }
-        else {
-            for (uint32_t k = 0; k < ncls; k++) count[k + 1] += count[k];
-            for (uint32_t f = 0; f < F; f++) { const uint32_t pos = count[raw[f]]++; idx[pos] = raw[f]; map[pos] = f; }
+            raw[f] = k;
         }
     }
-    {       /* short layers by products (k_autocorr_prod): all trials present and every unit length even, in every class */
-        const char *e_ = getenv("LINNE_AMD_L0_PRODUCTS");
-        ctx->prod_ok = 0;
-        for (uint32_t l = 0; l < hs->L; l++) {
-            if (hs->P[l] > 16u || !(e_ ? atoi(e_) : 1)) continue;
-            uint32_t nt = 0; for (uint32_t u = 1; u <= hs->P[l]; u <<= 1) nt++;
-            int ok = 1;
-            for (uint32_t k = 0; k < ncls; k++) if (cls[k].ntrials[l] != nt || (cls[k].na % (1u << nt)) != 0) ok = 0;
-            if (ok) ctx->prod_ok |= 1 << l;
-        }
+    /* the resident table: keep it if it has (room for) every length of this call, else start over with this call's lengths */
+    const bool same_shape = ctx->sig_valid && memcmp(&ctx->sig_shape, shape, sizeof(*shape)) == 0;
+    uint32_t missing = 0;
+    for (uint32_t k = 0; k < nlen; k++) {
+        uint32_t j = 0;
+        if (same_shape) for (; j < ctx->sig_ncls; j++) if (ctx->sig_cls[j].n == lens[k]) break;
+        slot_of[k] = (same_shape && j < ctx->sig_ncls) ? j : 0xFFFFFFFFu;
+        if (slot_of[k] == 0xFFFFFFFFu) missing++;
     }
-    int ret;
-    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * 2 * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
-    const bool resident = ctx->sig_valid && memcmp(&ctx->sig_shape, shape, sizeof(*shape)) == 0 && memcmp(ctx->sig_cls, cls, sizeof(cls)) == 0;
-    if (!resident) {
-        hipError_t e = hipSuccess;
-        double *tab = NULL, *wt = NULL;
-        ctx->sig_valid = 0;
-        tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
-        wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
-        if (!tab || !wt) { free(tab); free(wt); snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
-        for (uint32_t k = 0; k < ncls; k++) {
-            const uint32_t n = cls[k].n;
-            for (uint32_t s = 0; s < n; s++) tab[cls[k].sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
+    if (missing) {
+        if (!same_shape || ctx->sig_ncls + missing > LNN_MAXCLS) {
+            ctx->sig_valid = 0; ctx->sig_ncls = 0; ctx->sig_sin_total = 0; ctx->sig_wt_total = 0;
+            memset(ctx->sig_cls, 0, sizeof(ctx->sig_cls));
+            for (uint32_t k = 0; k < nlen; k++) slot_of[k] = 0xFFFFFFFFu;
+        }
+        for (uint32_t k = 0; k < nlen; k++) if (slot_of[k] == 0xFFFFFFFFu) {
+            if ((ret = make_class(ctx, hs, S, lens[k], &ctx->sig_sin_total, &ctx->sig_wt_total, &ctx->sig_cls[ctx->sig_ncls])) != LNN_OK) { ctx->sig_valid = 0; ctx->sig_ncls = 0; return ret; }
+            slot_of[k] = ctx->sig_ncls++;
+        }
+        /* (re)build and upload the tables of every resident class */
+        const uint64_t sin_total = ctx->sig_sin_total, wt_total = ctx->sig_wt_total;
+        double *tab = (double *)malloc(sizeof(double) * (sin_total ? sin_total : 1));
+        double *wt = (double *)calloc(wt_total ? wt_total : 1, sizeof(double));
+        if (!tab || !wt) { free(tab); free(wt); ctx->sig_valid = 0; ctx->sig_ncls = 0; snprintf(ctx->err, sizeof(ctx->err), "out of host memory"); return LNN_NG; }
+        for (uint32_t k = 0; k < ctx->sig_ncls; k++) {
+            const DevClass &c = ctx->sig_cls[k];
+            const uint32_t n = c.n;
+            for (uint32_t s = 0; s < n; s++) tab[c.sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
             /* Welch weights per trial over one padded unit (lpc.c:199-204): w[loc] = (div * h) * (n-1-h), h = min(loc, n-1-loc);
              * zero in the zero zone; the (never written) middle of an odd unit is handled on the device (Q1) */
             for (uint32_t l = 0; l < hs->L; l++)
-                for (uint32_t t = 0; t < cls[k].ntrials[l]; t++) {
-                    const uint32_t u = cls[k].trial_u[l][t], nu = cls[k].na / u;
-                    const double div = cls[k].trial_div[l][t];
-                    double *w = wt + cls[k].wt_off[l][t];
+                for (uint32_t t = 0; t < c.ntrials[l]; t++) {
+                    const uint32_t u = c.trial_u[l][t], nu = c.na / u;
+                    const double div = c.trial_div[l][t];
+                    double *w = wt + c.wt_off[l][t];
                     for (uint32_t loc = 0; loc < nu; loc++) {
                         const uint32_t h = (loc < (nu >> 1)) ? loc : (nu - 1 - loc);
                         w[loc] = div * (double)h * (double)(nu - 1 - h);
                     }
                 }
         }
-        ret = ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1));
+        /* the old tables may still be read by work enqueued on the sub-streams / side stream of an earlier call */
+        hipError_t e = hipDeviceSynchronize();
+        ret = (e == hipSuccess) ? ensure_buf(ctx, (void **)&ctx->d_sin, &ctx->sin_cap, sizeof(double) * (sin_total ? sin_total : 1)) : LNN_NG;
         if (ret == LNN_OK) ret = ensure_buf(ctx, (void **)&ctx->d_wt, &ctx->wt_cap, sizeof(double) * (wt_total ? wt_total : 1));
-        if (ret != LNN_OK) { free(tab); free(wt); return ret; }
+        if (ret != LNN_OK) { free(tab); free(wt); ctx->sig_valid = 0; ctx->sig_ncls = 0; return ret; }
         e = hipMemcpyAsync(ctx->d_sin, tab, sizeof(double) * sin_total, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_wt, wt, sizeof(double) * wt_total, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          /* cls is on the stack, tab/wt are freed here */
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cls, ctx->sig_cls, sizeof(DevClass) * LNN_MAXCLS, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          /* tab / wt are freed here */
         free(tab); free(wt);
-        if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "class table upload: %s", hipGetErrorString(e)); return LNN_NG; }
-        memcpy(ctx->sig_cls, cls, sizeof(cls)); ctx->sig_shape = *shape; ctx->sig_valid = 1;
+        if (e != hipSuccess) { ctx->sig_valid = 0; ctx->sig_ncls = 0; snprintf(ctx->err, sizeof(ctx->err), "class table upload: %s", hipGetErrorString(e)); return LNN_NG; }
+        ctx->sig_shape = *shape; ctx->sig_valid = 1;
     }
+    /* pass 2: class slots in order of first appearance in this call, stable counting sort by class
+     * (LINNE_AMD_SORT=0: the caller's order, for tests of the mixed-run fallback) */
+    memset(count, 0, sizeof(count));
+    ctx->na_max = 0;
+    for (uint32_t k = 0; k < nlen; k++) if (ctx->sig_cls[slot_of[k]].na > ctx->na_max) ctx->na_max = ctx->sig_cls[slot_of[k]].na;
+    {
+        const char *e_ = getenv("LINNE_AMD_SORT");
+        if (e_ && atoi(e_) == 0) { for (uint32_t f = 0; f < F; f++) { idx[f] = slot_of[raw[f]]; map[f] = f; } }
+        else {
+            for (uint32_t f = 0; f < F; f++) count[raw[f] + 1]++;
+            for (uint32_t k = 0; k < nlen; k++) count[k + 1] += count[k];
+            for (uint32_t f = 0; f < F; f++) { const uint32_t pos = count[raw[f]]++; idx[pos] = slot_of[raw[f]]; map[pos] = f; }
+        }
+    }
+    {       /* short layers by products (k_autocorr_prod): all trials present and every unit length even, in every class of this call */
+        const char *e_ = getenv("LINNE_AMD_L0_PRODUCTS");
+        ctx->prod_ok = 0;
+        for (uint32_t l = 0; l < hs->L; l++) {
+            if (hs->P[l] > 16u || !(e_ ? atoi(e_) : 1)) continue;
+            uint32_t nt = 0; for (uint32_t u = 1; u <= hs->P[l]; u <<= 1) nt++;
+            int ok = 1;
+            for (uint32_t k = 0; k < nlen; k++) { const DevClass &c = ctx->sig_cls[slot_of[k]]; if (c.ntrials[l] != nt || (c.na % (1u << nt)) != 0) ok = 0; }
+            if (ok) ctx->prod_ok |= 1 << l;
+        }
+    }
+    if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * 2 * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
     ctx->d_map = ctx->d_clsidx + F;
     HIPCHK(ctx, hipMemcpyAsync(ctx->d_clsidx, idx, sizeof(uint32_t) * 2 * (size_t)F, hipMemcpyHostToDevice, ctx->stream));    /* class index and map, back to back */
     HIPCHK(ctx, hipEventRecord(ctx->meta_ev[m], ctx->stream));

@@ -26,6 +26,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
         st[LINNE_AMD_ST_BEST] = (double)best;
         st[LINNE_AMD_ST_LOSS] = p.jloss[(size_t)cf * p.R + best];
     }
+    /* the record is written completely, whatever the caller's buffer held: words this preset does not use are zero */
+    for (uint32_t i = LINNE_AMD_PRM_UNITS + tid; i < LINNE_AMD_PARAM_WORDS; i += FIN_THREADS) rec[i] = 0;
     __syncthreads();
     const uint32_t job = cf * p.R + s_best;
     if (tid < p.L) {    /* lpc.c:981-1040 over all units of the layer together */

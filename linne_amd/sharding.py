@@ -48,6 +48,9 @@ class ChunkExchange:
         self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.root, self.device = root, device
+        # device tensors on a backend that only moves host memory ("gloo": rehearsals of the N > 1 path on a one-GPU box): every
+        # transfer is staged through a host copy.  Never the case on "nccl" (RCCL moves device memory over xGMI directly).
+        self.stage_through_host = bool(self.world > 1 and torch.device(device).type != "cpu" and dist.get_backend() != "nccl")
         self.num_frames, self.chunk_frames = int(num_frames), int(chunk_frames)
         self.chunks = chunk_ranges(self.num_frames, self.chunk_frames)
         self.in_specs, self.out_specs = list(in_specs), list(out_specs)
@@ -69,7 +72,11 @@ class ChunkExchange:
         return c if c < len(self.chunks) else None
 
     def _post(self, ops):
-        return self.dist.batch_isend_irecv(ops) if ops else []
+        if not ops:
+            return []
+        if self.stage_through_host:
+            return [_StagedOp(self.dist, op) for op in ops]
+        return self.dist.batch_isend_irecv(ops)
 
     def run(self, process, num_samples, root_inputs=None, root_outputs=None):
         """process(inputs_chunk, num_samples_chunk, outputs_chunk) fills the output views from the input views.
@@ -141,6 +148,20 @@ class ChunkExchange:
         for ws in send_work.values():
             for w in ws:
                 w.wait()
+
+
+class _StagedOp:
+    """one point-to-point transfer of a device tensor through host memory (see ChunkExchange.stage_through_host)"""
+
+    def __init__(self, dist, op):
+        self.tensor, self.is_recv = op.tensor, op.op is dist.irecv
+        self.host = op.tensor.cpu() if not self.is_recv else op.tensor.new_empty(op.tensor.shape, device="cpu")
+        self.work = (dist.irecv if self.is_recv else dist.isend)(self.host, op.peer)
+
+    def wait(self):
+        self.work.wait()
+        if self.is_recv:
+            self.tensor.copy_(self.host)
 
 
 def barrier_and_sync(dist=None, cuda_sync=None):
