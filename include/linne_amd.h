@@ -80,6 +80,9 @@ void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx);
 const char *LINNEAmd_GetLastError(const struct LINNEAmdContext *ctx);
 /* grows the scratch arena to at least `bytes` (bigger arena = more frames per launch) */
 int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t bytes);
+/* scratch one frame of this shape needs inside EncodeFramesDevice (0 for an invalid shape): frames x this = the arena that holds a
+ * batch in one launch chunk */
+uint64_t LINNEAmd_ScratchBytesPerFrame(const struct LINNEAmdShape *shape);
 /* issue all subsequent work on an existing hipStream_t (e.g. torch's current stream); NULL names the device's
  * default (null) stream.  Until this is called the context uses a stream of its own. */
 int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream);
@@ -119,9 +122,19 @@ int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmd
  * guard band of a parameter step (the host then runs its own search for this channel-frame; the libm expression decides),
  * [16 ..] the parameter of each partition of the chosen order.  Enqueues on the context's stream. */
 #define LINNE_AMD_RICE_PLAN_BYTES  1040
+#define LINNE_AMD_RICE_PLAN_NBITS  4       /* uint32 at this byte offset: length of the channel's whole Rice code in bits (0xFFFFFFFF when flagged) */
 #define LINNE_AMD_RICE_PLAN_K2     16
 int LINNEAmd_RicePlanDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         const int32_t *d_residual, const uint32_t *h_num_samples, uint32_t num_frames, uint8_t *d_plan);
+
+/* Rice EMISSION on the device (beyond step 2): writes every channel-frame's partitioned recursive Rice code
+ * (linne_coder.c:281-302 with the bit order of bit_stream.h:240-282) from the residual and the plan RicePlanDevice made for the
+ * same batch (call it first).  d_offsets [F * C + 1] receives each code's byte offset in d_packed (8-byte aligned; 0xFFFFFFFF
+ * for a channel-frame whose plan is flagged or whose code does not fit), the last entry the bytes used.  The host stage then
+ * appends the codes at their bit positions instead of coding the residual (LINNEAmd_PackFramesEmitted). */
+int LINNEAmd_RiceEmitDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *d_residual, uint32_t num_frames, const uint8_t *d_plan,
+        uint32_t *d_offsets, uint8_t *d_packed, uint64_t packed_capacity);
 
 /* Staging slots: what a whole-stream caller (LINNEEncoder_EncodeWhole / LINNEDecoder_DecodeWhole,
  * linne_encoder.c:865-932, linne_decoder.c:671-742) uses instead of the synchronous host forms.  A slot owns pinned
@@ -133,6 +146,22 @@ int LINNEAmd_RicePlanDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdSh
 struct LINNEAmdSlot;
 struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         uint32_t max_frames, int for_encode);
+/* Encode slots with less PCIe traffic (what LINNEEncoder_EncodeWhole uses):
+ *   LINNE_AMD_SLOT_PCM16  the input is staged as int16 (SlotPcm16; ignored above 16 bits per sample) and widened on the device;
+ *   LINNE_AMD_SLOT_EMIT   the device also WRITES the residual's Rice code (linne_coder.c:281-302; LINNEAmd_RiceEmitDevice): after
+ *                         SlotWait, SlotPacked holds the channels' codes back to back, SlotOffsets[cf] the byte offset of
+ *                         channel-frame cf's code (0xFFFFFFFF: not emitted -- flagged plan or no room; the host then fetches that
+ *                         frame's residual with SlotFetchResidual and codes it itself), SlotRicePlan the plans with each code's
+ *                         bit length at LINNE_AMD_RICE_PLAN_NBITS.  The residual is not copied to the host (SlotData is NULL). */
+#define LINNE_AMD_SLOT_PCM16  1u
+#define LINNE_AMD_SLOT_EMIT   2u
+struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        uint32_t max_frames, int for_encode, uint32_t flags);
+uint32_t  LINNEAmd_SlotFlags(const struct LINNEAmdSlot *slot);
+int16_t  *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *slot);                   /* [F][C][S] int16 (NULL unless LINNE_AMD_SLOT_PCM16 took effect; SlotPcm is NULL then) */
+const uint8_t  *LINNEAmd_SlotPacked(struct LINNEAmdSlot *slot);
+const uint32_t *LINNEAmd_SlotOffsets(struct LINNEAmdSlot *slot);           /* [F * C + 1], the last entry = bytes used */
+int LINNEAmd_SlotFetchResidual(struct LINNEAmdSlot *slot, uint32_t frame, int32_t *dst /* [C][S] */);
 void      LINNEAmd_SlotDestroy(struct LINNEAmdSlot *slot);
 int32_t  *LINNEAmd_SlotPcm(struct LINNEAmdSlot *slot);       /* [F][C][S] int32, encode input (NULL for a decode slot) */
 int32_t  *LINNEAmd_SlotData(struct LINNEAmdSlot *slot);      /* [F][C][S] int32, residual (encode out, decode in) / PCM (decode out) */
@@ -212,6 +241,17 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
         uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
         uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
         uint32_t num_threads);
+
+/* The host stage when the device wrote the Rice codes (LINNEAmd_RiceEmitDevice, or an encode slot with LINNE_AMD_SLOT_EMIT): block
+ * types in stream order, then per block the header, the parameter bits (linne_encoder.c:698-735), the channels' codes appended at
+ * the running bit position, padding and CRC16 (:743-749, :848-855).  PCM is read in place from the caller's planes (frame f of
+ * the batch starts at sample first_sample + f * num_samples_per_block of every plane; needed for the SILENT test and RAW blocks).
+ * fetch(arg, frame, dst[C][S]) must deliver a frame's residual; it is called for the (rare) channel-frames without a device code
+ * (offset 0xFFFFFFFF).  Same bytes as LINNEAmd_PackFrames. */
+int LINNEAmd_PackFramesEmitted(const struct LINNEAmdShape *shape, const int32_t *const *planes, uint64_t first_sample,
+        const uint32_t *num_samples, uint32_t num_frames, const int32_t *params, const double *stats, const uint8_t *rice_plan,
+        const uint8_t *packed, const uint32_t *offsets, int (*fetch)(void *arg, uint32_t frame, int32_t *dst), void *fetch_arg,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state, uint32_t num_threads);
 
 #ifdef __cplusplus
 }

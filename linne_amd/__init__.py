@@ -37,12 +37,13 @@ API_SYMBOLS = [
 ]
 AMD_SYMBOLS = [
     "LINNEAmd_GetDeviceCount", "LINNEAmd_ContextCreate", "LINNEAmd_ContextDestroy", "LINNEAmd_GetLastError",
-    "LINNEAmd_ReserveScratch", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
+    "LINNEAmd_ReserveScratch", "LINNEAmd_ScratchBytesPerFrame", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
     "LINNEAmd_GetLastMinMargin", "LINNEAmd_MultiCreate", "LINNEAmd_MultiDestroy", "LINNEAmd_MultiNumDevices", "LINNEAmd_MultiDevice",
     "LINNEAmd_MultiContext", "LINNEAmd_MultiGetLastError", "LINNEAmd_MultiEncodeFramesHost", "LINNEAmd_MultiDecodeFramesHost", "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
-    "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
+    "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_SlotCreateEx", "LINNEAmd_SlotFlags", "LINNEAmd_SlotPcm16", "LINNEAmd_SlotPacked", "LINNEAmd_SlotOffsets",
+    "LINNEAmd_SlotFetchResidual", "LINNEAmd_RiceEmitDevice", "LINNEAmd_PackFramesEmitted", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
 ]
 
 
@@ -71,6 +72,8 @@ def _load():
     L.LINNEAmd_GetLastError.restype = C.c_char_p
     L.LINNEAmd_GetLastError.argtypes = [C.c_void_p]
     L.LINNEAmd_ReserveScratch.argtypes = [C.c_void_p, C.c_uint64]
+    L.LINNEAmd_ScratchBytesPerFrame.restype = C.c_uint64
+    L.LINNEAmd_ScratchBytesPerFrame.argtypes = [C.POINTER(Shape)]
     L.LINNEAmd_SetStream.argtypes = [C.c_void_p, C.c_void_p]
     L.LINNEAmd_EncodeFramesDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32,
                                               C.c_void_p, C.c_void_p, C.c_void_p]
@@ -93,6 +96,10 @@ def _load():
     L.LINNEAmd_PackFramesPlanned.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_double), C.c_uint32]
     L.LINNEAmd_RicePlanDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.LINNEAmd_RiceEmitDevice.argtypes = [C.c_void_p, C.POINTER(Shape), C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]
+    L.LINNEAmd_PackFramesEmitted.argtypes = [C.POINTER(Shape), C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p,
+                                             C.POINTER(C.c_double), C.c_uint32]
     L.LINNEAmd_MultiCreate.restype = C.c_void_p
     L.LINNEAmd_MultiCreate.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
     L.LINNEAmd_MultiDestroy.argtypes = [C.c_void_p]
@@ -202,6 +209,18 @@ class Context:
                                                 F, plan.data_ptr()), "RicePlanDevice")
         return plan
 
+    def rice_emit(self, shape, residual, plan, capacity_bytes=None):
+        """residual int32 cuda [F][C][S], plan = rice_plan(...) of the same batch -> (packed uint8 cuda [capacity], offsets uint32-as-int32
+        cuda [F*C+1]): every channel-frame's Rice code, written by the device (include/linne_amd.h LINNEAmd_RiceEmitDevice)"""
+        import torch
+        F, Cn, S = residual.shape
+        cap = int(capacity_bytes if capacity_bytes is not None else F * Cn * (S * 4 + 64))
+        packed = torch.zeros(cap, dtype=torch.uint8, device=residual.device)
+        offsets = torch.zeros(F * Cn + 1, dtype=torch.int32, device=residual.device)
+        self._check(lib.LINNEAmd_RiceEmitDevice(self.h, C.byref(shape), residual.data_ptr(), F, plan.data_ptr(), offsets.data_ptr(),
+                                                packed.data_ptr(), cap), "RiceEmitDevice")
+        return packed, offsets
+
     def decode_frames(self, shape, data, params, num_samples=None):
         """in place: data int32 cuda [F][C][S] residual -> PCM"""
         import torch
@@ -289,6 +308,45 @@ class Multi:
         self._check(lib.LINNEAmd_MultiDecodeFramesHost(self.h, C.byref(shape), d.ctypes.data, ns.ctypes.data if ns is not None else None,
                                                        d.shape[0], prm.ctypes.data, int(group_frames)), "MultiDecodeFramesHost")
         return d
+
+
+def pack_frames_emitted(shape, planes, first_sample, params, stats, plan, packed, offsets, num_samples=None, parcor_state=0.0, threads=0, residual=None):
+    """host stitch stage over the device's Rice codes (LINNEAmd_PackFramesEmitted): planes = int32 [C][total samples] (the caller's PCM),
+    the batch's frames start at first_sample; residual [F][C][S] (numpy) serves the fetch callback for channel-frames without a code"""
+    planes = np.ascontiguousarray(planes, dtype=np.int32)
+    params = np.ascontiguousarray(params, dtype=np.int32)
+    stats = np.ascontiguousarray(stats, dtype=np.float64)
+    plan = np.ascontiguousarray(plan, dtype=np.uint8)
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets).view(np.uint32)
+    F, Cn = params.shape[0], params.shape[1]
+    ptrs = (C.POINTER(C.c_int32) * Cn)(*[planes[ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(Cn)])
+    cap = F * Cn * shape.num_samples_per_block * 8 + 64 * F + 64
+    out = np.zeros(cap, dtype=np.uint8)
+    sizes = np.zeros(F, dtype=np.uint32)
+    ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+    st = C.c_double(parcor_state)
+    fetched = []
+    FETCH = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.POINTER(C.c_int32))
+
+    def _fetch(arg, frame, dst):
+        if residual is None:
+            return 7
+        fetched.append(int(frame))
+        C.memmove(dst, np.ascontiguousarray(residual[frame], dtype=np.int32).ctypes.data, Cn * shape.num_samples_per_block * 4)
+        return 0
+
+    cb = FETCH(_fetch)
+    ret = lib.LINNEAmd_PackFramesEmitted(C.byref(shape), ptrs, int(first_sample), ns.ctypes.data if ns is not None else None, F,
+                                         params.ctypes.data, stats.ctypes.data, plan.ctypes.data, packed.ctypes.data, offsets.ctypes.data,
+                                         C.cast(cb, C.c_void_p), None, out.ctypes.data, cap, sizes.ctypes.data, C.byref(st), threads or (os.cpu_count() or 1))
+    if ret != 0:
+        raise LinneAmdError(f"PackFramesEmitted -> {ret}")
+    blocks, off = [], 0
+    for s in sizes:
+        blocks.append(out[off:off + int(s)].tobytes())
+        off += int(s)
+    return blocks, st.value, fetched
 
 
 def pack_frames(shape, pcm, residual, params, stats, num_samples=None, parcor_state=0.0, threads=0, plan=None):

@@ -23,7 +23,6 @@
 #define LNN_SLOTS 3u                    /* groups of frames in flight in EncodeWhole / DecodeWhole */
 #define ALIGN_UP(v) (((v) + (LNN_ALIGN - 1u)) & ~(uintptr_t)(LNN_ALIGN - 1u))
 
-extern int LINNEAmd_ReserveScratch(struct LINNEAmdContext *ctx, uint64_t bytes);
 
 /* host threads of the entropy stage: LINNE_AMD_THREADS, else the CPUs this process may actually use (affinity mask,
  * capped by the cgroup v2 CPU quota: a container often sees every core of the machine but owns a few) */
@@ -52,19 +51,25 @@ static uint32_t default_threads(void)
 }
 #include <time.h>
 static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
-static int trace_on(void) { static int v = -1; if (v < 0) { const char *e = getenv("LINNE_AMD_TRACE"); v = (e && atoi(e)) ? 1 : 0; } return v; }
-/* frames per staging slot: LINNE_AMD_GROUP, else large enough that a group is throughput- rather than latency-bound on
- * the GPU (one batch call has a few ms of dependent-kernel latency) while a long stream still splits into several groups
- * that overlap with the host stage */
-static uint32_t default_group(uint32_t num_frames)
+static int trace_on(void) { static int v = -1; if (v < 0) { const char *e = getenv("LINNE_AMD_TRACE"); v = e ? atoi(e) : 0; } return v; }
+/* Frames per staging slot: LINNE_AMD_GROUP, else a group large enough that the GPU runs its large-batch kernel forms on it
+ * (EncodeFramesDevice picks them from 24 576 jobs = channel-frames x regulariser passes, DecodeFramesDevice from 6 144
+ * channel-frames: smaller groups are latency-bound and took 1.7x the GPU time for the same stream), capped by what a slot may
+ * pin (about 1 GiB per buffer); a long stream then splits into equal groups so that the host stage, PCIe and the kernels
+ * overlap from the second group on. */
+static uint32_t default_group(uint32_t num_frames, const struct LINNEAmdShape *shape, const struct lnn_layers *ly, int for_encode)
 {
     const char *e = getenv("LINNE_AMD_GROUP");
-    long n = e ? atol(e) : (long)((num_frames + 5u) / 6u);
-    if (!e && n < 256) n = 256;
-    if (!e && n > 1024) n = 1024;
-    if (n < 1) n = 1;
-    if (n > 4096) n = 4096;
-    return (uint32_t)n;
+    const uint64_t rows = (uint64_t)shape->num_channels * (for_encode ? ly->num_regs : 1u);
+    const uint64_t want = ((for_encode ? 24576u : 6144u) + rows - 1) / rows + 8;
+    const uint64_t cap = (1ull << 30) / ((uint64_t)shape->num_channels * shape->num_samples_per_block * sizeof(int32_t)) + 1;
+    uint64_t n, ngroups;
+    if (e) { long v = atol(e); if (v < 1) v = 1; if (v > 4096) v = 4096; return (uint32_t)v; }
+    n = want < cap ? want : cap;
+    if (n < 256) n = 256;
+    if (n >= num_frames) return num_frames ? num_frames : 1u;
+    ngroups = num_frames / n;                               /* equal groups, none below the threshold */
+    return (uint32_t)((num_frames + ngroups - 1) / ngroups);
 }
 /* The GPUs of a handle: LINNE_AMD_DEVICES="0,1,..." (whole streams fan out over them: group g of frames goes to device
  * g mod G), else LINNE_AMD_DEVICE (one device), else device 0.  Block-at-a-time calls use the first one. */
@@ -72,7 +77,7 @@ struct lnn_gpus {
     uint32_t ndev; int device[LNN_MAX_DEVICES];
     struct LINNEAmdContext *ctx[LNN_MAX_DEVICES];
     struct LINNEAmdSlot *slot[LNN_MAX_DEVICES][LNN_SLOTS];      /* whole-stream staging (pinned + device), created at the first Whole call */
-    struct LINNEAmdShape slot_shape; uint32_t slot_frames;
+    struct LINNEAmdShape slot_shape; uint32_t slot_frames, slot_flags;
 };
 static void drop_slots(struct lnn_gpus *g)
 {
@@ -83,11 +88,15 @@ static void drop_slots(struct lnn_gpus *g)
 /* (re)creates the staging slots of a handle for `frames` frames per slot, `count` per device; keeps what already fits */
 static int want_slots(struct lnn_gpus *g, const struct LINNEAmdShape *shape, uint32_t frames, uint32_t count, int for_encode)
 {
-    uint32_t d, i;
-    if (memcmp(&g->slot_shape, shape, sizeof(*shape)) != 0 || g->slot_frames < frames) { drop_slots(g); g->slot_shape = *shape; g->slot_frames = frames; }
+    uint32_t d, i, flags = 0;
+    if (for_encode) {       /* 16-bit staging and Rice emission on the device (LINNE_AMD_EMIT=0: int32 both ways, the host codes the residual) */
+        const char *e = getenv("LINNE_AMD_EMIT");
+        if (!e || atoi(e) != 0) flags = LINNE_AMD_SLOT_PCM16 | LINNE_AMD_SLOT_EMIT;
+    }
+    if (memcmp(&g->slot_shape, shape, sizeof(*shape)) != 0 || g->slot_frames < frames || g->slot_flags != flags) { drop_slots(g); g->slot_shape = *shape; g->slot_frames = frames; g->slot_flags = flags; }
     for (d = 0; d < g->ndev; d++)
         for (i = 0; i < count && i < LNN_SLOTS; i++)
-            if (!g->slot[d][i] && !(g->slot[d][i] = LINNEAmd_SlotCreate(g->ctx[d], shape, g->slot_frames, for_encode))) return (int)d + 1;
+            if (!g->slot[d][i] && !(g->slot[d][i] = LINNEAmd_SlotCreateEx(g->ctx[d], shape, g->slot_frames, for_encode, flags))) return (int)d + 1;
     return 0;
 }
 /* opens the first device (block-at-a-time calls) or all of them (whole streams) */
@@ -288,22 +297,30 @@ LINNEApiResult LINNEEncoder_EncodeBlock(struct LINNEEncoder *encoder, const int3
 
 /* whole stream (linne_encoder.c:865-932): groups of frames rotate over LNN_SLOTS staging slots -- while the GPU analyses
  * one group, the host threads pack the previous one into the stream and fill the next */
-struct fill_job { const int32_t *const *input; int32_t *pcm; uint32_t *nsm; uint32_t C, S, num_samples, base; };
+struct fill_job { const int32_t *const *input; int32_t *pcm; int16_t *pcm16; uint32_t *nsm; uint32_t C, S, num_samples, base; };
 static void fill_frames(void *arg, uint32_t first, uint32_t count)
 {
     const struct fill_job *j = arg;
-    uint32_t f, ch;
+    uint32_t f, ch, s;
     for (f = first; f < first + count; f++) {
         const uint64_t start = (uint64_t)(j->base + f) * j->S;
         const uint32_t n = (j->num_samples - start < j->S) ? (uint32_t)(j->num_samples - start) : j->S;
         j->nsm[f] = n;
         for (ch = 0; ch < j->C; ch++) {
-            int32_t *dst = j->pcm + ((size_t)f * j->C + ch) * j->S;
-            memcpy(dst, j->input[ch] + start, sizeof(int32_t) * n);
-            if (n < j->S) memset(dst + n, 0, sizeof(int32_t) * (j->S - n));
+            const int32_t *src = j->input[ch] + start;
+            if (j->pcm16) {             /* <= 16 bits per sample: half the bytes over PCIe, widened again by k_prep */
+                int16_t *dst = j->pcm16 + ((size_t)f * j->C + ch) * j->S;
+                for (s = 0; s < n; s++) dst[s] = (int16_t)src[s];
+                if (n < j->S) memset(dst + n, 0, sizeof(int16_t) * (j->S - n));
+            } else {
+                int32_t *dst = j->pcm + ((size_t)f * j->C + ch) * j->S;
+                memcpy(dst, src, sizeof(int32_t) * n);
+                if (n < j->S) memset(dst + n, 0, sizeof(int32_t) * (j->S - n));
+            }
         }
     }
 }
+static int fetch_from_slot(void *arg, uint32_t frame, int32_t *dst) { return LINNEAmd_SlotFetchResidual((struct LINNEAmdSlot *)arg, frame, dst); }
 
 LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int32_t *const *input, uint32_t num_samples,
         uint8_t *data, uint32_t data_size, uint32_t *output_size)
@@ -326,12 +343,12 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
     gp = &encoder->gpus; ndev = gp->ndev;
     t_begin = now_s();
     F = (uint32_t)(((uint64_t)num_samples + S - 1) / S);
-    group = default_group((F + ndev - 1) / ndev); if (group > F) group = F;
+    group = default_group((F + ndev - 1) / ndev, &encoder->shape, &encoder->layers, 1); if (group > F) group = F;
     ngroups = (F + group - 1) / group;
     /* group g goes to device g mod ndev, slot (g / ndev) mod nslots of that device: ndev * nslots groups in flight */
     nslots = (ngroups + ndev - 1) / ndev; if (nslots > LNN_SLOTS) nslots = LNN_SLOTS;
     window = ndev * nslots;
-    if (F > 32) for (f = 0; f < ndev; f++) (void)LINNEAmd_ReserveScratch(gp->ctx[f], 2ull << 30);
+    if (F > 32) for (f = 0; f < ndev; f++) (void)LINNEAmd_ReserveScratch(gp->ctx[f], LINNEAmd_ScratchBytesPerFrame(&encoder->shape) * group + (1ull << 20));     /* a group = one launch chunk */
     if ((ret = want_slots(gp, &encoder->shape, group, nslots, 1)) != 0) {
         report(gp->ctx[ret - 1], "SlotCreate", LNN_NG); return LINNE_APIRESULT_NG;
     }
@@ -343,7 +360,7 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
             struct LINNEAmdSlot *sl = gp->slot[submitted % ndev][(submitted / ndev) % nslots];
             struct fill_job fj;
             const uint32_t base = submitted * group, cnt = (F - base < group) ? (F - base) : group;
-            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.nsm = nsm + (size_t)(submitted % window) * group;
+            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.pcm16 = LINNEAmd_SlotPcm16(sl); fj.nsm = nsm + (size_t)(submitted % window) * group;
             fj.C = C; fj.S = S; fj.num_samples = num_samples; fj.base = base;
             t0 = now_s();
             lnn_parallel_for(cnt, threads, fill_frames, &fj);
@@ -358,11 +375,17 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
             const uint32_t base = packed * group, cnt = (F - base < group) ? (F - base) : group;
             t0 = now_s();
             ret = LINNEAmd_SlotWait(sl);
+            if (trace_on() > 1) fprintf(stderr, "liblinne_amd:   group %u (%u frames): waited %.1f ms, ready at %.1f ms\n", packed, cnt, (now_s() - t0) * 1e3, (now_s() - t_begin) * 1e3);
             t_wait += now_s() - t0; t0 = now_s();
             if (ret != LNN_OK) { report(gp->ctx[packed % ndev], "SlotWait", ret); goto done; }
-            ret = LINNEAmd_PackFramesPlanned(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % window) * group, cnt,
-                    LINNEAmd_SlotData(sl), LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), LINNEAmd_SlotRicePlan(sl),
-                    data + off, data_size - off, sizes, &encoder->parcor_state, threads);
+            if (LINNEAmd_SlotFlags(sl) & LINNE_AMD_SLOT_EMIT)       /* the device wrote the Rice codes: stitch */
+                ret = LINNEAmd_PackFramesEmitted(&encoder->shape, input, (uint64_t)base * S, nsm + (size_t)(packed % window) * group, cnt,
+                        LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), LINNEAmd_SlotRicePlan(sl), LINNEAmd_SlotPacked(sl), LINNEAmd_SlotOffsets(sl),
+                        fetch_from_slot, sl, data + off, data_size - off, sizes, &encoder->parcor_state, threads);
+            else
+                ret = LINNEAmd_PackFramesPlanned(&encoder->shape, LINNEAmd_SlotPcm(sl), nsm + (size_t)(packed % window) * group, cnt,
+                        LINNEAmd_SlotData(sl), LINNEAmd_SlotParams(sl), LINNEAmd_SlotStats(sl), LINNEAmd_SlotRicePlan(sl),
+                        data + off, data_size - off, sizes, &encoder->parcor_state, threads);
             t_pack += now_s() - t0;
             if (ret != LNN_OK) goto done;
             for (f = 0; f < cnt; f++) off += sizes[f];
@@ -595,7 +618,7 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
         /* group g of blocks goes to device g mod ndev, slot (g / ndev) mod LNN_SLOTS of that device */
         if (gp->ndev == 0) { gp->ndev = lnn_parse_device_list(getenv("LINNE_AMD_DEVICES"), gp->device, LNN_MAX_DEVICES); if (gp->ndev == 0) { const char *e = getenv("LINNE_AMD_DEVICE"); gp->device[0] = e ? atoi(e) : 0; gp->ndev = 1; } }
         ndev = gp->ndev; window = ndev * LNN_SLOTS;
-        group = default_group((F + ndev - 1) / ndev); if (group > F) group = F ? F : 1;
+        group = default_group((F + ndev - 1) / ndev, &decoder->shape, &decoder->layers, 0); if (group > F) group = F ? F : 1;
     }
     for (ngalloc = 0; ngalloc < window; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;

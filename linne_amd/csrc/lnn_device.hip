@@ -70,6 +70,7 @@ struct LINNEAmdContext {
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
     int prod_ok;                        /* set per batch by build_classes, bit l: in layer l every class has all its trials and even unit lengths (k_autocorr_prod) */
     int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
+    int pcm16_next;                     /* the next EncodeFramesDevice call reads int16 samples (set by the staging slots, cleared by the call) */
     int force_exact;                    /* LINNE_AMD_EXACT=1: every unit-count search runs the exact ordered chains (diff against the certified search) */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
 };
@@ -520,6 +521,13 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     return b + 4096;
 }
 
+extern "C" uint64_t LINNEAmd_ScratchBytesPerFrame(const struct LINNEAmdShape *shape)
+{
+    HostShape hs;
+    if (shape_info(shape, &hs) != LNN_OK) return 0;
+    return frame_scratch_bytes(shape, &hs);
+}
+
 /* k_fir2 launcher: layer 0 reads the int32 channel (L0); `spec` = the search also writes the one-unit trial's forward output
  * (MODE 2) / the forward pass skips the jobs that chose one unit (MODE 1) */
 template <int MODE> static void launch_fir(hipStream_t st, const Plan &p, uint32_t l, uint32_t cur, uint32_t J, uint32_t tiles, bool spec)
@@ -546,6 +554,8 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
 {
     if (!ctx) return LNN_INVALID_ARGUMENT;
     ctx->err[0] = 0;
+    const uint32_t pcm16 = ctx->pcm16_next ? 1u : 0u;
+    ctx->pcm16_next = 0;
     if (!shape || !d_pcm || !d_residual || !d_params || !d_stats) { snprintf(ctx->err, sizeof(ctx->err), "null argument"); return LNN_INVALID_ARGUMENT; }
     if (num_frames == 0) return LNN_OK;
     HostShape hs;
@@ -593,7 +603,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         ps.C = C; ps.S = S; ps.bits = shape->bits_per_sample; ps.L = hs.L; ps.R = hs.R; ps.F = num_frames;
         for (uint32_t l = 0; l < hs.L; l++) ps.P[l] = hs.P[l];
         ps.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
-        ps.pcm = d_pcm; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.frame_map = ctx->d_map; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
+        ps.pcm = d_pcm; ps.pcm16 = pcm16; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.frame_map = ctx->d_map; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
         hipStream_t ss = ctx->stream;
         if (ctx->has_side && use_sub) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
         const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps); span_end(ctx, sp_, ss);
@@ -610,7 +620,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
         for (uint32_t r = 0; r < hs.R; r++) p.regs[r] = hs.regs[r];
         p.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
-        p.pcm = d_pcm; p.resid = d_residual; p.prm = d_params; p.stats = d_stats;      /* the caller's arrays: rows of the class-sorted chunk reach them through frame_map */
+        p.pcm = d_pcm; p.pcm16 = pcm16; p.resid = d_residual; p.prm = d_params; p.stats = d_stats;      /* the caller's arrays: rows of the class-sorted chunk reach them through frame_map */
         /* last layer: forward pass + loss in one kernel for the jobs it takes (fwd_loss_takes); the two-kernel form runs only
          * when the chunk holds frames it does not take */
         const uint32_t Plast = hs.P[hs.L - 1];
@@ -889,15 +899,43 @@ extern "C" int LINNEAmd_RicePlanDevice(struct LINNEAmdContext *ctx, const struct
     return LNN_OK;
 }
 
+/* Rice emission on the device: see lnn_k_rice.h.  d_plan is RicePlanDevice's output for the same batch (it carries every
+ * channel's code length); enqueues the scan and the emission on the context's stream. */
+extern "C" int LINNEAmd_RiceEmitDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const int32_t *d_residual, uint32_t num_frames, const uint8_t *d_plan,
+        uint32_t *d_offsets, uint8_t *d_packed, uint64_t packed_capacity)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->err[0] = 0;
+    if (!shape || !d_residual || !d_plan || !d_offsets || !d_packed) { snprintf(ctx->err, sizeof(ctx->err), "null argument"); return LNN_INVALID_ARGUMENT; }
+    if (num_frames == 0) return LNN_OK;
+    const uint64_t CF = (uint64_t)num_frames * shape->num_channels;
+    if (CF > 0x7FFFFFFFull || ctx->plan_nsmp_cap < sizeof(uint32_t) * (uint64_t)num_frames) { snprintf(ctx->err, sizeof(ctx->err), "RiceEmitDevice: call RicePlanDevice for the same batch first"); return LNN_INVALID_ARGUMENT; }
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    RiceEmitArgs a; memset(&a, 0, sizeof(a));
+    a.resid = d_residual; a.nsmp = ctx->d_plan_nsmp; a.plan = d_plan; a.offsets = d_offsets; a.packed = d_packed;
+    a.packed_cap = packed_capacity & ~(uint64_t)15; a.C = shape->num_channels; a.S = shape->num_samples_per_block; a.CF = (uint32_t)CF;
+    a.cap_bytes = shape->num_samples_per_block * 4u;
+    { const char *e_ = getenv("LINNE_AMD_RICE_EMIT_CAP"); if (e_) a.cap_bytes = (uint32_t)atol(e_); }      /* test knob: forces the host fallback */
+    { const int sp_ = span_begin(ctx, 24, ctx->stream);
+      hipLaunchKernelGGL(k_rice_scan, dim3(1), dim3(RSCAN_THREADS), 0, ctx->stream, a);
+      hipLaunchKernelGGL(k_rice_emit, dim3((uint32_t)CF), dim3(REMIT_THREADS), 0, ctx->stream, a);
+      span_end(ctx, sp_, ctx->stream); }
+    HIPCHK(ctx, hipGetLastError());
+    return LNN_OK;
+}
+
 /* ================================================================================================
  * staging slots: pinned host buffers + device buffers for a group of frames.  Submit enqueues H2D (copy-in
  * stream), the kernels (context stream) and D2H (copy-out stream) chained by events and returns at once, so a
  * caller that rotates over a few slots overlaps its own host work (entropy stage), PCIe and the kernels.
  * ============================================================================================== */
 struct LINNEAmdSlot {
-    LINNEAmdContext *ctx; struct LINNEAmdShape shape; uint32_t max_frames; int for_encode;
+    LINNEAmdContext *ctx; struct LINNEAmdShape shape; uint32_t max_frames; int for_encode; uint32_t flags;
     int32_t *h_pcm, *h_data, *h_prm; double *h_st; uint8_t *h_plan;
     int32_t *d_pcm, *d_data, *d_prm; double *d_st; uint8_t *d_plan;
+    /* emit mode: the channels' Rice code, packed back to back, instead of the residual */
+    uint8_t *h_packed, *d_packed; uint64_t packed_cap; uint32_t *h_offsets, *d_offsets;
     hipEvent_t ev_in, ev_k, ev_done; int pending;
 };
 
@@ -921,6 +959,10 @@ extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
     if (s->h_st) hipHostFree(s->h_st);
     if (s->h_plan) hipHostFree(s->h_plan);
     if (s->d_plan) hipFree(s->d_plan);
+    if (s->h_packed) hipHostFree(s->h_packed);
+    if (s->d_packed) hipFree(s->d_packed);
+    if (s->h_offsets) hipHostFree(s->h_offsets);
+    if (s->d_offsets) hipFree(s->d_offsets);
     if (s->d_pcm) hipFree(s->d_pcm);
     if (s->d_data) hipFree(s->d_data);
     if (s->d_prm) hipFree(s->d_prm);
@@ -934,6 +976,12 @@ extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
 extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         uint32_t max_frames, int for_encode)
 {
+    return LINNEAmd_SlotCreateEx(ctx, shape, max_frames, for_encode, 0u);
+}
+
+extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        uint32_t max_frames, int for_encode, uint32_t flags)
+{
     HostShape hs;
     if (!ctx) return NULL;
     ctx->err[0] = 0;
@@ -941,19 +989,33 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx,
     if (hipSetDevice(ctx->device) != hipSuccess || ctx_copy_streams(ctx) != LNN_OK) return NULL;
     LINNEAmdSlot *s = (LINNEAmdSlot *)calloc(1, sizeof(*s));
     if (!s) return NULL;
-    s->ctx = ctx; s->shape = *shape; s->max_frames = max_frames; s->for_encode = for_encode;
+    if (!for_encode) flags = 0;
+    if (shape->bits_per_sample > 16) flags &= ~(uint32_t)LINNE_AMD_SLOT_PCM16;
+    s->ctx = ctx; s->shape = *shape; s->max_frames = max_frames; s->for_encode = for_encode; s->flags = flags;
     const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * max_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * max_frames,
                    sb = sizeof(double) * LINNE_AMD_STAT_WORDS * (uint64_t)shape->num_channels * max_frames;
     hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_data, nb, hipHostMallocDefault);
+    const bool emit = (flags & LINNE_AMD_SLOT_EMIT) != 0, pcm16 = (flags & LINNE_AMD_SLOT_PCM16) != 0;
+    if (e == hipSuccess && !emit) e = hipHostMalloc((void **)&s->h_data, nb, hipHostMallocDefault);       /* emit mode: the residual stays on the device */
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_prm, pb, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_data, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_prm, pb);
     if (for_encode) {
-        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pcm, nb, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pcm, pcm16 ? nb / 2 : nb, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_st, sb, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->d_pcm, nb);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_pcm, pcm16 ? nb / 2 : nb);
+        if (emit) {
+            /* room for the code of a group: what the samples' own width would take, a little more than any audio that is
+             * not emitted RAW anyway needs; channels that do not fit fall back to the host (offset 0xFFFFFFFF) */
+            const uint64_t CF = (uint64_t)shape->num_channels * max_frames;
+            s->packed_cap = (CF * ((uint64_t)shape->num_samples_per_block * ((shape->bits_per_sample + 7u) / 8u) + 64u) + 4095u) & ~(uint64_t)4095u;
+            if (s->packed_cap > 0xFFFFFFF0ull) s->packed_cap = 0xFFFFF000ull;
+            if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_packed, s->packed_cap, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_packed, s->packed_cap);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_offsets, sizeof(uint32_t) * (CF + 1), hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_offsets, sizeof(uint32_t) * (CF + 1));
+        }
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_st, sb);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames);
@@ -965,7 +1027,21 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx,
     return s;
 }
 
-extern "C" int32_t *LINNEAmd_SlotPcm(struct LINNEAmdSlot *s) { return s ? s->h_pcm : NULL; }
+extern "C" int32_t *LINNEAmd_SlotPcm(struct LINNEAmdSlot *s) { return (s && !(s->flags & LINNE_AMD_SLOT_PCM16)) ? s->h_pcm : NULL; }
+extern "C" int16_t *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *s) { return (s && (s->flags & LINNE_AMD_SLOT_PCM16)) ? (int16_t *)s->h_pcm : NULL; }
+extern "C" const uint8_t *LINNEAmd_SlotPacked(struct LINNEAmdSlot *s) { return s ? s->h_packed : NULL; }
+extern "C" const uint32_t *LINNEAmd_SlotOffsets(struct LINNEAmdSlot *s) { return s ? s->h_offsets : NULL; }
+extern "C" uint32_t LINNEAmd_SlotFlags(const struct LINNEAmdSlot *s) { return s ? s->flags : 0; }
+
+/* emit mode keeps the residual on the device; the host asks for a frame's residual only when it has to code a channel
+ * itself (flagged plan, code that did not fit): synchronous, valid until the slot is submitted again */
+extern "C" int LINNEAmd_SlotFetchResidual(struct LINNEAmdSlot *s, uint32_t frame, int32_t *dst)
+{
+    if (!s || !dst || !s->for_encode || frame >= s->max_frames) return LNN_INVALID_ARGUMENT;
+    const uint64_t fb = sizeof(int32_t) * (uint64_t)s->shape.num_channels * s->shape.num_samples_per_block;
+    if (hipSetDevice(s->ctx->device) != hipSuccess || hipMemcpy(dst, (const uint8_t *)s->d_data + fb * frame, fb, hipMemcpyDeviceToHost) != hipSuccess) return LNN_NG;
+    return LNN_OK;
+}
 extern "C" int32_t *LINNEAmd_SlotData(struct LINNEAmdSlot *s) { return s ? s->h_data : NULL; }
 extern "C" int32_t *LINNEAmd_SlotParams(struct LINNEAmdSlot *s) { return s ? s->h_prm : NULL; }
 extern "C" double *LINNEAmd_SlotStats(struct LINNEAmdSlot *s) { return s ? s->h_st : NULL; }
@@ -991,15 +1067,21 @@ extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t 
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames, sb = sizeof(double) * LINNE_AMD_STAT_WORDS * C * num_frames;
-    HIPCHK(ctx, hipMemcpyAsync(s->d_pcm, s->h_pcm, nb, hipMemcpyHostToDevice, ctx->copy_in));
+    const bool emit = (s->flags & LINNE_AMD_SLOT_EMIT) != 0, pcm16 = (s->flags & LINNE_AMD_SLOT_PCM16) != 0;
+    HIPCHK(ctx, hipMemcpyAsync(s->d_pcm, s->h_pcm, pcm16 ? nb / 2 : nb, hipMemcpyHostToDevice, ctx->copy_in));
     HIPCHK(ctx, hipEventRecord(s->ev_in, ctx->copy_in));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
-    HIPCHK(ctx, hipMemsetAsync(s->d_prm, 0, pb, ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(s->d_st, 0, sb, ctx->stream));
+    ctx->pcm16_next = pcm16 ? 1 : 0;
     if ((ret = LINNEAmd_EncodeFramesDevice(ctx, &s->shape, s->d_pcm, num_samples, num_frames, s->d_data, s->d_prm, s->d_st)) != LNN_OK) return ret;
     if ((ret = LINNEAmd_RicePlanDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_plan)) != LNN_OK) return ret;
+    if (emit && (ret = LINNEAmd_RiceEmitDevice(ctx, &s->shape, s->d_data, num_frames, s->d_plan, s->d_offsets, s->d_packed, s->packed_cap)) != LNN_OK) return ret;
     HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
+    if (emit) {         /* the code's used bytes (a size only the device knows so far) by a copy kernel, then the offsets */
+        hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, ctx->copy_out, (const uint4 *)s->d_packed, (uint4 *)s->h_packed, (const uint32_t *)(s->d_offsets + (size_t)C * num_frames));
+        HIPCHK(ctx, hipMemcpyAsync(s->h_offsets, s->d_offsets, sizeof(uint32_t) * (C * num_frames + 1), hipMemcpyDeviceToHost, ctx->copy_out));
+    } else
     HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipMemcpyAsync(s->h_prm, s->d_prm, pb, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipMemcpyAsync(s->h_st, s->d_st, sb, hipMemcpyDeviceToHost, ctx->copy_out));

@@ -81,6 +81,17 @@ static inline void bw_zero_run_then_one(struct bitw *w, uint32_t run)   /* `run`
     while (run >= 32) { bw_put56(w, 0, 32); run -= 32; }
     bw_put56(w, 1, run + 1);
 }
+/* appends `nbits` bits of a byte-aligned, MSB-first source at the writer's bit position (the device's Rice code of a channel) */
+static void bw_append_bits(struct bitw *w, const uint8_t *src, uint64_t nbits)
+{
+    while (nbits >= 32) {
+        const uint32_t v = ((uint32_t)src[0] << 24) | ((uint32_t)src[1] << 16) | ((uint32_t)src[2] << 8) | src[3];
+        bw_put56(w, v, 32);
+        src += 4; nbits -= 32;
+    }
+    while (nbits >= 8) { bw_put56(w, *src++, 8); nbits -= 8; }
+    if (nbits) bw_put56(w, (uint64_t)(*src >> (8u - nbits)), (uint32_t)nbits);
+}
 static void bw_flush(struct bitw *w)                        /* pads the last byte with zeros */
 {
     if (w->n) { const uint8_t last = (uint8_t)(w->acc << (8u - w->n)); if (w->p < w->end) *w->p++ = last; else w->overflow = 1; w->n = 0; }
@@ -250,6 +261,7 @@ struct rice_scratch {
     double mean[RICE_LOG2_PARTS + 1][RICE_PARTS]; uint8_t k2[RICE_LOG2_PARTS + 1][RICE_PARTS];
     uint32_t prefix[RICE_MAX_DISTINCT][RICE_PARTS + 1];
     uint32_t *u; uint32_t ucap; uint32_t *t; uint32_t tcap;
+    int32_t *fetched; uint64_t fcap;    /* a frame's residual, brought in from the device for a channel without a device code */
 };
 /* prefix[i] = sum over the first i finest partitions (ns samples each) of the excess under parameter k */
 __attribute__((target_clones("avx512f", "avx2", "default")))
@@ -475,8 +487,27 @@ int lnn_shape_layers(const struct LINNEAmdShape *shape, struct lnn_layers *out)
 /* Block-type decision (linne_encoder.c:480-529) from the device statistics; the transcendental part of
  * LPCCalculator_EstimateCodeLength (lpc.c:832-859) runs here with the host libm.  *state carries what the
  * reference's calculator holds in parcor[order] (oracle quirk Q2). */
+/* where a frame's PCM lives: a frames array [F][C][S] (frame f, channel ch at frames + (f * C + ch) * S) or the caller's planes
+ * (channel ch of frame f at planes[ch] + first_sample + f * S) */
+struct pcm_view { const int32_t *frames; const int32_t *const *planes; uint64_t first_sample; };
+static inline const int32_t *pcm_channel(const struct pcm_view *v, const struct LINNEAmdShape *shape, uint64_t f, uint32_t ch)
+{
+    const uint64_t S = shape->num_samples_per_block;
+    return v->frames ? v->frames + (f * shape->num_channels + ch) * S : v->planes[ch] + v->first_sample + f * S;
+}
+
+static uint32_t decide_block_type_view(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t n,
+        const struct pcm_view *pv, uint64_t f, const double *stats_frame, double *state);
+
 uint32_t lnn_decide_block_type(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t n,
         const int32_t *pcm_frame, const double *stats_frame, double *state)
+{
+    struct pcm_view pv; pv.frames = pcm_frame; pv.planes = NULL; pv.first_sample = 0;
+    return decide_block_type_view(shape, ly, n, &pv, 0, stats_frame, state);
+}
+
+static uint32_t decide_block_type_view(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t n,
+        const struct pcm_view *pv, uint64_t f, const double *stats_frame, double *state)
 {
     const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, order = ly->size[0];
     uint32_t ch, s, ord;
@@ -503,15 +534,18 @@ uint32_t lnn_decide_block_type(const struct LINNEAmdShape *shape, const struct l
     mean /= bits;
     if (mean >= 0.95f) return LNN_BLOCK_RAW;
     for (ch = 0; ch < C; ch++) {
-        const int32_t *x = pcm_frame + (size_t)ch * shape->num_samples_per_block;
+        const int32_t *x = pcm_channel(pv, shape, f, ch);
         for (s = 0; s < n; s++) if (x[s] != 0) return LNN_BLOCK_COMPRESS;
     }
     return LNN_BLOCK_SILENT;
 }
 
 /* serialises one block (linne_encoder.c:806-855); returns LNN_* and the byte count */
+/* emitted: the device's Rice code of this frame's channels (packed + offsets[ch], bit lengths in the plan records); a channel
+ * without one (offset 0xFFFFFFFF) is coded here from the residual, which fetch() brings in when the caller did not pass it */
+struct emitted { const uint8_t *packed; const uint32_t *offsets; int (*fetch)(void *arg, uint32_t frame, int32_t *dst); void *fetch_arg; uint32_t frame; };
 static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, uint32_t type, uint32_t n,
-        const int32_t *pcm, const int32_t *residual, const int32_t *params, const uint8_t *plan,
+        const struct pcm_view *pv, uint64_t f, const int32_t *residual, const int32_t *params, const uint8_t *plan, const struct emitted *em,
         uint8_t *out, uint64_t cap, uint32_t *size_out, struct rice_scratch *sc)
 {
     const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, S = shape->num_samples_per_block;
@@ -526,7 +560,7 @@ static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers
         if (cap - 11 < ((uint64_t)bits * n * C) / 8) return LNN_INSUFFICIENT_BUFFER;
         for (s = 0; s < n; s++)
             for (ch = 0; ch < C; ch++) {
-                const uint32_t u = zz(pcm[(size_t)ch * S + s]);
+                const uint32_t u = zz(pcm_channel(pv, shape, f, ch)[s]);
                 if (bits == 24) *p++ = (uint8_t)(u >> 16);
                 if (bits >= 16) *p++ = (uint8_t)(u >> 8);
                 *p++ = (uint8_t)u;
@@ -556,6 +590,17 @@ static int pack_block(const struct LINNEAmdShape *shape, const struct lnn_layers
         for (ch = 0; ch < C; ch++) {
             /* the device's plan (order + parameters) when there is one and none of its means sat in a guard band */
             const uint8_t *pl = plan ? plan + (size_t)ch * LINNE_AMD_RICE_PLAN_BYTES : NULL;
+            if (em && pl && em->offsets[ch] != 0xFFFFFFFFu) {          /* the code itself came from the device: append it */
+                uint32_t nb; memcpy(&nb, pl + LINNE_AMD_RICE_PLAN_NBITS, 4);
+                bw_append_bits(&w, em->packed + em->offsets[ch], nb);
+                continue;
+            }
+            if (!residual) {                                         /* emit mode: the residual stayed on the device */
+                if (!em || !em->fetch) return LNN_NG;
+                if (sc->fcap < (uint64_t)C * S) { free(sc->fetched); sc->fetched = malloc(sizeof(int32_t) * (size_t)C * S); sc->fcap = sc->fetched ? (uint64_t)C * S : 0; if (!sc->fetched) return LNN_NG; }
+                if (em->fetch(em->fetch_arg, em->frame, sc->fetched) != LNN_OK) return LNN_NG;
+                residual = sc->fetched;
+            }
             if (pl && pl[1] == 0 && pl[0] <= RICE_LOG2_PARTS && (n % (1u << pl[0])) == 0)
                 rice_emit(&w, residual + (size_t)ch * S, n, pl[0], pl + LINNE_AMD_RICE_PLAN_K2);
             else if (rice_encode(&w, residual + (size_t)ch * S, n, sc) != 0) return LNN_NG;
@@ -596,7 +641,8 @@ void lnn_parallel_for(uint32_t count, uint32_t num_threads, void (*fn)(void *arg
  * After the join the regions are copied to their places in the output, again in parallel. */
 struct pack_share {
     const struct LINNEAmdShape *shape; const struct lnn_layers *ly;
-    const int32_t *pcm, *residual, *params; const uint32_t *nsmp; const uint8_t *types, *plan;
+    struct pcm_view pv; const int32_t *residual, *params; const uint32_t *nsmp; const uint8_t *types, *plan;
+    const uint8_t *packed; const uint32_t *offsets; int (*fetch)(void *, uint32_t, int32_t *); void *fetch_arg;
     uint8_t *pool, *out; uint64_t per_slot; uint32_t *sizes; int *rets;
     uint32_t nshare; uint32_t share_first[65]; uint64_t share_dst[65];
 };
@@ -610,13 +656,15 @@ static void pack_range(void *arg, uint32_t first, uint32_t count)
     uint32_t f;
     for (f = first; f < first + count; f++) {
         if (!sc) { j->rets[f] = LNN_NG; continue; }
+        struct emitted em;
+        em.packed = j->packed; em.offsets = j->offsets ? j->offsets + (size_t)f * C : NULL; em.fetch = j->fetch; em.fetch_arg = j->fetch_arg; em.frame = f;
         j->rets[f] = pack_block(j->shape, j->ly, j->types[f], j->nsmp ? j->nsmp[f] : j->shape->num_samples_per_block,
-                j->pcm + f * CS, j->residual + f * CS, j->params + (size_t)f * C * LINNE_AMD_PARAM_WORDS,
-                j->plan ? j->plan + (size_t)f * C * LINNE_AMD_RICE_PLAN_BYTES : NULL,
+                &j->pv, f, j->residual ? j->residual + f * CS : NULL, j->params + (size_t)f * C * LINNE_AMD_PARAM_WORDS,
+                j->plan ? j->plan + (size_t)f * C * LINNE_AMD_RICE_PLAN_BYTES : NULL, j->offsets ? &em : NULL,
                 cursor, j->per_slot, &j->sizes[f], sc);
         if (j->rets[f] == LNN_OK) cursor += j->sizes[f];
     }
-    if (sc) { free(sc->u); free(sc->t); free(sc); }
+    if (sc) { free(sc->u); free(sc->t); free(sc->fetched); free(sc); }
 }
 static void copy_range(void *arg, uint32_t first, uint32_t count)
 {
@@ -664,10 +712,43 @@ int LINNEAmd_PackFrames(const struct LINNEAmdShape *shape, const int32_t *pcm, c
             blocks_out, blocks_capacity, block_sizes, parcor_state, num_threads);
 }
 
+static int pack_frames_core(const struct LINNEAmdShape *shape, const struct pcm_view *pv, const uint32_t *num_samples,
+        uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
+        const uint8_t *packed, const uint32_t *offsets, int (*fetch)(void *, uint32_t, int32_t *), void *fetch_arg,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state, uint32_t num_threads);
+
 int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t *pcm, const uint32_t *num_samples,
         uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
         uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
         uint32_t num_threads)
+{
+    struct pcm_view pv; pv.frames = pcm; pv.planes = NULL; pv.first_sample = 0;
+    if (!pcm || !residual) return LNN_INVALID_ARGUMENT;
+    return pack_frames_core(shape, &pv, num_samples, num_frames, residual, params, stats, rice_plan, NULL, NULL, NULL, NULL,
+            blocks_out, blocks_capacity, block_sizes, parcor_state, num_threads);
+}
+
+/* The host stage when the device wrote the Rice codes (LINNEAmd_RiceEmitDevice / staging slots with LINNE_AMD_SLOT_EMIT): block
+ * types in stream order (quirk Q2), then per block the header, the parameter bits (linne_encoder.c:698-735), the channels' codes
+ * appended at the running bit position, padding and CRC16 (:743-749, :848-855).  The frames' PCM is read in place from the
+ * caller's planes (frame f of the batch starts at sample first_sample + f * num_samples_per_block of every plane): it is needed
+ * for the SILENT test and for RAW blocks only.  fetch(arg, frame, dst[C][S]) must deliver a frame's residual; it is called for
+ * the (rare) channel-frames without a device code. */
+int LINNEAmd_PackFramesEmitted(const struct LINNEAmdShape *shape, const int32_t *const *planes, uint64_t first_sample,
+        const uint32_t *num_samples, uint32_t num_frames, const int32_t *params, const double *stats, const uint8_t *rice_plan,
+        const uint8_t *packed, const uint32_t *offsets, int (*fetch)(void *arg, uint32_t frame, int32_t *dst), void *fetch_arg,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state, uint32_t num_threads)
+{
+    struct pcm_view pv; pv.frames = NULL; pv.planes = planes; pv.first_sample = first_sample;
+    if (!planes || !rice_plan || !packed || !offsets) return LNN_INVALID_ARGUMENT;
+    return pack_frames_core(shape, &pv, num_samples, num_frames, NULL, params, stats, rice_plan, packed, offsets, fetch, fetch_arg,
+            blocks_out, blocks_capacity, block_sizes, parcor_state, num_threads);
+}
+
+static int pack_frames_core(const struct LINNEAmdShape *shape, const struct pcm_view *pv, const uint32_t *num_samples,
+        uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
+        const uint8_t *packed, const uint32_t *offsets, int (*fetch)(void *, uint32_t, int32_t *), void *fetch_arg,
+        uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state, uint32_t num_threads)
 {
     struct lnn_layers ly;
     uint8_t *types = NULL, *pool = NULL;
@@ -676,7 +757,7 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
     int *rets = NULL, ret = LNN_OK;
     double state = parcor_state ? *parcor_state : 0.0;
     uint32_t f, t, C;
-    if (!shape || !pcm || !residual || !params || !stats || !blocks_out || !block_sizes) return LNN_INVALID_ARGUMENT;
+    if (!shape || !params || !stats || !blocks_out || !block_sizes) return LNN_INVALID_ARGUMENT;
     if (lnn_shape_layers(shape, &ly) != 0) return LNN_INVALID_FORMAT;
     if (num_frames == 0) return LNN_OK;
     lnn_tables_init();
@@ -689,7 +770,7 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
     for (f = 0; f < num_frames; f++) {
         const uint32_t n = num_samples ? num_samples[f] : shape->num_samples_per_block;
         const double *st = stats + (size_t)f * C * LINNE_AMD_STAT_WORDS;
-        types[f] = (uint8_t)lnn_decide_block_type(shape, &ly, n, pcm + f * CS, st, &state);
+        types[f] = (uint8_t)decide_block_type_view(shape, &ly, n, pv, f, st, &state);
         if (types[f] == LNN_BLOCK_COMPRESS) state = st[(size_t)(C - 1) * LINNE_AMD_STAT_WORDS + LINNE_AMD_ST_TAIL];
     }
     if (parcor_state) *parcor_state = state;
@@ -704,7 +785,8 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
         if (num_threads == 0) num_threads = 1;
         if (num_threads > 64) num_threads = 64;
         nt = (num_threads < num_frames) ? num_threads : num_frames;
-        sh.shape = shape; sh.ly = &ly; sh.pcm = pcm; sh.residual = residual; sh.params = params; sh.nsmp = num_samples;
+        sh.shape = shape; sh.ly = &ly; sh.pv = *pv; sh.residual = residual; sh.params = params; sh.nsmp = num_samples;
+        sh.packed = packed; sh.offsets = offsets; sh.fetch = fetch; sh.fetch_arg = fetch_arg;
         sh.types = types; sh.plan = rice_plan; sh.pool = pool; sh.out = blocks_out; sh.per_slot = per_slot; sh.sizes = block_sizes; sh.rets = rets;
         lnn_parallel_for(num_frames, nt, pack_range, &sh);
         for (f = 0; f < num_frames; f++) if (rets[f] != LNN_OK) { ret = rets[f]; goto done; }

@@ -45,7 +45,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
     const uint32_t fo = p.frame_map[f];                      /* the caller's frame behind row f of the class-sorted chunk */
-    const int32_t *in = p.pcm + (size_t)fo * C * S;
+    const size_t inbase = (size_t)fo * C * S;                /* input PCM: int32, or int16 when the caller staged 16-bit samples (Plan.pcm16) */
     int32_t *src = p.xint + ((size_t)f * C + ch) * S, *dst = p.xtmp + ((size_t)f * C + ch) * S;
     int32_t *rec = p.prm + ((size_t)fo * C + ch) * LINNE_AMD_PARAM_WORDS;
 
@@ -54,9 +54,9 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
     for (uint32_t s = tid; s < S; s += PREP_THREADS) {
         int32_t v = 0;
         if (s < n) {
-            v = in[(size_t)ch * S + s];
+            v = pcm_at(p, inbase + (size_t)ch * S + s);
             if (p.ms && ch < 2) {
-                const uint32_t l = (uint32_t)in[s], r = (uint32_t)in[(size_t)S + s];
+                const uint32_t l = (uint32_t)pcm_at(p, inbase + s), r = (uint32_t)pcm_at(p, inbase + (size_t)S + s);
                 const int32_t side = (int32_t)(r - l);
                 v = (ch == 1) ? side : (int32_t)(l + (uint32_t)(side >> 1));
             }
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(STAT_THREADS) void k_stats(Plan p)
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
     const uint32_t fo = p.frame_map[f];
-    const int32_t *x = p.pcm + ((size_t)fo * C + ch) * S;
+    const size_t xbase = ((size_t)fo * C + ch) * S;
     const uint32_t P0 = p.P[0];                              /* 2 or 4 */
     const double *sinw = p.sintab + c.sin_off;
     double r = 0.0;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(STAT_THREADS) void k_stats(Plan p)
         __syncthreads();
         for (uint32_t i = tid; i < STAT_CHUNK + P0; i += STAT_THREADS) {
             const uint32_t g = base + i;
-            sv[i] = (g < n) ? ((double)x[g] * p.scale) * sinw[g] : 0.0;
+            sv[i] = (g < n) ? ((double)pcm_at(p, xbase + g) * p.scale) * sinw[g] : 0.0;
         }
         __syncthreads();
         for (uint32_t idx = tid; idx < (P0 + 1) * STAT_CHUNK; idx += STAT_THREADS) {

@@ -85,10 +85,162 @@ __global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(RicePlanArgs a)
         for (uint32_t o = 0; o <= max_order; o++) if (min_bits > tot[o]) { min_bits = tot[o]; best = o; }
         best_s = best;
         rec[0] = (uint8_t)best; rec[1] = (uint8_t)flag;
+        /* length of this channel's code in bits: the order field + what the search counted for the winning order
+         * (k_rice_scan / k_rice_emit lay the code out from it) */
+        *(uint32_t *)(rec + LINNE_AMD_RICE_PLAN_NBITS) = flag ? 0xFFFFFFFFu : (10u + min_bits);
     }
     __syncthreads();
     const uint32_t best = best_s;
     for (uint32_t p = tid; p < (1u << best); p += RICE_THREADS) rec[LINNE_AMD_RICE_PLAN_K2 + p] = kk[((1u << best) - 1u) + p];
+}
+
+
+/* ================================================================================================
+ * Rice EMISSION on the device (linne_coder.c:281-302, bit_stream.h:240-282).  With the plan known, every
+ * sample's code and its length follow from the sample alone, so the bit position of every code is an exclusive scan of the
+ * lengths: k_rice_scan places the channel-frames of a batch back to back (8-byte aligned) in one buffer, k_rice_emit
+ * writes each channel's code there exactly as the host's rice_emit would -- 10-bit order, per partition its parameter (5 bits,
+ * then gamma-coded steps) and its samples' recursive Rice codes, MSB first -- and k_copy_out moves the used part of the
+ * buffer to pinned host memory.  The host then only stitches: block header, parameter bits, the channels' code appended at
+ * the running bit position, CRC16 (lnn_entropy.c).  D2H shrinks from 4 bytes per sample to the code's own size.
+ * A channel whose plan is flagged (a mean inside a parameter step's guard band) or whose code would not fit `cap_bytes`
+ * gets offset 0xFFFFFFFF: the host fetches its residual and codes it itself.
+ * ============================================================================================== */
+struct RiceEmitArgs {
+    const int32_t *resid; const uint32_t *nsmp; const uint8_t *plan;
+    uint32_t *offsets;                  /* [CF + 1]: byte offset of each channel-frame's code in `packed` (0xFFFFFFFF: none); [CF] = total */
+    uint8_t *packed; uint64_t packed_cap;
+    uint32_t C, S, CF, cap_bytes;
+};
+
+#define RSCAN_THREADS 1024
+__global__ __launch_bounds__(RSCAN_THREADS) void k_rice_scan(RiceEmitArgs a)
+{
+    __shared__ uint64_t wsum[RSCAN_THREADS / 64];
+    __shared__ uint64_t carry;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < a.CF; base += RSCAN_THREADS) {
+        const uint32_t cf = base + tid;
+        uint64_t bytes = 0;
+        if (cf < a.CF) {
+            const uint32_t nb = *(const uint32_t *)(a.plan + (size_t)cf * LINNE_AMD_RICE_PLAN_BYTES + LINNE_AMD_RICE_PLAN_NBITS);
+            const uint64_t b = (((uint64_t)nb + 63u) >> 6) << 3;           /* whole 8-byte words */
+            bytes = (nb == 0xFFFFFFFFu || b > a.cap_bytes) ? 0u : b;
+        }
+        uint64_t incl = bytes;                               /* wave inclusive scan, then the waves' totals */
+#pragma unroll
+        for (uint32_t d = 1; d < 64; d <<= 1) { const uint64_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry;
+        for (uint32_t w = 0; w < wave; w++) before += wsum[w];
+        const uint64_t off = before + incl - bytes;
+        if (cf < a.CF) a.offsets[cf] = (bytes == 0 || off + bytes > a.packed_cap || off + bytes > 0xFFFFFFF0ull) ? 0xFFFFFFFFu : (uint32_t)off;
+        __syncthreads();
+        if (tid == RSCAN_THREADS - 1) carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) a.offsets[a.CF] = (uint32_t)((carry > a.packed_cap) ? a.packed_cap : carry);
+}
+
+/* bit writer of one thread: its codes occupy a contiguous run of bits of the channel's (pre-zeroed) region; the run's first and
+ * last 32-bit words may be shared with the neighbouring threads' runs (atomicOr), the words in between are its own (store) */
+struct RiceBW {
+    uint32_t *dst; uint32_t w, fill, cur, first_w;
+    __device__ __forceinline__ void flush() {
+        if (cur) { const uint32_t be = __builtin_bswap32(cur); if (w == first_w) atomicOr(dst + w, be); else dst[w] = be; }
+        w++; cur = 0; fill = 0;
+    }
+    __device__ __forceinline__ void put(uint32_t val, uint32_t len) {              /* len <= 32, val < 2^len */
+        while (len) {
+            const uint32_t room = 32u - fill, take = len < room ? len : room;
+            const uint32_t bits = (take == 32u) ? val : ((val >> (len - take)) & ((1u << take) - 1u));
+            cur |= bits << (room - take);
+            fill += take; len -= take;
+            if (fill == 32u) flush();
+        }
+    }
+    __device__ __forceinline__ void zeros(uint64_t z) {                              /* the region is zero already: just move on */
+        const uint32_t room = 32u - fill;
+        if (z < room) { fill += (uint32_t)z; return; }
+        z -= room; flush();
+        w += (uint32_t)(z >> 5); fill = (uint32_t)(z & 31u);
+    }
+    __device__ __forceinline__ void finish() { if (cur) atomicOr(dst + w, __builtin_bswap32(cur)); }
+};
+
+#define REMIT_THREADS 256
+__global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit(RiceEmitArgs a)
+{
+    __shared__ uint8_t kk[1024];
+    __shared__ uint64_t wsum[REMIT_THREADS / 64];
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t off = a.offsets[cf];
+    if (off == 0xFFFFFFFFu) return;                          /* block-uniform */
+    const uint8_t *rec = a.plan + (size_t)cf * LINNE_AMD_RICE_PLAN_BYTES;
+    const uint32_t nbits = *(const uint32_t *)(rec + LINNE_AMD_RICE_PLAN_NBITS);
+    const uint32_t n = a.nsmp[cf / a.C], best = rec[0], ns = n >> best, parts = 1u << best;
+    const int32_t *x = a.resid + (size_t)cf * a.S;
+    uint32_t *dst = (uint32_t *)(a.packed + off);
+    const uint32_t nwords = (uint32_t)((((uint64_t)nbits + 63u) >> 6) << 1);
+    for (uint32_t i = tid; i < nwords; i += REMIT_THREADS) dst[i] = 0;
+    for (uint32_t p = tid; p < parts; p += REMIT_THREADS) kk[p] = rec[LINNE_AMD_RICE_PLAN_K2 + p];
+    __syncthreads();
+    /* a thread owns ipt consecutive samples; a partition's parameter code sits in front of the partition's first sample */
+    const uint32_t ipt = (n + REMIT_THREADS - 1) / REMIT_THREADS;
+    const uint32_t s0 = tid * ipt < n ? tid * ipt : n, s1 = (s0 + ipt < n) ? s0 + ipt : n;
+    uint64_t mybits = 0;
+    {
+        uint32_t part = ns ? s0 / ns : 0, loc = ns ? s0 - part * ns : 0;
+        for (uint32_t s = s0; s < s1; s++) {
+            const uint32_t k2 = kk[part], k1 = k2 + 1u, k1pow = 1u << (k1 & 31u);
+            if (loc == 0) mybits += part ? rp_gamma_len(rp_zz((int32_t)k2 - (int32_t)kk[part - 1])) : 15u;
+            const uint32_t v = rp_zz(x[s]);
+            mybits += (v < k1pow) ? (k1 + 1u) : (uint64_t)(((v - k1pow) >> k2) + 2u + k2);
+            if (++loc == ns) { loc = 0; part++; }
+        }
+    }
+    uint64_t incl = mybits;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) { const uint64_t v = __shfl_up(incl, d, 64); if (lane >= d) incl += v; }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint64_t start = incl - mybits;
+    for (uint32_t w = 0; w < wave; w++) start += wsum[w];
+    if (s0 >= s1) return;
+    RiceBW bw; bw.dst = dst; bw.w = bw.first_w = (uint32_t)(start >> 5); bw.fill = (uint32_t)(start & 31u); bw.cur = 0;
+    {
+        uint32_t part = ns ? s0 / ns : 0, loc = ns ? s0 - part * ns : 0;
+        for (uint32_t s = s0; s < s1; s++) {
+            const uint32_t k2 = kk[part], k1 = k2 + 1u, k1pow = 1u << (k1 & 31u);       /* k2 = 31: the count modulo 32, as everywhere */
+            if (loc == 0) {
+                if (part == 0) bw.put((best << 5) | k2, 15u);
+                else {
+                    const uint32_t g = rp_zz((int32_t)k2 - (int32_t)kk[part - 1]);
+                    if (g == 0) bw.put(1u, 1u);
+                    else { const uint32_t nd = 32u - (uint32_t)__clz((int)(g + 1u)); bw.zeros(nd - 1u); bw.put(g + 1u, nd); }
+                }
+            }
+            const uint32_t v = rp_zz(x[s]);
+            if (v < k1pow) { bw.put(1u, 1u); bw.put((k1 == 32u) ? v : (v & ((1u << (k1 & 31u)) - 1u)), k1); }
+            else {
+                const uint32_t d = v - k1pow;
+                bw.zeros((uint64_t)(d >> k2) + 1u);
+                bw.put((1u << k2) | (d & ((1u << k2) - 1u)), k2 + 1u);
+            }
+            if (++loc == ns) { loc = 0; part++; }
+        }
+    }
+    bw.finish();
+}
+
+/* the used part of the packed buffer -> pinned host memory (the device knows the size, the host does not yet) */
+__global__ __launch_bounds__(256) void k_copy_out(const uint4 *src, uint4 *dst, const uint32_t *total_bytes)
+{
+    const uint64_t n16 = ((uint64_t)*total_bytes + 15u) >> 4;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
 
 

@@ -531,3 +531,57 @@ def test_corrupt_streams_decode_to_the_reference_pcm(product):
         else:
             assert ret == want["ret"], f"trial {trial}: the reference rejects this stream with {want['ret']}, the product returns {ret}"
     assert compared >= 40
+
+
+@pytest.mark.parametrize("cap", [None, "64"])
+@pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 24, 4096, 0, 4096), (3, 8, 1024, 2, 1000), (8, 24, 2048, 7, 130)])
+def test_device_rice_emission_equals_the_host_coder(ctx, monkeypatch, nch, bits, block, preset, tail, cap):
+    """Rice EMISSION on the device (k_rice_scan / k_rice_emit; linne_coder.c:281-302 with bit_stream.h's bit order): the codes the
+    device writes, stitched into blocks by LINNEAmd_PackFramesEmitted, must give the bytes of the host coder on the same
+    residual -- music, white noise (long codes), tiny residuals (parameter 0), a silent frame, a ragged tail.  With
+    LINNE_AMD_RICE_EMIT_CAP=64 nothing fits: every channel-frame takes the fetch-the-residual fallback, same bytes again."""
+    import torch
+    if cap:
+        monkeypatch.setenv("LINNE_AMD_RICE_EMIT_CAP", cap)
+    ms = nch >= 2
+    F = 7
+    frames = music_frames(F, nch, block, bits, seed=131 + nch)
+    frames[2] = waveform("white_noise", nch, block, bits, seed=4)
+    frames[3] //= 64
+    frames[4] = 0
+    ns = np.full(F, block, dtype=np.uint32); ns[-1] = tail
+    frames[-1, :, tail:] = 0
+    shape = ctx.shape(nch, bits, block, preset, ms)
+    pcm = torch.from_numpy(frames).cuda()
+    res, prm, st = ctx.encode_frames(shape, pcm, ns)
+    plan = ctx.rice_plan(shape, res, ns)
+    packed, offsets = ctx.rice_emit(shape, res, plan)
+    ctx.synchronize()
+    res, prm, st, plan, packed, offsets = (t.cpu().numpy() for t in (res, prm, st, plan, packed, offsets))
+    want, _ = linne_amd.pack_frames(shape, frames, res, prm, st, ns, 0.0, 2)
+    planes = np.ascontiguousarray(frames.transpose(1, 0, 2).reshape(nch, F * block))
+    got, _, fetched = linne_amd.pack_frames_emitted(shape, planes, 0, prm, st, plan, packed, offsets, ns, 0.0, 2, residual=res)
+    assert got == want
+    off = offsets.view(np.uint32)
+    if cap:
+        assert (off[:-1] == 0xFFFFFFFF).all() and off[-1] == 0 and len(fetched) >= F - 2      # (RAW / SILENT frames need no residual)
+    else:
+        assert (off[:-1] != 0xFFFFFFFF).all() and not fetched
+        nbits = plan[:, :, 4:8].copy().view(np.uint32).reshape(-1)
+        assert int(off[-1]) == int(((nbits.astype(np.uint64) + 63) // 64 * 8).sum())
+
+
+@pytest.mark.parametrize("emit", ["0", "1"])
+def test_whole_stream_with_and_without_device_emission(product, oracle, reference, monkeypatch, emit):
+    """LINNEEncoder_EncodeWhole stages 16-bit PCM as int16 and lets the device write the Rice codes (LINNE_AMD_EMIT, default 1);
+    LINNE_AMD_EMIT=0 keeps int32 staging both ways and the host coder.  Same .lnn either way: the reference's"""
+    monkeypatch.setenv("LINNE_AMD_EMIT", emit)
+    monkeypatch.setenv("LINNE_AMD_GROUP", "3")
+    block = 4096
+    parts = [music(2, 7 * block, 16, seed=41), np.zeros((2, block), dtype=np.int32), waveform("white_noise", 2, 2 * block, 16, seed=6),
+             music(2, 3 * block + 1500, 16, seed=42)]
+    x = np.concatenate(parts, axis=1)
+    mine = product.encode_whole(x, 16, 44100, block, 7, True)
+    assert mine == reference.encode_whole(x, 16, 44100, block, 7, True)
+    x24 = music(3, 5 * 2048 + 99, 24, seed=43)
+    assert product.encode_whole(x24, 24, 96000, 2048, 5, True) == oracle.encode_whole(x24, 24, 96000, 2048, 5, True)

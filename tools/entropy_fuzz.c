@@ -84,7 +84,8 @@ int main(int argc, char **argv)
         type = (rnd() % 8 == 0) ? LNN_BLOCK_RAW : (rnd() % 16 == 0) ? LNN_BLOCK_SILENT : LNN_BLOCK_COMPRESS;
         cap = 64 + (uint64_t)C * (64 + 2 * ly.total) + (uint64_t)C * n * 9;       /* generous: 33+ bits per sample worst case */
         blk = malloc(cap);
-        ret = pack_block(&sh, &ly, type, n, pcm, res, prm, NULL, blk, cap, &size, sc);
+        { struct pcm_view pv; pv.frames = pcm; pv.planes = NULL; pv.first_sample = 0;
+          ret = pack_block(&sh, &ly, type, n, &pv, 0, res, prm, NULL, NULL, blk, cap, &size, sc); }
         if (ret != LNN_OK) { fprintf(stderr, "pack_block failed: %d (type %u n %u C %u kind %u)\n", ret, type, n, C, kind); return 1; }
         blocks++;
         {   /* exact-size copy, round trip */
