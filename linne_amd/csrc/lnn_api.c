@@ -20,7 +20,7 @@
 #include <unistd.h>
 
 #define LNN_ALIGN 16u
-#define LNN_SLOTS 3u                    /* groups of frames in flight in EncodeWhole / DecodeWhole */
+#define LNN_SLOTS 4u                    /* groups of frames in flight in EncodeWhole / DecodeWhole */
 #define ALIGN_UP(v) (((v) + (LNN_ALIGN - 1u)) & ~(uintptr_t)(LNN_ALIGN - 1u))
 
 
@@ -61,7 +61,7 @@ static uint32_t default_group(uint32_t num_frames, const struct LINNEAmdShape *s
 {
     const char *e = getenv("LINNE_AMD_GROUP");
     const uint64_t rows = (uint64_t)shape->num_channels * (for_encode ? ly->num_regs : 1u);
-    const uint64_t want = ((for_encode ? 24576u : 6144u) + rows - 1) / rows + 8;
+    const uint64_t want = ((for_encode ? 30720u : 6144u) + rows - 1) / rows;     /* a quarter above the threshold: the lanes = jobs kernels are still filling the chip there */
     const uint64_t cap = (1ull << 30) / ((uint64_t)shape->num_channels * shape->num_samples_per_block * sizeof(int32_t)) + 1;
     uint64_t n, ngroups;
     if (e) { long v = atol(e); if (v < 1) v = 1; if (v > 4096) v = 4096; return (uint32_t)v; }
@@ -366,6 +366,7 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
             lnn_parallel_for(cnt, threads, fill_frames, &fj);
             t_fill += now_s() - t0; t0 = now_s();
             ret = LINNEAmd_SlotEncodeSubmit(sl, fj.nsm, cnt);
+            if (trace_on() > 1) fprintf(stderr, "liblinne_amd:   group %u submitted at %.1f ms (the call took %.1f ms)\n", submitted, (now_s() - t_begin) * 1e3, (now_s() - t0) * 1e3);
             t_submit += now_s() - t0;
             if (ret != LNN_OK) { report(gp->ctx[submitted % ndev], "SlotEncodeSubmit", ret); goto done; }
             submitted++;

@@ -93,6 +93,15 @@ extern "C" int lnn_preset_info(uint32_t preset, uint32_t *num_layers, uint32_t *
     return 0;
 }
 
+/* A HIP stream is multiplexed onto one of a few hardware queues -- four per process by default -- and streams that share a
+ * queue execute in submission order whatever their events allow.  A context pipelines over four streams (analysis, block-type
+ * statistics, copy-in, copy-out) next to whatever the host application uses (torch has its own); when copy-in and copy-out
+ * shared a queue, the H2D of group g + 1 sat behind the Rice emission of group g, which waits for the analysis of g: the
+ * staging pipeline ran serially (measured: 28 ms per group instead of 23).  The runtime reads GPU_MAX_HW_QUEUES when it
+ * initialises, i.e. at the first HIP call of the process; loading this library comes before that.  A value the user set is
+ * left alone. */
+__attribute__((constructor)) static void lnn_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+
 extern "C" int LINNEAmd_GetDeviceCount(void)
 {
     int n = 0;
@@ -123,13 +132,17 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
         int ns = env ? atoi(env) : 1;
         if (ns < 1) ns = 1;
         if (ns > LNN_MAXSUB) ns = LNN_MAXSUB;
+        /* One stream of a process maps onto one of a few hardware queues (four by default); streams that share a queue run in
+         * order whatever their events say.  A context therefore creates as few streams as it needs: with one compute stream
+         * (the default) the analysis runs on the context's own stream, and sub-streams exist only for LINNE_AMD_STREAMS >= 2. */
         ctx->nsub = 0;
-        for (int i = 0; i < ns; i++) {
+        for (int i = 0; i < ns && ns >= 2; i++) {
             if (hipStreamCreateWithFlags(&ctx->sub[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming) != hipSuccess) break;
             ctx->nsub++;
         }
-        if (hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) != hipSuccess) ctx->nsub = 0;
-        ctx->has_side = (ctx->nsub > 0) && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess
+        const bool have_start = hipEventCreateWithFlags(&ctx->ev_start, hipEventDisableTiming) == hipSuccess;
+        if (!have_start) ctx->nsub = 0;
+        ctx->has_side = have_start && hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->side_done, hipEventDisableTiming) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming) == hipSuccess;
@@ -154,7 +167,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_cls) hipFree(ctx->d_cls);
     if (ctx->d_ucount) hipFree(ctx->d_ucount);
     for (int i = 0; i < ctx->nsub; i++) { hipStreamSynchronize(ctx->sub[i]); hipStreamDestroy(ctx->sub[i]); hipEventDestroy(ctx->sub_done[i]); }
-    if (ctx->nsub) hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_start) hipEventDestroy(ctx->ev_start);
     if (ctx->has_side) { hipStreamSynchronize(ctx->side); hipStreamDestroy(ctx->side); hipEventDestroy(ctx->side_done); hipEventDestroy(ctx->fork_ev); hipEventDestroy(ctx->join_ev); }
     if (ctx->d_sin) hipFree(ctx->d_sin);
     if (ctx->d_wt) hipFree(ctx->d_wt);
@@ -594,10 +607,8 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount + 2, 0x7F, 2 * sizeof(uint32_t), ctx->stream));      /* min margin: a huge double (0x7F7F...) */
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     const bool use_sub = ctx->nsub > 0;
-    if (use_sub) {
-        HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
-        for (uint32_t i = 0; i < nsub; i++) HIPCHK(ctx, hipStreamWaitEvent(ctx->sub[i], ctx->ev_start, 0));
-    }
+    if (use_sub || ctx->has_side) HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    if (use_sub) for (uint32_t i = 0; i < nsub; i++) HIPCHK(ctx, hipStreamWaitEvent(ctx->sub[i], ctx->ev_start, 0));
     {   /* statistics of every frame of the call: one launch beside the analysis */
         Plan ps; memset(&ps, 0, sizeof(ps));
         ps.C = C; ps.S = S; ps.bits = shape->bits_per_sample; ps.L = hs.L; ps.R = hs.R; ps.F = num_frames;
@@ -605,7 +616,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         ps.scale = ldexp(1.0, -(int)(shape->bits_per_sample - 1));
         ps.pcm = d_pcm; ps.pcm16 = pcm16; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.frame_map = ctx->d_map; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
         hipStream_t ss = ctx->stream;
-        if (ctx->has_side && use_sub) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
+        if (ctx->has_side) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
         const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps); span_end(ctx, sp_, ss);
         if (ss != ctx->stream) HIPCHK(ctx, hipEventRecord(ctx->side_done, ss));
     }
@@ -668,7 +679,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 const bool hist_layer = p.hist && hs.P[l] >= 64u;
                 /* the general kernels serve what the lanes = jobs kernels do not take -- usually one ragged frame, a launch that is
                  * all latency: it runs beside them on the side stream */
-                const bool beside = hist_layer && !hist_all[l] && ctx->has_side && use_sub;
+                const bool beside = hist_layer && !hist_all[l] && ctx->has_side;
                 if (beside) {
                     HIPCHK(ctx, hipEventRecord(ctx->fork_ev, st)); HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_ev, 0));
                     const int sp_ = span_begin(ctx, 3, ctx->side); dispatch_autocorr2(ctx->side, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, ctx->side);
@@ -723,7 +734,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         { const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st); }
         HIPCHK(ctx, hipGetLastError());
     }
-    if (ctx->has_side && use_sub) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
+    if (ctx->has_side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     if (use_sub) {
         for (uint32_t i = 0; i < nsub; i++) { HIPCHK(ctx, hipEventRecord(ctx->sub_done[i], ctx->sub[i])); HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->sub_done[i], 0)); }
     }
@@ -919,7 +930,8 @@ extern "C" int LINNEAmd_RiceEmitDevice(struct LINNEAmdContext *ctx, const struct
     { const char *e_ = getenv("LINNE_AMD_RICE_EMIT_CAP"); if (e_) a.cap_bytes = (uint32_t)atol(e_); }      /* test knob: forces the host fallback */
     { const int sp_ = span_begin(ctx, 24, ctx->stream);
       hipLaunchKernelGGL(k_rice_scan, dim3(1), dim3(RSCAN_THREADS), 0, ctx->stream, a);
-      hipLaunchKernelGGL(k_rice_emit, dim3((uint32_t)CF), dim3(REMIT_THREADS), 0, ctx->stream, a);
+      if (a.S <= REMIT_LDS_SAMPLES) hipLaunchKernelGGL(k_rice_emit<true>, dim3((uint32_t)CF), dim3(REMIT_THREADS), sizeof(uint32_t) * (a.S + REMIT_THREADS + 1u), ctx->stream, a);
+      else hipLaunchKernelGGL(k_rice_emit<false>, dim3((uint32_t)CF), dim3(REMIT_THREADS), 0, ctx->stream, a);
       span_end(ctx, sp_, ctx->stream); }
     HIPCHK(ctx, hipGetLastError());
     return LNN_OK;
@@ -1074,12 +1086,21 @@ extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t 
     HIPCHK(ctx, hipMemsetAsync(s->d_st, 0, sb, ctx->stream));
     ctx->pcm16_next = pcm16 ? 1 : 0;
     if ((ret = LINNEAmd_EncodeFramesDevice(ctx, &s->shape, s->d_pcm, num_samples, num_frames, s->d_data, s->d_prm, s->d_st)) != LNN_OK) return ret;
-    if ((ret = LINNEAmd_RicePlanDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_plan)) != LNN_OK) return ret;
-    if (emit && (ret = LINNEAmd_RiceEmitDevice(ctx, &s->shape, s->d_data, num_frames, s->d_plan, s->d_offsets, s->d_packed, s->packed_cap)) != LNN_OK) return ret;
+    /* The Rice planning and emission are light integer kernels behind the analysis: they run on the copy-out stream, where
+     * they overlap the next group's (FP64-bound) analysis instead of delaying it; the slots of a context share that stream,
+     * so their use of the context's plan metadata stays ordered. */
     HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
+    {
+        hipStream_t keep = ctx->stream;
+        ctx->stream = ctx->copy_out;
+        ret = LINNEAmd_RicePlanDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_plan);
+        if (ret == LNN_OK && emit) ret = LINNEAmd_RiceEmitDevice(ctx, &s->shape, s->d_data, num_frames, s->d_plan, s->d_offsets, s->d_packed, s->packed_cap);
+        ctx->stream = keep;
+        if (ret != LNN_OK) return ret;
+    }
     if (emit) {         /* the code's used bytes (a size only the device knows so far) by a copy kernel, then the offsets */
-        hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, ctx->copy_out, (const uint4 *)s->d_packed, (uint4 *)s->h_packed, (const uint32_t *)(s->d_offsets + (size_t)C * num_frames));
+        hipLaunchKernelGGL(k_copy_out, dim3(96), dim3(256), 0, ctx->copy_out, (const uint4 *)s->d_packed, (uint4 *)s->h_packed, (const uint32_t *)(s->d_offsets + (size_t)C * num_frames));
         HIPCHK(ctx, hipMemcpyAsync(s->h_offsets, s->d_offsets, sizeof(uint32_t) * (C * num_frames + 1), hipMemcpyDeviceToHost, ctx->copy_out));
     } else
     HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));

@@ -172,8 +172,14 @@ struct RiceBW {
 };
 
 #define REMIT_THREADS 256
-__global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit(RiceEmitArgs a)
+#define REMIT_LDS_SAMPLES 12288u            /* frames up to this length are staged in LDS (48 KB + padding) */
+/* A thread codes `ipt` consecutive samples.  Read straight from global memory that is a 4 * ipt byte stride between lanes --
+ * every load instruction touches 64 cache lines -- so the block first brings the channel-frame into LDS with coalesced loads
+ * (zig-zagged on the way) and the two passes read it from there; run r starts at r * (ipt + 1) so that the lanes' strided reads
+ * fall on different banks. */
+template <bool LDS> __global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit(RiceEmitArgs a)
 {
+    extern __shared__ uint32_t zbuf[];
     __shared__ uint8_t kk[1024];
     __shared__ uint64_t wsum[REMIT_THREADS / 64];
     const uint32_t cf = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -185,19 +191,21 @@ __global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit(RiceEmitArgs a)
     const int32_t *x = a.resid + (size_t)cf * a.S;
     uint32_t *dst = (uint32_t *)(a.packed + off);
     const uint32_t nwords = (uint32_t)((((uint64_t)nbits + 63u) >> 6) << 1);
+    const uint32_t ipt = (n + REMIT_THREADS - 1) / REMIT_THREADS;
     for (uint32_t i = tid; i < nwords; i += REMIT_THREADS) dst[i] = 0;
     for (uint32_t p = tid; p < parts; p += REMIT_THREADS) kk[p] = rec[LINNE_AMD_RICE_PLAN_K2 + p];
+    if (LDS) for (uint32_t s = tid; s < n; s += REMIT_THREADS) zbuf[s + s / ipt] = rp_zz(x[s]);
     __syncthreads();
     /* a thread owns ipt consecutive samples; a partition's parameter code sits in front of the partition's first sample */
-    const uint32_t ipt = (n + REMIT_THREADS - 1) / REMIT_THREADS;
     const uint32_t s0 = tid * ipt < n ? tid * ipt : n, s1 = (s0 + ipt < n) ? s0 + ipt : n;
+    const uint32_t *zrun = zbuf + (size_t)tid * (ipt + 1u);
     uint64_t mybits = 0;
     {
         uint32_t part = ns ? s0 / ns : 0, loc = ns ? s0 - part * ns : 0;
         for (uint32_t s = s0; s < s1; s++) {
             const uint32_t k2 = kk[part], k1 = k2 + 1u, k1pow = 1u << (k1 & 31u);
             if (loc == 0) mybits += part ? rp_gamma_len(rp_zz((int32_t)k2 - (int32_t)kk[part - 1])) : 15u;
-            const uint32_t v = rp_zz(x[s]);
+            const uint32_t v = LDS ? zrun[s - s0] : rp_zz(x[s]);
             mybits += (v < k1pow) ? (k1 + 1u) : (uint64_t)(((v - k1pow) >> k2) + 2u + k2);
             if (++loc == ns) { loc = 0; part++; }
         }
@@ -223,7 +231,7 @@ __global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit(RiceEmitArgs a)
                     else { const uint32_t nd = 32u - (uint32_t)__clz((int)(g + 1u)); bw.zeros(nd - 1u); bw.put(g + 1u, nd); }
                 }
             }
-            const uint32_t v = rp_zz(x[s]);
+            const uint32_t v = LDS ? zrun[s - s0] : rp_zz(x[s]);
             if (v < k1pow) { bw.put(1u, 1u); bw.put((k1 == 32u) ? v : (v & ((1u << (k1 & 31u)) - 1u)), k1); }
             else {
                 const uint32_t d = v - k1pow;
