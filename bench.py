@@ -33,9 +33,10 @@ MAC_PER_CF_EXECUTED = 25.2e6        # multiply-adds (separate or fused) per chan
 HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
 FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
-ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23)
+ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
-                5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward)",
+                5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)",
+                25: "k_search_long<P> (search of the long layer in one window pass + fused one-unit forward)",
                 18: "k_fir_small<P,false,*> (search of the last, short layer)", 15: "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)",
                 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false,true> (forward, jobs with several units)",
                 19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_fwd_loss<P> (last layer: forward pass + ordered loss)", 21: "k_autocorr_hist<P,0> (long layer, one-unit trial)", 22: "k_autocorr_hist<P,1> (long layer, two-unit trial)", 23: "k_autocorr_sub<P> (long layer, trials of order <= 32)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
@@ -506,7 +507,7 @@ def main():
         layers = linne_amd.PRESET_LAYERS[args.preset]
         n_big = sum(1 for P in layers if P >= 32)
         # timed spans of one kind per frame group: per-layer kernels have one span per layer they serve
-        launches_per_chunk = {3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2), 16: 1, 21: n_big, 22: n_big, 23: n_big}.get(dom, 1)
+        launches_per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2), 16: 1, 21: n_big, 22: n_big, 23: n_big}.get(dom, 1)
         chunk_launches = launches / launches_per_chunk
         cf_per_launch = F * nch * args.steps / chunk_launches
         # a per-layer kernel of one layer carries that layer's share; report the whole-kernel view: bytes of the

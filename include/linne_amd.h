@@ -223,7 +223,8 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * the last layer, or LINNE_AMD_SPECULATE=0 -- they are different kernels and report as kinds 18 / 19), 20 the last layer's
  * forward pass fused with its loss (k_fwd_loss; replaces 19 + 9 for the frames it takes), 21 / 22 / 23 the long layer's
  * autocorrelation with lanes = jobs (k_autocorr_hist for the trials of order P and P/2, k_autocorr_sub for the shorter ones;
- * replace 3 for the frames they take). */
+ * replace 3 for the frames they take), 24 Rice scan + emission, 25 the long layer's search in one window pass (k_search_long;
+ * replaces 5 for the frames it takes). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);

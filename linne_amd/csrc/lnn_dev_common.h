@@ -41,6 +41,7 @@ struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;
     uint32_t hist;                      /* the long layer's lags come from k_autocorr_hist / k_autocorr_sub where they take the frame (LINNE_AMD_HIST, default 1) */
     uint32_t rows16;                    /* order-16 layers take the register-ring autocorrelation form (LINNE_AMD_ROWS16, default 1) */
+    uint32_t search_long;               /* the long layer's search comes from k_search_long where it takes the job (LINNE_AMD_SEARCH_LONG, default 1) */
     uint32_t fused_last;                /* the last layer's forward pass and loss come from k_fwd_loss where it takes the job (fwd_loss_takes) */
     RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */
     uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
@@ -62,11 +63,24 @@ struct Plan {
     uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
     uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
     unsigned long long *min_margin;     /* bits of the smallest certified relative gap of the call (k_select)        */
+    uint32_t dbg_maxtr;                 /* TIMING EXPERIMENTS ONLY (LINNE_AMD_DBG_MAXTR): the long layer's search evaluates only the first trials; results are wrong */
     uint32_t force_exact;               /* LINNE_AMD_EXACT: flag every search as uncertain              */
     double *lparams;                    /* [J][MAXL][MAXP]             */
     uint32_t *lunits;                   /* [J][MAXL]                   */
     double *jloss, *jtail;              /* [J]                         */
 };
+
+typedef const double __attribute__((address_space(4))) *lnn_cdp;    /* constant address space: wave-uniform loads become scalar loads */
+#define LNN_FIR_TILE 2048u               /* samples per block of the search / forward kernels (lnn_k_fir.h FIR_TILE) */
+/* does k_search_long (lnn_k_search.h) produce this job's unit-count search of `layer`?  The long layer (64 / 128 taps) of a preset
+ * with a layer behind it, every trial present, the analysis length whole 2048-sample tiles (all full 10240-sample frames);
+ * k_fir2<2> keeps the other frames */
+__device__ __host__ __forceinline__ bool search_long_takes(const Plan &p, uint32_t layer, const DevClass &c)
+{
+    const uint32_t P = p.P[layer];
+    uint32_t nt = 0; for (uint32_t u = 1; u <= P && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
+    return p.search_long && layer > 0 && layer + 1 < p.L && (P == 128u || P == 64u) && c.ntrials[layer] == nt && (c.na % LNN_FIR_TILE) == 0;
+}
 
 /* input sample i of the caller's PCM array */
 __device__ __forceinline__ int32_t pcm_at(const Plan &p, size_t i) { return p.pcm16 ? (int32_t)((const int16_t *)p.pcm)[i] : p.pcm[i]; }

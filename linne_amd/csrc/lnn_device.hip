@@ -32,6 +32,7 @@
 #include "lnn_k_autocorr.h"
 #include "lnn_k_levinson.h"
 #include "lnn_k_fir.h"
+#include "lnn_k_search.h"
 #include "lnn_k_fwdloss.h"
 #include "lnn_k_finalize.h"
 #include "lnn_k_decode.h"
@@ -643,6 +644,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         bool fuse_all = fuse_cfg;
         for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
         p.fused_last = fuse_cfg ? 1u : 0u;
+        { const char *e_ = getenv("LINNE_AMD_SEARCH_LONG"); p.search_long = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
         { const char *e_ = getenv("LINNE_AMD_ROWS16"); p.rows16 = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
         build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         { const char *e_ = getenv("LINNE_AMD_HIST"); p.hist = (e_ ? (atoi(e_) != 0) : (J >= 12288u)) ? 1u : 0u; }
@@ -656,7 +658,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 if (!(c.ntrials[l] == nt && (c.na % (16u << (nt - 1))) == 0 && (c.na >> (nt - 1)) >= 32u)) hist_all[l] = false;
             }
         }
-        p.cls_of_frame = ctx->d_clsidx + f0; p.frame_map = ctx->d_map + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount; p.min_margin = (unsigned long long *)(ctx->d_ucount + 2); p.force_exact = ctx->force_exact ? 1u : 0u;
+        p.cls_of_frame = ctx->d_clsidx + f0; p.frame_map = ctx->d_map + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount; p.min_margin = (unsigned long long *)(ctx->d_ucount + 2); p.force_exact = ctx->force_exact ? 1u : 0u; { const char *e_ = getenv("LINNE_AMD_DBG_MAXTR"); p.dbg_maxtr = e_ ? (uint32_t)atoi(e_) : 0u; }
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
         uint8_t *a = abase;
 #define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
@@ -709,7 +711,23 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(carry ? 64 * (1 + LEV_MAXRIDE) : 64), lds, st, p, l, t, carry ? ride : (uint32_t)LNN_MAXT);
               }
               span_end(ctx, sp_, st); }
-            { const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st); if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]); else launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
+            {   /* unit-count search.  Short layers: the register-window kernel.  The long layer: k_search_long for the frames it takes
+                 * (search_long_takes), k_fir2<2> for the others (it returns at once for the jobs taken there) */
+                bool long_any = false, long_all = true;
+                for (uint32_t f = f0; f < f0 + Fc; f++) { const bool t_ = fir_spec && search_long_takes(p, l, ctx->sig_cls[ctx->cur_idx[f]]); long_any |= t_; long_all &= t_; }
+                if (long_any) {
+                    const int sp_ = span_begin(ctx, 25, st);
+                    const dim3 grid((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), blk(FIR_THREADS);
+                    if (hs.P[l] == 128u) hipLaunchKernelGGL(k_search_long<128>, grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL(k_search_long<64>, grid, blk, 0, st, p, l, cur);
+                    span_end(ctx, sp_, st);
+                }
+                if (!(long_any && long_all)) {
+                    const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st);
+                    if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]);
+                    else launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0);
+                    span_end(ctx, sp_, st);
+                }
+            }
             { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);

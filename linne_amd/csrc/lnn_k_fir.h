@@ -46,6 +46,7 @@ __device__ __forceinline__ double wave_max_f64_lane63(double v)     /* max of no
 #define FIR_THREADS 256
 #define FIR_SPL     8                       /* consecutive samples per lane */
 #define FIR_TILE    (FIR_THREADS * FIR_SPL)
+static_assert(FIR_TILE == LNN_FIR_TILE, "search_long_takes assumes the tile of the FIR kernels");
 template <int MODE, bool L0, bool SPEC>
 __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan p, uint32_t layer, uint32_t cur)
 {
@@ -62,10 +63,12 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
     if (MODE == 1 && fwd_loss_takes(p, layer, na)) return;         /* the last layer of this job is k_fwd_loss's */
+    if (MODE == 2 && !L0 && SPEC && search_long_takes(p, layer, c)) return;     /* this job's search is k_search_long's */
     const uint32_t P = p.P[layer];
     const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;          /* layer 0 reads the pre-emphasised int32 channel (linne_encoder.c:661-663) */
-    const uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
+    uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
+    if (MODE == 2 && p.dbg_maxtr && ntr > p.dbg_maxtr) ntr = p.dbg_maxtr;
     if (MODE == 0 && tid < LNN_MAXT) chain[tid] = 0.0;
     {
         const double *hsrc = (MODE != 1) ? (p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);
@@ -123,7 +126,8 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
     auto trial_body = [&](auto dual_tag, const uint32_t t) {
         constexpr bool dual = decltype(dual_tag)::value;
         const uint32_t u = (MODE != 1) ? c.trial_u[layer][t] : p.lunits[(size_t)job * LNN_MAXL + layer];
-        const uint32_t n = na / u, np = P / u;
+        const uint32_t lgu = 31u - (uint32_t)__builtin_clz(u | 1u);   /* unit counts are powers of two (linne_network.c:289): shifts, not divisions */
+        const uint32_t n = na >> lgu, np = P >> lgu;
         const double *hbuf = hs[t];
         if (t == 0) __syncthreads();                                 /* tile and coefficients are staged */
         double acc[FIR_SPL];
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
             /* all FIR_SPL samples in one unit, every tap present */
             const bool whole = ((n & (FIR_SPL - 1)) == 0) && (s >= np) && (s + FIR_SPL - 1 < na);
             if (whole && (np & 3u) == 0) {
-                const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - (uint32_t)(__ffs((int)u) - 1))) : (s / n);
+                const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - lgu)) : (s / n);
                 const double *hb = hbuf + (size_t)my_unit * np;
                 const double *xw = xc - np;                              /* -> x[s - np] */
                 /* Window x[s-np+k .. +11] in a register ring of 16 (element e lives in w[e % 16]): a step of 4 taps reads
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
                 }
 #undef FIR_STEP
             } else if (whole && np <= 2) {
-                const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - (uint32_t)(__ffs((int)u) - 1))) : (s / n);
+                const uint32_t my_unit = fine_ok ? (fine_unit >> (7u - lgu)) : (s / n);
                 const double *hb = hbuf + (size_t)my_unit * np;
                 const double h0 = hb[0];
                 if (np == 1) {

@@ -24,7 +24,7 @@ for r in range(a.reps):
     res, prm, st = ctx.encode_frames(shape, frames, nsm)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"rep {r}: encode {a.frames} frames {dt*1e3:.2f} ms -> {a.frames/dt:.0f} frames/s;", {KERNEL_KINDS[k]: round(ctx.last_ms(k), 3) for k in list(range(1, 11)) + [13, 14, 15, 16, 18, 19, 20, 21, 22, 23] if ctx.last_ms(k) > 0})
+    print(f"rep {r}: encode {a.frames} frames {dt*1e3:.2f} ms -> {a.frames/dt:.0f} frames/s;", {KERNEL_KINDS[k]: round(ctx.last_ms(k), 3) for k in list(range(1, 11)) + [13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25] if ctx.last_ms(k) > 0})
 if a.decode:
     for r in range(a.reps):
         w = res.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
