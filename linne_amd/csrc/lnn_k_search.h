@@ -13,8 +13,8 @@
  *   - ONE pass over the 128-tap window feeds the three big trials.  Trial u (order P/u) looks back P/u samples: its window is
  *     the tail of the one-unit trial's.  While the one-unit chain walks taps 0 .. P-1, the two-unit trial joins at tap P/2 and
  *     the four-unit trial at tap 3P/4, on the same window registers: the window is read from LDS once, not once per trial.
- *   - their coefficients come through the scalar unit (a wave's 512 samples lie inside one unit for u <= 4 when the analysis
- *     length is a multiple of 2048): no LDS reads and no vector registers for them.
+ *   - a wave's 512 samples lie inside one unit for u <= 4 (the analysis length is a multiple of 2048), so the big trials'
+ *     coefficients are wave-uniform: broadcast LDS reads, free of bank conflicts.
  *   - the tile image in LDS is padded (2 doubles behind every 8 samples): lane l's window is 80 bytes from lane l-1's, window
  *     reads are conflict-free, and with 8 taps per unrolled pair of steps every offset is a compile-time constant.
  *   - the five small trials (16, 8, 4, 2, 1 taps) run from ONE 24-sample register window.
@@ -35,6 +35,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
     constexpr int HS = 16 + 8 + 4 + 2 + 1;                 /* taps of the small trials */
     __shared__ __attribute__((aligned(16))) double xs[SL_XPAD(P + FIR_TILE + 8) + 2];
     __shared__ __attribute__((aligned(16))) double hsm[5][LNN_MAXP];          /* coefficients of the five small trials (16 .. 1 taps), all units */
+    __shared__ __attribute__((aligned(16))) double hbg[3][LNN_MAXP + 8];      /* coefficients of the big trials, all units (+8: the loop reads one step ahead) */
     const uint32_t job = blockIdx.x, tid = threadIdx.x, s0 = blockIdx.y * FIR_TILE;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
         }
     }
     for (uint32_t i = tid; i < 5u * P; i += FIR_THREADS) { const uint32_t tt = i / P, k = i % P; hsm[tt][k] = hglob[(size_t)(NBIG + tt) * LNN_MAXP + k]; }
+    for (uint32_t i = tid; i < (uint32_t)NBIG * P; i += FIR_THREADS) { const uint32_t tt = i / P, k = i % P; hbg[tt][k] = hglob[(size_t)tt * LNN_MAXP + k]; }
     if (blockIdx.y == 0 && tid < (uint32_t)NT) {            /* per trial: the largest L1 norm of a unit's coefficients (search_slack) */
         const uint32_t u = 1u << tid, np = P >> tid;
         double mx = 0.0;
@@ -68,13 +70,10 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
     const double *xc = xs + SL_XPAD(P + FIR_SPL * tid);      /* -> x[s]; x[s + j] = xc[j], 0 <= j < 8 */
     const size_t part = blockIdx.y * (FIR_THREADS / 64) + wave;
     const bool last_lane = (tid & 63u) == 63u;
-    double xo[FIR_SPL];
-#pragma unroll
-    for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); xo[j] = v.x; xo[j + 1] = v.y; }
     {   /* max |x| of the wave's samples (search_slack) */
         double mx = 0.0;
 #pragma unroll
-        for (int j = 0; j < FIR_SPL; j++) mx = fmax(mx, fabs(xo[j]));
+        for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); mx = fmax(mx, fmax(fabs(v.x), fabs(v.y))); }
         mx = wave_max_f64_lane63(mx);
         if (last_lane) p.txmax[(size_t)job * p.npart + part] = mx;
     }
@@ -82,46 +81,76 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
     /* ---------------- the big trials: one pass over the window ---------------- */
     {
         const uint32_t ws = s0 + wave * 64u * FIR_SPL;                           /* first sample of the wave: wave-uniform */
-        const lnn_cdp c0 = (lnn_cdp)(uintptr_t)(hglob);                          /* u = 1 */
-        const lnn_cdp c1 = (lnn_cdp)(uintptr_t)(hglob + LNN_MAXP + (size_t)(ws / (na >> 1)) * (P / 2));     /* u = 2: the wave's unit */
-        const lnn_cdp c2 = (lnn_cdp)(uintptr_t)(hglob + 2 * LNN_MAXP + (size_t)(ws / (na >> 2)) * (P / 4));  /* u = 4 (P = 128 only) */
+        /* The coefficients come from LDS by broadcast reads (every lane of the wave reads the same address: its unit's
+         * coefficients).  Scalar loads from global memory were tried first: the co-resident blocks' coefficient sets (3 KB
+         * each) do not fit the scalar cache, every 64-byte line was a miss, and the waves sat on s_waitcnt 60 % of the time. */
+        const double *c0 = hbg[0];                                                                  /* u = 1 */
+        const double *c1 = hbg[1] + (size_t)(ws / (na >> 1)) * (P / 2);                             /* u = 2: the wave's unit */
+        const double *c2 = hbg[2] + (size_t)(ws / (na >> 2)) * (P / 4);                             /* u = 4 (P = 128 only) */
         double a0[FIR_SPL], a1[FIR_SPL], a2[FIR_SPL];
 #pragma unroll
-        for (int j = 0; j < FIR_SPL; j++) { a0[j] = 0.0; a1[j] = xo[j]; a2[j] = xo[j]; }
+        for (int j = 0; j < FIR_SPL; j++) a0[j] = 0.0;
         const double *xw = xc - (P >> 3) * 10;                                   /* -> x[s - P] in the padded image */
         double w[16];
 #pragma unroll
         for (int j = 0; j < 12; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + SL_XPAD(j)); w[j] = v.x; w[j + 1] = v.y; }
-        /* step G (of four, ring position): taps q .. q+3 of the one-unit trial; the new samples q+12 .. q+15 sit at padded
-         * xw + 14 (G even) or xw + 20 (G odd), and xw moves on one group after every odd step */
-#define SL_LOAD(G) { \
+        /* Step G (of four: the ring position) handles taps q .. q+3 of the one-unit trial.  The new samples q+12 .. q+15 sit at
+         * padded xw + 14 (G even) or xw + 20 (G odd); xw moves on one group after every odd step.  Software pipeline: the samples
+         * and the one-unit trial's coefficients of the NEXT step are requested before this step's multiply-adds issue (HN); the
+         * joining trials' coefficients of this step are requested first thing and used behind the one-unit trial's 64
+         * instructions. */
+#define SL_LOAD(G, Q, HN0, HN1) \
             const lnn_d2 na_ = *(const lnn_d2 *)(xw + ((G & 1) ? 20 : 14)), nb_ = *(const lnn_d2 *)(xw + ((G & 1) ? 22 : 16)); \
             if (G & 1) xw += 10; \
-            w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y; }
-#define SL_T0(G, Q) { _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { const double h_ = c0[(Q) + kk]; \
-            _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) a0[j] = a0[j] + h_ * w[(4 * G + kk + j) % 16]; } }
-#define SL_TF(G, ACC, CP, K) { _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { const double h_ = CP[(K) + kk]; \
-            _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) ACC[j] = __builtin_fma(h_, w[(4 * G + kk + j) % 16], ACC[j]); } }
+            HN0 = *(const lnn_d2 *)(c0 + (Q) + 4); HN1 = *(const lnn_d2 *)(c0 + (Q) + 6);
+#define SL_RING(G) \
+            w[(4 * G + 12) % 16] = na_.x; w[(4 * G + 13) % 16] = na_.y; w[(4 * G + 14) % 16] = nb_.x; w[(4 * G + 15) % 16] = nb_.y;
+#define SL_T0(G, HC0, HC1) { const double hh_[4] = { HC0.x, HC0.y, HC1.x, HC1.y }; \
+            _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
+            _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) a0[j] = a0[j] + hh_[kk] * w[(4 * G + kk + j) % 16]; } }
+#define SL_TF(G, ACC, H0, H1) { const double hh_[4] = { H0.x, H0.y, H1.x, H1.y }; \
+            _Pragma("unroll") for (int kk = 0; kk < 4; kk++) { \
+            _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) ACC[j] = __builtin_fma(hh_[kk], w[(4 * G + kk + j) % 16], ACC[j]); } }
+#define SL_STEP1(G, Q, HC0, HC1, HN0, HN1) { SL_LOAD(G, Q, HN0, HN1) SL_T0(G, HC0, HC1) SL_RING(G) }
+#define SL_STEP2(G, Q, K1, HC0, HC1, HN0, HN1) { \
+            const lnn_d2 p0_ = *(const lnn_d2 *)(c1 + (K1)), p1_ = *(const lnn_d2 *)(c1 + (K1) + 2); \
+            SL_LOAD(G, Q, HN0, HN1) SL_T0(G, HC0, HC1) SL_TF(G, a1, p0_, p1_) SL_RING(G) }
+#define SL_STEP3(G, Q, K1, K2, HC0, HC1, HN0, HN1) { \
+            const lnn_d2 p0_ = *(const lnn_d2 *)(c1 + (K1)), p1_ = *(const lnn_d2 *)(c1 + (K1) + 2); \
+            const lnn_d2 r0_ = *(const lnn_d2 *)(c2 + (K2)), r1_ = *(const lnn_d2 *)(c2 + (K2) + 2); \
+            SL_LOAD(G, Q, HN0, HN1) SL_T0(G, HC0, HC1) SL_TF(G, a1, p0_, p1_) SL_TF(G, a2, r0_, r1_) SL_RING(G) }
+        lnn_d2 ha0 = *(const lnn_d2 *)(c0), ha1 = *(const lnn_d2 *)(c0 + 2), hb0, hb1;
         uint32_t q = 0;
         for (; q < (uint32_t)(P / 2); q += 16) {             /* the one-unit trial alone */
-            SL_LOAD(0) SL_T0(0, q)      SL_LOAD(1) SL_T0(1, q + 4)
-            SL_LOAD(2) SL_T0(2, q + 8)  SL_LOAD(3) SL_T0(3, q + 12)
+            SL_STEP1(0, q, ha0, ha1, hb0, hb1)      SL_STEP1(1, q + 4, hb0, hb1, ha0, ha1)
+            SL_STEP1(2, q + 8, ha0, ha1, hb0, hb1)  SL_STEP1(3, q + 12, hb0, hb1, ha0, ha1)
         }
+#pragma unroll
+        for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); a1[j] = v.x; a1[j + 1] = v.y; }
         for (; q < (uint32_t)(NBIG == 3 ? 3 * P / 4 : P); q += 16) {             /* the two-unit trial joins */
             const uint32_t k1 = q - P / 2;
-            SL_LOAD(0) SL_T0(0, q)      SL_TF(0, a1, c1, k1)      SL_LOAD(1) SL_T0(1, q + 4)  SL_TF(1, a1, c1, k1 + 4)
-            SL_LOAD(2) SL_T0(2, q + 8)  SL_TF(2, a1, c1, k1 + 8)  SL_LOAD(3) SL_T0(3, q + 12) SL_TF(3, a1, c1, k1 + 12)
+            SL_STEP2(0, q, k1, ha0, ha1, hb0, hb1)          SL_STEP2(1, q + 4, k1 + 4, hb0, hb1, ha0, ha1)
+            SL_STEP2(2, q + 8, k1 + 8, ha0, ha1, hb0, hb1)  SL_STEP2(3, q + 12, k1 + 12, hb0, hb1, ha0, ha1)
         }
-        if (NBIG == 3) for (; q < (uint32_t)P; q += 16) {     /* the four-unit trial joins */
-            const uint32_t k1 = q - P / 2, k2 = q - 3 * P / 4;
-            SL_LOAD(0) SL_T0(0, q)      SL_TF(0, a1, c1, k1)      SL_TF(0, a2, c2, k2)
-            SL_LOAD(1) SL_T0(1, q + 4)  SL_TF(1, a1, c1, k1 + 4)  SL_TF(1, a2, c2, k2 + 4)
-            SL_LOAD(2) SL_T0(2, q + 8)  SL_TF(2, a1, c1, k1 + 8)  SL_TF(2, a2, c2, k2 + 8)
-            SL_LOAD(3) SL_T0(3, q + 12) SL_TF(3, a1, c1, k1 + 12) SL_TF(3, a2, c2, k2 + 12)
+        if (NBIG == 3) {
+#pragma unroll
+            for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); a2[j] = v.x; a2[j + 1] = v.y; }
+            for (; q < (uint32_t)P; q += 16) {                /* the four-unit trial joins */
+                const uint32_t k1 = q - P / 2, k2 = q - 3 * P / 4;
+                SL_STEP3(0, q, k1, k2, ha0, ha1, hb0, hb1)              SL_STEP3(1, q + 4, k1 + 4, k2 + 4, hb0, hb1, ha0, ha1)
+                SL_STEP3(2, q + 8, k1 + 8, k2 + 8, ha0, ha1, hb0, hb1)  SL_STEP3(3, q + 12, k1 + 12, k2 + 12, hb0, hb1, ha0, ha1)
+            }
         }
 #undef SL_LOAD
+#undef SL_RING
 #undef SL_T0
 #undef SL_TF
+#undef SL_STEP1
+#undef SL_STEP2
+#undef SL_STEP3
+        double xo[FIR_SPL];
+#pragma unroll
+        for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); xo[j] = v.x; xo[j + 1] = v.y; }
         /* the one-unit trial's forward output (linne_network.c:165-210) straight from the registers, and its search term */
         double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
         double ps0 = 0.0, ps1 = 0.0, ps2 = 0.0;
@@ -144,7 +173,9 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
 
     /* ---------------- the small trials (16, 8, 4, 2, 1 taps) from one register window ---------------- */
     {
-        double wv[24];                                       /* x[s - 16 .. s + 7] */
+        double wv[24], xo[FIR_SPL];                          /* x[s - 16 .. s + 7] */
+#pragma unroll
+        for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); xo[j] = v.x; xo[j + 1] = v.y; }
 #pragma unroll
         for (int j = 0; j < 8; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc - 20 + j); wv[j] = v.x; wv[j + 1] = v.y; }
 #pragma unroll
