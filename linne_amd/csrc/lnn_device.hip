@@ -355,7 +355,6 @@ static int make_class(LINNEAmdContext *ctx, const HostShape *hs, uint32_t S, uin
     if (na > S) na = S;
     c.na = na;
     c.sin_off = (uint32_t)*sin_total; *sin_total += n;
-    if (na & 1u) { snprintf(ctx->err, sizeof(ctx->err), "odd analysis length %u (odd num_samples_per_block) is not supported by the device path", na); return LNN_INVALID_FORMAT; }
     for (uint32_t l = 0; l < hs->L; l++) {
         const uint32_t maxu = hs->P[l] < 128u ? hs->P[l] : 128u;    /* linne_network.c:586,594 */
         uint32_t nt = 0;

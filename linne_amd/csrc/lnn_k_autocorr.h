@@ -7,6 +7,17 @@
  * analysis, one layer at a time over every job = (channel-frame, regulariser pass)
  * ---------------------------------------------------------------------------------------------- */
 __device__ __forceinline__ const DevClass &job_class(const Plan &p, uint32_t job) { return p.cls[p.cls_of_frame[(job / p.R) / p.C]]; }
+/* Quirk Q1 for an ODD analysis length (an odd num_samples_per_block): only the one-unit trial exists then, its Welch window never
+ * writes the middle sample (lpc.c:200-204), no other Welch call of the frame does either, and what the window buffer holds there
+ * is what the block-type estimate left (linne_encoder.c:494-503 -> lpc.c:188-195): the LAST channel's raw sample at that index
+ * under the SIN window -- a function of the frame alone */
+__device__ __forceinline__ double q1_stale_first_trial(const Plan &p, uint32_t job, const DevClass &c)
+{
+    const uint32_t f = (job / p.R) / p.C, mid = c.na >> 1;
+    if (mid >= c.n) return 0.0;
+    const size_t i = ((size_t)p.frame_map[f] * p.C + (p.C - 1u)) * p.S + mid;
+    return ((double)pcm_at(p, i) * p.scale) * p.sintab[c.sin_off + mid];
+}
 
 /* ------------------------------------------------------------------------------------------------
  * K_A (v2): Welch window + autocorrelation of every unit-count trial of one layer, fused.
@@ -99,7 +110,8 @@ __global__ __launch_bounds__(64) void k_autocorr2(Plan p, uint32_t layer, uint32
                     if (L0) g_xi = p.xint + (size_t)(job / p.R) * p.S; else g_xd = p.sig + ((size_t)job * 2 + cur) * p.S;
                     g_q = sub; g_loc = sub; g_pos = (int32_t)sub;
                     while (g_loc >= g_upl) { g_loc -= g_upl; g_unit++; g_ubase += g_n; }
-                    if (g_n & 1u) {     /* Q1: stale middle sample = previous trial's last unit at local index m */
+                    if ((g_n & 1u) && g_u == 1u) g_stale = q1_stale_first_trial(p, job, c);
+                    else if (g_n & 1u) {     /* Q1: stale middle sample = previous trial's last unit at local index m */
                         const uint32_t m = g_n >> 1, n2 = 2 * g_n, si = (g_u / 2 - 1) * n2 + m;
                         const double xv = L0 ? ((double)g_xi[si] * p.scale) : g_xd[si];
                         const double wgt = c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m);
@@ -304,7 +316,8 @@ __device__ __forceinline__ void autocorr_lane(const Plan &p, uint32_t layer, uin
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
     const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
     double stale = 0.0;
-    if (active && (n & 1u)) {                       /* Q1, as in k_autocorr2 */
+    if (active && (n & 1u) && u == 1u) stale = q1_stale_first_trial(p, job, c);
+    else if (active && (n & 1u)) {                  /* Q1, as in k_autocorr2 */
         const uint32_t m = n >> 1, n2 = 2 * n, si = (u / 2 - 1) * n2 + m;
         const double xv = L0 ? ((double)xi[si] * p.scale) : xd[si];
         stale = xv * (c.trial_div[layer][t - 1] * (double)m * (double)(n2 - 1 - m));

@@ -312,7 +312,7 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LINNE_FUZZ_SEEDS", "16"))))
 def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, seed):
-    """randomised sweep over what the API accepts: channels, bit depth, preset, (even) block size, MS on/off, stream length
+    """randomised sweep over what the API accepts: channels, bit depth, preset, block size (even or odd), MS on/off, stream length
     with a ragged tail, and material that mixes music, silence, noise and a constant; the .lnn must equal the oracle's
     byte for byte and decode back to the input.  Odd seeds force the large-batch kernel forms (picked by batch size
     otherwise, and these streams are short) so that the sweep covers both."""
@@ -324,7 +324,7 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     bits = int(rng.choice([8, 16, 24]))
     preset = int(rng.integers(0, 8))
     maxp = 32 if preset < 2 else (64 if preset < 5 else 128)
-    block = int(rng.choice([2 * int(rng.integers(max(maxp, 128) // 2 + 1, 1500)), 1024, 2048, 4096]))     # the handle is created for 128-tap layers
+    block = int(rng.choice([2 * int(rng.integers(max(maxp, 128) // 2 + 1, 1500)), 2 * int(rng.integers(max(maxp, 128) // 2 + 1, 1500)) + 1, 1024, 2048, 4096]))     # even and odd; the handle is created for 128-tap layers
     ms = bool(nch >= 2 and rng.integers(0, 2))
     nblocks = int(rng.integers(2, 6))
     total = nblocks * block + int(rng.integers(1, block))
@@ -585,3 +585,21 @@ def test_whole_stream_with_and_without_device_emission(product, oracle, referenc
     assert mine == reference.encode_whole(x, 16, 44100, block, 7, True)
     x24 = music(3, 5 * 2048 + 99, 24, seed=43)
     assert product.encode_whole(x24, 24, 96000, 2048, 5, True) == oracle.encode_whole(x24, 24, 96000, 2048, 5, True)
+
+
+@pytest.mark.parametrize("nch,bits,block,preset,total", [(2, 16, 1023, 7, 5 * 1023 + 400), (1, 16, 2047, 4, 3 * 2047 + 1000), (2, 24, 1025, 5, 4 * 1025 + 1021),
+                                                         (2, 16, 4095, 7, 2 * 4095 + 4090), (2, 16, 1023, 0, 4000), (8, 16, 1021, 7, 3500), (2, 16, 10239, 7, 3 * 10239 + 5000)])
+def test_odd_block_sizes(product, oracle, reference, nch, bits, block, preset, total):
+    """an odd num_samples_per_block (linne_encoder.c:410-477 accepts any): the analysis length of a full block is odd, every layer
+    has the one-unit trial only, and the Welch window's unwritten middle sample (quirk Q1, lpc.c:200-204) holds what the
+    block-type estimate left there -- the last channel's SIN-windowed sample (linne_encoder.c:494-503).  Bytes must equal the
+    reference's, whole-stream and block by block; tails of such streams have even analysis lengths and odd sub-lengths"""
+    x = music(nch, total, bits, seed=block)
+    ms = nch >= 2
+    want = reference.encode_whole(x, bits, 44100, block, preset, ms)
+    assert oracle.encode_whole(x, bits, 44100, block, preset, ms) == want
+    mine = product.encode_whole(x, bits, 44100, block, preset, ms)
+    assert mine == want
+    assert product.encode_blocks(x, bits, 44100, block, preset, ms) == want
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
