@@ -87,6 +87,12 @@ uint64_t LINNEAmd_ScratchBytesPerFrame(const struct LINNEAmdShape *shape);
  * default (null) stream.  Until this is called the context uses a stream of its own. */
 int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream);
 
+/* `-a N` (struct LINNEEncodeParameter.num_afmethod_iterations; lpc.c:578-633): the number of auxiliary-function iterations that
+ * refine every layer's coefficients in the final pass of LINNENetwork_SetUnitsAndParameters (linne_network.c:605-630).  Applies to
+ * the following EncodeFramesDevice / Host calls of this context; 0 (the default) = off.  With N > 0 a call synchronises the
+ * host: every Cholesky pivot's pow(x, -0.5) is taken from the host's libm, whose bits no device routine can promise. */
+int LINNEAmd_SetAfIterations(struct LINNEAmdContext *ctx, uint32_t iterations);
+
 /* ENCODE hot path, device resident.  Replaces, for every frame of the batch, the numeric core of
  * LINNEEncoder_EncodeCompressData (linne_encoder.c:613-696) and the analysis half of
  * LINNEEncoder_DecideBlockDataType (linne_encoder.c:494-503):

@@ -68,7 +68,7 @@ class LinneApi:
 
     Header, EncodeParameter, EncoderConfig, DecoderConfig = _RefHeader, _RefEncodeParameter, _RefEncoderConfig, _RefDecoderConfig
 
-    def new_encoder(self, nch, bits, rate, block, preset, ms, max_block=None):
+    def new_encoder(self, nch, bits, rate, block, preset, ms, max_block=None, af_iters=0, learning=0):
         cfg = _RefEncoderConfig(max(nch, 1), max_block or block, 5, 128)
         # The reference mallocs its work area and never clears the LPC calculator's buffers; what the first
         # block's raw/compress decision reads there (oracle quirk Q2) is heap garbage unless the caller
@@ -81,16 +81,16 @@ class LinneApi:
         assert enc, "LINNEEncoder_Create failed"
         self._work = getattr(self, "_work", {})
         self._work[enc] = work
-        par = _RefEncodeParameter(nch, bits, rate, block, preset, int(ms), 0, 0)
+        par = _RefEncodeParameter(nch, bits, rate, block, preset, int(ms), learning, af_iters)
         ret = self.L.LINNEEncoder_SetEncodeParameter(enc, C.byref(par))
         if ret != 0:
             self.L.LINNEEncoder_Destroy(enc)
             raise RuntimeError(f"SetEncodeParameter -> {ret}")
         return enc
 
-    def encode_whole(self, x, bits, rate, block, preset, ms):
+    def encode_whole(self, x, bits, rate, block, preset, ms, af_iters=0):
         x = np.ascontiguousarray(x, dtype=np.int32)
-        enc = self.new_encoder(x.shape[0], bits, rate, block, preset, ms)
+        enc = self.new_encoder(x.shape[0], bits, rate, block, preset, ms, af_iters=af_iters)
         ptrs, keep = _planar_ptrs(x)
         cap = x.size * 4 * 2 + 65536
         out = np.zeros(cap, dtype=np.uint8)

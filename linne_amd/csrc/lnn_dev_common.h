@@ -68,6 +68,18 @@ struct Plan {
     double *lparams;                    /* [J][MAXL][MAXP]             */
     uint32_t *lunits;                   /* [J][MAXL]                   */
     double *jloss, *jtail;              /* [J]                         */
+    /* -a N (auxiliary-function refinement, lpc.c:578-633): the FINAL pass of linne_network.c:605-630 runs as a plan of its own with
+     * one job per channel-frame (R = 1) whose regulariser is the winner of the R search passes */
+    const double *job_reg;              /* [J] regulariser of each job (NULL: regs[job % R])                                   */
+    const uint32_t *af_best; const double *af_loss;   /* [J] winner of the search passes and its loss, for the stats record (NULL: from jloss) */
+    double *af_a;                       /* [J][MAXP]   coefficients in LPC order, units back to back                           */
+    double *af_inv;                     /* [J][S]      1 / max(|residual|, 1e-6) per sample                                    */
+    double *af_R;                       /* [J][MAXP*MAXP] normal matrices, unit un of order np at un * np * np, row-major      */
+    double *af_rv, *af_invd;            /* [J][MAXP]   right-hand sides / inverse diagonals, units back to back               */
+    double *af_obj, *af_prev;           /* [J][MAXU]   objective of this / the previous iteration per unit                     */
+    uint32_t *af_state;                 /* [J][MAXU]   0 iterating, 1 converged, 2 zero problem, 3 singular                    */
+    uint32_t *af_prob, *af_nprob;       /* compact list of the (job, unit) problems of the layer (job * MAXU + unit), its length */
+    double *af_pivot;                   /* [problems]  pivot sums out / pow(sum, -0.5) in (host libm), per Cholesky step       */
 };
 
 typedef const double __attribute__((address_space(4))) *lnn_cdp;    /* constant address space: wave-uniform loads become scalar loads */

@@ -34,6 +34,7 @@
 #include "lnn_k_fir.h"
 #include "lnn_k_search.h"
 #include "lnn_k_fwdloss.h"
+#include "lnn_k_af.h"
 #include "lnn_k_finalize.h"
 #include "lnn_k_decode.h"
 #include "lnn_k_rice.h"
@@ -71,6 +72,8 @@ struct LINNEAmdContext {
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
     int prod_ok;                        /* set per batch by build_classes, bit l: in layer l every class has all its trials and even unit lengths (k_autocorr_prod) */
     int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
+    uint32_t af_iters;                  /* -a N: auxiliary-function iterations of the final pass (LINNEAmd_SetAfIterations), 0 = off */
+    double *af_h; uint32_t af_h_cap;    /* pinned: a Cholesky step's pivots on their way through the host's pow() */
     int pcm16_next;                     /* the next EncodeFramesDevice call reads int16 samples (set by the staging slots, cleared by the call) */
     int force_exact;                    /* LINNE_AMD_EXACT=1: every unit-count search runs the exact ordered chains (diff against the certified search) */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
@@ -175,6 +178,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
     if (ctx->d_plan_nsmp) hipFree(ctx->d_plan_nsmp);
+    if (ctx->af_h) hipHostFree(ctx->af_h);
     for (int i = 0; i < LNN_META; i++) { if (ctx->meta_h[i]) hipHostFree(ctx->meta_h[i]); if (ctx->meta_ev[i]) hipEventDestroy(ctx->meta_ev[i]); }
     if (ctx->has_copy) { hipStreamSynchronize(ctx->copy_in); hipStreamSynchronize(ctx->copy_out); hipStreamDestroy(ctx->copy_in); hipStreamDestroy(ctx->copy_out); }
     hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
@@ -235,6 +239,12 @@ extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
     return LNN_OK;
 }
 
+extern "C" int LINNEAmd_SetAfIterations(struct LINNEAmdContext *ctx, uint32_t iterations)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->af_iters = iterations;
+    return LNN_OK;
+}
 extern "C" int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable) { if (!ctx) return LNN_INVALID_ARGUMENT; ctx->timing = enable; return LNN_OK; }
 /* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
 static int span_begin(LINNEAmdContext *ctx, int kind, hipStream_t st)
@@ -516,7 +526,7 @@ static void build_runs(RowRuns *rr, const uint32_t *idx, uint32_t F, uint32_t rp
 }
 
 /* bytes of scratch one frame needs (C channel-frames, R passes each) */
-static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const HostShape *hs)
+static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const HostShape *hs, uint32_t af_iters = 0)
 {
     const uint64_t C = shape->num_channels, S = shape->num_samples_per_block, J = C * hs->R;
     uint64_t b = 0;
@@ -531,6 +541,8 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     b += J * LNN_MAXL * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXL * sizeof(uint32_t);
     b += J * 2 * sizeof(double);
+    if (af_iters)       /* the auxiliary-function pass: per channel-frame the normal matrices, reciprocals, vectors, problem lists */
+        b += C * (sizeof(double) * ((uint64_t)hs->maxP * hs->maxP + S + 3 * LNN_MAXP + 3 * LNN_MAXU + 2) + sizeof(uint32_t) * (2 * LNN_MAXU + 1)) + 8192;
     return b + 4096;
 }
 
@@ -578,7 +590,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames)) != LNN_OK) return ret;
 
     const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
-    const uint64_t per_frame = frame_scratch_bytes(shape, &hs);
+    const uint64_t per_frame = frame_scratch_bytes(shape, &hs, ctx->af_iters);
     if (ctx->arena_bytes < per_frame * 4 + 65536) {       /* grow the arena to hold at least a few frames */
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(ctx->arena)); ctx->arena = NULL; ctx->arena_bytes = 0;
@@ -667,34 +679,83 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
         TAKE(p.tloss, double, J * LNN_MAXT); p.npart = ((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64); TAKE(p.tsum, double, J * LNN_MAXT * p.npart); TAKE(p.txmax, double, J * p.npart); TAKE(p.thsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
+        uint32_t *af_best = NULL; double *af_loss = NULL, *af_reg = NULL;
+        if (ctx->af_iters) {      /* the final pass works on CF jobs */
+            TAKE(af_best, uint32_t, CF); TAKE(af_loss, double, CF); TAKE(af_reg, double, CF);
+            TAKE(p.af_a, double, CF * LNN_MAXP); TAKE(p.af_inv, double, CF * S); TAKE(p.af_R, double, CF * hs.maxP * hs.maxP);
+            TAKE(p.af_rv, double, CF * LNN_MAXP); TAKE(p.af_invd, double, CF * LNN_MAXP);
+            TAKE(p.af_obj, double, CF * LNN_MAXU); TAKE(p.af_prev, double, CF * LNN_MAXU); TAKE(p.af_state, uint32_t, CF * LNN_MAXU);
+            TAKE(p.af_prob, uint32_t, CF * LNN_MAXU); TAKE(p.af_nprob, uint32_t, 64); TAKE(p.af_pivot, double, CF * LNN_MAXU);
+        }
 #undef TAKE
         if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
         const uint32_t sblocks = (S + 255) / 256;
         { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_prep, dim3(Fc, C), dim3(PREP_THREADS), 0, st, p); span_end(ctx, sp_, st); }
-        uint32_t cur = 0;
+        /* -a N: the auxiliary-function iterations on the coefficients k_select kept for layer l (lnn_k_af.h); synchronous: every
+         * Cholesky pivot goes through the host's pow() */
+        auto run_af = [&](const Plan &q, uint64_t Jq, uint32_t l, uint32_t cur, uint32_t iters) -> int {
+            const uint32_t P = hs.P[l];
+            HIPCHK(ctx, hipMemsetAsync(q.af_nprob, 0, sizeof(uint32_t), st));
+            hipLaunchKernelGGL(k_af_init, dim3(((uint32_t)Jq + 255) / 256), dim3(256), 0, st, q, l);
+            uint32_t nprob = 0;
+            HIPCHK(ctx, hipMemcpyAsync(&nprob, q.af_nprob, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            if (nprob == 0) return LNN_OK;
+            if (ctx->af_h_cap < nprob) {
+                if (ctx->af_h) HIPCHK(ctx, hipHostFree(ctx->af_h));
+                ctx->af_h = NULL; ctx->af_h_cap = 0;
+                HIPCHK(ctx, hipHostMalloc((void **)&ctx->af_h, sizeof(double) * (size_t)nprob, hipHostMallocDefault));
+                ctx->af_h_cap = nprob;
+            }
+            const uint32_t M = P * (P + 1u) / 2u + P;
+            for (uint32_t it = 0; it < iters; it++) {
+                hipLaunchKernelGGL(k_af_resid, dim3((uint32_t)Jq, (S + AFR_THREADS * 4 - 1) / (AFR_THREADS * 4)), dim3(AFR_THREADS), 0, st, q, l, cur);
+                hipLaunchKernelGGL(k_af_obj, dim3((nprob + 63) / 64), dim3(64), 0, st, q, l, cur);
+                hipLaunchKernelGGL(k_af_matrix, dim3((uint32_t)Jq, (M + AFM_THREADS - 1) / AFM_THREADS), dim3(AFM_THREADS), 0, st, q, l, cur);
+                for (uint32_t i = 0; i < P; i++) {
+                    hipLaunchKernelGGL(k_af_pivot, dim3((nprob + 63) / 64), dim3(64), 0, st, q, l, i);
+                    HIPCHK(ctx, hipMemcpyAsync(ctx->af_h, q.af_pivot, sizeof(double) * (size_t)nprob, hipMemcpyDeviceToHost, st));
+                    HIPCHK(ctx, hipStreamSynchronize(st));
+                    for (uint32_t k = 0; k < nprob; k++) { const double v = ctx->af_h[k]; ctx->af_h[k] = (v <= 0.0) ? -1.0 : pow(v, -0.5); }      /* lpc.c:418-421, host libm */
+                    HIPCHK(ctx, hipMemcpyAsync(q.af_pivot, ctx->af_h, sizeof(double) * (size_t)nprob, hipMemcpyHostToDevice, st));
+                    hipLaunchKernelGGL(k_af_column, dim3(nprob), dim3(128), 0, st, q, l, i);
+                }
+                hipLaunchKernelGGL(k_af_solve, dim3((nprob + 63) / 64), dim3(64), 0, st, q, l);
+            }
+            hipLaunchKernelGGL(k_af_finish, dim3(((uint32_t)Jq + 255) / 256), dim3(256), 0, st, q, l);
+            HIPCHK(ctx, hipGetLastError());
+            return LNN_OK;
+        };
+        /* the layers of one pass over the jobs of plan q (linne_network.c:582-602): lags, Levinson-Durbin, the unit-count search,
+         * [the auxiliary-function refinement of the chosen coefficients], the forward pass.  Returns LNN_*; cur_out = which half of
+         * `sig` holds the last layer's output */
+        uint32_t cur_final = 0;
+        auto run_layers = [&](const Plan &q, uint64_t Jq, bool spec_ok, const bool *hall, bool fcfg, bool fall, uint32_t af_iters, bool final_pass) -> int {
+            int ret = LNN_OK;
+            uint32_t cur = 0;
         for (uint32_t l = 0; l < hs.L; l++) {
             const uint32_t maxu = hs.P[l] < 128u ? hs.P[l] : 128u;
             /* the first two layers nearly always keep one unit: their search pass also writes that trial's forward output */
-            const uint32_t fir_spec = (ctx->fir_spec && l + 1 < hs.L) ? 1u : 0u;
+            const uint32_t fir_spec = (spec_ok && ctx->fir_spec && l + 1 < hs.L) ? 1u : 0u;
             {
-                const bool hist_layer = p.hist && hs.P[l] >= 64u;
+                const bool hist_layer = q.hist && hs.P[l] >= 64u;
                 /* the general kernels serve what the lanes = jobs kernels do not take -- usually one ragged frame, a launch that is
                  * all latency: it runs beside them on the side stream */
-                const bool beside = hist_layer && !hist_all[l] && ctx->has_side;
+                const bool beside = hist_layer && !hall[l] && ctx->has_side;
                 if (beside) {
                     HIPCHK(ctx, hipEventRecord(ctx->fork_ev, st)); HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->fork_ev, 0));
-                    const int sp_ = span_begin(ctx, 3, ctx->side); dispatch_autocorr2(ctx->side, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, ctx->side);
+                    const int sp_ = span_begin(ctx, 3, ctx->side); dispatch_autocorr2(ctx->side, q, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, ctx->side);
                     HIPCHK(ctx, hipEventRecord(ctx->join_ev, ctx->side));
                 }
                 if (hist_layer) {                               /* long layer: lanes = jobs kernels for the frames they take (hist_takes) */
                     for (int w = 0; w < 3; w++) {
                         if (hs.P[l] == 64u && w == 1) continue;
-                        const int sp_ = span_begin(ctx, 21 + w, st); (void)launch_autocorr_hist(st, p, l, cur, w); span_end(ctx, sp_, st);
+                        const int sp_ = span_begin(ctx, 21 + w, st); (void)launch_autocorr_hist(st, q, l, cur, w); span_end(ctx, sp_, st);
                     }
                 }
                 if (beside) HIPCHK(ctx, hipStreamWaitEvent(st, ctx->join_ev, 0));
-                else if (!hist_all[l]) {
-                    const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, p, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, st);
+                else if (!hall[l]) {
+                    const int sp_ = span_begin(ctx, (hs.P[l] >= 32u) ? 3 : 14, st); dispatch_autocorr2(st, q, l, cur, ctx->na_max, (ctx->prod_ok >> l) & 1); span_end(ctx, sp_, st);
                 }
             }
             { const int sp_ = span_begin(ctx, 4, st);
@@ -707,48 +768,72 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   const uint32_t np = hs.P[l] / u;
                   const bool carry = (t == 0 && ride < LNN_MAXT);
                   const size_t lds = LEV_LDS(np) + (carry ? LEV_MAXRIDE * LEV_LDS(hs.P[l] >> ride) : 0);
-                  hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)J + 63) / 64, u), dim3(carry ? 64 * (1 + LEV_MAXRIDE) : 64), lds, st, p, l, t, carry ? ride : (uint32_t)LNN_MAXT);
+                  hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)Jq + 63) / 64, u), dim3(carry ? 64 * (1 + LEV_MAXRIDE) : 64), lds, st, q, l, t, carry ? ride : (uint32_t)LNN_MAXT);
               }
               span_end(ctx, sp_, st); }
             {   /* unit-count search.  Short layers: the register-window kernel.  The long layer: k_search_long for the frames it takes
                  * (search_long_takes), k_fir2<2> for the others (it returns at once for the jobs taken there) */
                 bool long_any = false, long_all = true;
-                for (uint32_t f = f0; f < f0 + Fc; f++) { const bool t_ = fir_spec && search_long_takes(p, l, ctx->sig_cls[ctx->cur_idx[f]]); long_any |= t_; long_all &= t_; }
+                for (uint32_t f = f0; f < f0 + Fc; f++) { const bool t_ = fir_spec && search_long_takes(q, l, ctx->sig_cls[ctx->cur_idx[f]]); long_any |= t_; long_all &= t_; }
                 if (long_any) {
                     const int sp_ = span_begin(ctx, 25, st);
-                    const dim3 grid((uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE), blk(FIR_THREADS);
-                    if (hs.P[l] == 128u) hipLaunchKernelGGL(k_search_long<128>, grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL(k_search_long<64>, grid, blk, 0, st, p, l, cur);
+                    const dim3 grid((uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE), blk(FIR_THREADS);
+                    if (hs.P[l] == 128u) hipLaunchKernelGGL(k_search_long<128>, grid, blk, 0, st, q, l, cur); else hipLaunchKernelGGL(k_search_long<64>, grid, blk, 0, st, q, l, cur);
                     span_end(ctx, sp_, st);
                 }
                 if (!(long_any && long_all)) {
                     const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st);
-                    if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]);
-                    else launch_fir<2>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0);
+                    if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, q, l, cur, (uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]);
+                    else launch_fir<2>(st, q, l, cur, (uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0);
                     span_end(ctx, sp_, st);
                 }
             }
-            { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 0u); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 0u); span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
-            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)J, 1), dim3(FIR_THREADS), 0, st, p, l, cur);
-              hipLaunchKernelGGL(k_select, dim3(((uint32_t)J + 63) / 64), dim3(64), 0, st, p, l, 1u); span_end(ctx, sp_, st); }
+            { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)Jq, 1), dim3(FIR_THREADS), 0, st, q, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)Jq, 1), dim3(FIR_THREADS), 0, st, q, l, cur);
+              hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 1u); span_end(ctx, sp_, st); }
             /* the last layer's output is only ever summed: layers of <= 16 taps do the forward pass and the ordered loss in one
              * kernel and write nothing else */
-            if (l + 1 == hs.L && fuse_cfg) {
+            if (l + 1 == hs.L && fcfg && !final_pass) {
                 const int sp_ = span_begin(ctx, 20, st);
-                const dim3 g(((uint32_t)J + 63) / 64), b(64);
+                const dim3 g(((uint32_t)Jq + 63) / 64), b(64);
                 switch (hs.P[l]) {
-                case 2: hipLaunchKernelGGL(k_fwd_loss<2>, g, b, 0, st, p, l, cur); break;
-                case 4: hipLaunchKernelGGL(k_fwd_loss<4>, g, b, 0, st, p, l, cur); break;
-                case 8: hipLaunchKernelGGL(k_fwd_loss<8>, g, b, 0, st, p, l, cur); break;
-                default: hipLaunchKernelGGL(k_fwd_loss<16>, g, b, 0, st, p, l, cur); break;
+                case 2: hipLaunchKernelGGL(k_fwd_loss<2>, g, b, 0, st, q, l, cur); break;
+                case 4: hipLaunchKernelGGL(k_fwd_loss<4>, g, b, 0, st, q, l, cur); break;
+                case 8: hipLaunchKernelGGL(k_fwd_loss<8>, g, b, 0, st, q, l, cur); break;
+                default: hipLaunchKernelGGL(k_fwd_loss<16>, g, b, 0, st, q, l, cur); break;
                 }
                 span_end(ctx, sp_, st);
             }
-            if (!(l + 1 == hs.L && fuse_all)) { const int sp_ = span_begin(ctx, (l == 0) ? 16 : (fir_spec ? 8 : 19), st); launch_fir<1>(st, p, l, cur, (uint32_t)J, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
+            if (af_iters && (ret = run_af(q, Jq, l, cur, af_iters)) != LNN_OK) return ret;
+            if (final_pass && l + 1 == hs.L) { cur ^= 1u; continue; }       /* the final pass needs no output of the last layer: only its parameters */
+            if (!(l + 1 == hs.L && fall)) { const int sp_ = span_begin(ctx, (l == 0) ? 16 : (fir_spec ? 8 : 19), st); launch_fir<1>(st, q, l, cur, (uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }
             cur ^= 1u;
         }
+            cur_final = cur;
+            return ret;
+        };
+        const uint32_t af_iters = ctx->af_iters;
+        if ((ret = run_layers(p, J, true, hist_all, fuse_cfg, fuse_all, 0u, false)) != LNN_OK) return ret;
+        uint32_t cur = cur_final;
         if (!fuse_all) { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
-        { const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st); }
+        if (af_iters == 0) {        /* the final pass of linne_network.c:628-629 repeats the winning pass bit for bit: skipped */
+            const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st);
+        } else {
+            /* -a N: the final pass is real -- the winner's regulariser, the refinement after every layer's search, and therefore
+             * new inputs (and possibly new unit counts) for the layers behind it.  One job per channel-frame, general kernels. */
+            Plan q = p;
+            q.R = 1; q.J = (uint32_t)CF; q.regs[0] = 0.0;
+            q.hist = 0; q.fused_last = 0; q.search_long = 0;
+            build_runs(&q.runs[1], ctx->cur_idx + f0, Fc, C);
+            q.job_reg = af_reg; q.af_best = af_best; q.af_loss = af_loss;
+            hipLaunchKernelGGL(k_af_best, dim3(((uint32_t)CF + 255) / 256), dim3(256), 0, st, p, af_best, af_loss, af_reg);
+            const bool none[LNN_MAXL] = { false, false, false };
+            const int sp_ = span_begin(ctx, 26, st);
+            if ((ret = run_layers(q, CF, false, none, false, false, af_iters, true)) != LNN_OK) return ret;
+            span_end(ctx, sp_, st);
+            { const int sp2_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, q); span_end(ctx, sp2_, st); }
+        }
         HIPCHK(ctx, hipGetLastError());
     }
     if (ctx->has_side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));

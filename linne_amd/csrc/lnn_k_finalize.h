@@ -23,8 +23,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
         for (uint32_t r = 0; r < p.R; r++) { const double l = p.jloss[(size_t)cf * p.R + r]; if (l < min_loss) { min_loss = l; best = r; } }
         s_best = best;
         st[LINNE_AMD_ST_TAIL] = p.jtail[(size_t)cf * p.R + best];
-        st[LINNE_AMD_ST_BEST] = (double)best;
-        st[LINNE_AMD_ST_LOSS] = p.jloss[(size_t)cf * p.R + best];
+        st[LINNE_AMD_ST_BEST] = p.af_best ? (double)p.af_best[cf] : (double)best;       /* -a N: this plan is the final pass of the winner */
+        st[LINNE_AMD_ST_LOSS] = p.af_loss ? p.af_loss[cf] : p.jloss[(size_t)cf * p.R + best];
     }
     /* the record is written completely, whatever the caller's buffer held: words this preset does not use are zero */
     for (uint32_t i = LINNE_AMD_PRM_UNITS + tid; i < LINNE_AMD_PARAM_WORDS; i += FIN_THREADS) rec[i] = 0;

@@ -17,7 +17,7 @@ __device__ __forceinline__ void levinson_problem(const Plan &p, uint32_t layer, 
     const bool have = inrange && t < c.ntrials[layer];
     const uint32_t n = c.na / u;
     double *sa = lev_lds + lane, *sr = lev_lds + (size_t)(np + 2) * 64 + lane;      /* element i at [i * 64] */
-    const double reg = p.regs[job % p.R];
+    const double reg = p.job_reg ? p.job_reg[job] : p.regs[job % p.R];
     const uint32_t ajob = (layer == 0) ? job - job % p.R : job;          /* layer 0: lags are computed once per channel-frame */
     const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
     double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;

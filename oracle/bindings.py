@@ -62,6 +62,7 @@ class Oracle:
         L.oracle_encoder_create.restype = C.c_void_p
         L.oracle_encoder_create.argtypes = [C.POINTER(EncodeParameter)]
         L.oracle_encoder_destroy.argtypes = [C.c_void_p]
+        L.oracle_encoder_set_af_iterations.argtypes = [C.c_void_p, C.c_uint32]
         L.oracle_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                           C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.oracle_encode_whole.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -84,11 +85,12 @@ class Oracle:
     def param(nch, bits, rate, block, preset, ms):
         return EncodeParameter(nch, bits, rate, block, preset, int(ms))
 
-    def encode_whole(self, x, bits, rate, block, preset, ms):
+    def encode_whole(self, x, bits, rate, block, preset, ms, af_iters=0):
         x = np.ascontiguousarray(x, dtype=np.int32)
         p = self.param(x.shape[0], bits, rate, block, preset, ms)
         enc = self.L.oracle_encoder_create(C.byref(p))
         assert enc, "oracle_encoder_create failed"
+        self.L.oracle_encoder_set_af_iterations(enc, af_iters)
         ptrs, keep = _planar_ptrs(x)
         cap = x.size * 4 * 2 + 65536
         out = np.zeros(cap, dtype=np.uint8)
@@ -110,11 +112,12 @@ class Oracle:
     class Encoder:
         """stateful block encoder (keeps the reference's cross-block buffer state, quirks Q1/Q2)"""
 
-        def __init__(self, oracle, nch, bits, rate, block, preset, ms):
+        def __init__(self, oracle, nch, bits, rate, block, preset, ms, af_iters=0):
             self.o = oracle
             self.p = Oracle.param(nch, bits, rate, block, preset, ms)
             self.h = oracle.L.oracle_encoder_create(C.byref(self.p))
             assert self.h
+            oracle.L.oracle_encoder_set_af_iterations(self.h, af_iters)
             self.nch, self.block = nch, block
 
         def close(self):
@@ -148,8 +151,8 @@ class Oracle:
             assert ret == 0, ret
             return tap, res
 
-    def encoder(self, nch, bits, rate, block, preset, ms):
-        return Oracle.Encoder(self, nch, bits, rate, block, preset, ms)
+    def encoder(self, nch, bits, rate, block, preset, ms, af_iters=0):
+        return Oracle.Encoder(self, nch, bits, rate, block, preset, ms, af_iters)
 
     def decode_hotpath(self, taps, residual, bits, block, preset, ms):
         """taps: sequence of ChannelTap (one per channel); residual [ch][n] -> pcm [ch][n]"""

@@ -301,6 +301,7 @@ struct Lpc {
     double *a, *u, *v;          /* order + 2 each */
     double *auto_corr, *lpc_coef, *parcor;   /* order + 1 each */
     double *buffer;             /* window output, max_samples */
+    double **r_mat;             /* (order + 1)^2, the auxiliary-function method's normal matrix (lpc.c:41) */
 };
 enum { WINDOW_SIN, WINDOW_WELCH };
 
@@ -382,19 +383,88 @@ static void lpc_calc(struct Lpc *c, const double *data, uint32_t n, uint32_t ord
     c->auto_corr[0] *= (1.0 + reg);
     lpc_levinson(c, c->auto_corr, order, c->lpc_coef, c->parcor);
 }
-/* LPCCalculator_CalculateLPCCoefficientsAF with zero AF iterations: lpc.c:578-661.  (-a N > 0 is
- * outside every BASELINE configuration and not restated.) */
-static void lpc_calc_af0(struct Lpc *c, const double *data, uint32_t n, double *coef, uint32_t order, double reg)
+/* LPC_CholeskyDecomposition, lpc.c:402-448: solves A x = b in place (A symmetric positive definite, upper triangle in,
+ * factor written below the diagonal); inv_diag[i] = pow(sum, -0.5) from libm.  Returns -1 for a non-positive pivot. */
+static int lpc_cholesky(double **A, int32_t dim, double *x, const double *b, double *inv_diag)
 {
-    uint32_t i;
+    int32_t i, j, k;
+    double sum;
+    for (i = 0; i < dim; i++) {
+        sum = A[i][i];
+        for (k = i - 1; k >= 0; k--) sum -= A[i][k] * A[i][k];
+        if (sum <= 0.0) return -1;
+        inv_diag[i] = pow(sum, -0.5);
+        for (j = i + 1; j < dim; j++) {
+            sum = A[i][j];
+            for (k = i - 1; k >= 0; k--) sum -= A[i][k] * A[j][k];
+            A[j][i] = sum * inv_diag[i];
+        }
+    }
+    for (i = 0; i < dim; i++) {
+        sum = b[i];
+        for (j = i - 1; j >= 0; j--) sum -= A[i][j] * x[j];
+        x[i] = sum * inv_diag[i];
+    }
+    for (i = dim - 1; i >= 0; i--) {
+        sum = x[i];
+        for (j = i + 1; j < dim; j++) sum -= A[j][i] * x[j];
+        x[i] = sum * inv_diag[i];
+    }
+    return 0;
+}
+/* LPCAF_CalculateCoefMatrixAndVector (forward residual form, the one compiled: lpc.c:451-509) */
+#define LPCAF_RESIDUAL_EPSILON 1e-6
+static double lpc_af_matrix(const double *data, uint32_t n, const double *a, double **R, double *rv, uint32_t order)
+{
+    uint32_t s, i, j;
+    double obj = 0.0;
+    for (i = 0; i < order; i++) { rv[i] = 0.0; for (j = 0; j < order; j++) R[i][j] = 0.0; }
+    for (s = order; s < n; s++) {
+        double residual = data[s], inv;
+        for (i = 0; i < order; i++) residual += a[i] * data[s - i - 1];
+        residual = fabs(residual);
+        obj += residual;
+        residual = (residual < LPCAF_RESIDUAL_EPSILON) ? LPCAF_RESIDUAL_EPSILON : residual;
+        inv = 1.0 / residual;
+        for (i = 0; i < order; i++) {
+            rv[i] -= data[s] * data[s - i - 1] * inv;
+            for (j = i; j < order; j++) R[i][j] += data[s - i - 1] * data[s - j - 1] * inv;
+        }
+    }
+    for (i = 0; i < order; i++) for (j = i + 1; j < order; j++) R[j][i] = R[i][j];
+    return obj / (n - order);
+}
+/* LPCCalculator_CalculateLPCCoefficientsAF -> LPC_CalculateCoefAF, lpc.c:578-661: Levinson-Durbin start, then up to max_iter
+ * rounds of the auxiliary-function (IRLS for the L1 norm) update; the solve writes a_vec from r_vec = u_vec with v_vec as the
+ * inverse diagonal, as the reference does (they are Levinson's work vectors otherwise) */
+static void lpc_calc_af(struct Lpc *c, const double *data, uint32_t n, double *coef, uint32_t order, uint32_t max_iter, double reg)
+{
+    uint32_t i, itr;
+    double obj, prev_obj;
     lpc_calc(c, data, n, order, WINDOW_WELCH, reg);
     memcpy(c->a, c->lpc_coef, sizeof(double) * order);
     if (fabs(c->auto_corr[0]) < FLT_EPSILON) {
         for (i = 0; i < order + 1; i++) c->lpc_coef[i] = 0.0;
-    } else {
-        memmove(c->lpc_coef, c->a, sizeof(double) * order);
+        memmove(coef, c->lpc_coef, sizeof(double) * order);
+        return;
     }
+    prev_obj = FLT_MAX;
+    for (itr = 0; itr < max_iter; itr++) {
+        obj = lpc_af_matrix(data, n, c->a, c->r_mat, c->u, order);
+        if (lpc_cholesky(c->r_mat, (int32_t)order, c->a, c->u, c->v) != 0) {
+            for (i = 0; i < order; i++) c->lpc_coef[i] = 0.0;
+            memmove(coef, c->lpc_coef, sizeof(double) * order);
+            return;
+        }
+        if (fabs(prev_obj - obj) < 1e-8) break;
+        prev_obj = obj;
+    }
+    memmove(c->lpc_coef, c->a, sizeof(double) * order);
     memmove(coef, c->lpc_coef, sizeof(double) * order);
+}
+static void lpc_calc_af0(struct Lpc *c, const double *data, uint32_t n, double *coef, uint32_t order, double reg)
+{
+    lpc_calc_af(c, data, n, coef, order, 0, reg);           /* LINNE_NUM_AF_METHOD_ITERATION_DETERMINEUNIT = 0 (linne_internal.h:26) */
 }
 /* lpc.c:810-865 (SIN window, regulariser 0) */
 static double lpc_estimate_code_length(struct Lpc *c, const double *data, uint32_t n, uint32_t bits, uint32_t order)
@@ -513,13 +583,13 @@ static uint32_t layer_search_units(struct Layer *L, struct Lpc *c, const double 
     return best;
 }
 /* linne_network.c:350-376 */
-static void layer_set_parameter(struct Layer *L, struct Lpc *c, const double *input, uint32_t n, double reg)
+static void layer_set_parameter(struct Layer *L, struct Lpc *c, const double *input, uint32_t n, uint32_t af_iters, double reg)
 {
     uint32_t i, unit;
     const uint32_t np = L->num_params / L->num_units, ns = n / L->num_units;
     for (unit = 0; unit < L->num_units; unit++) {
         double *h = &L->params[unit * np];
-        lpc_calc_af0(c, &input[unit * ns], ns, h, np, reg);
+        lpc_calc_af(c, &input[unit * ns], ns, h, np, af_iters, reg);
         for (i = 0; i < np / 2; i++) { double t = h[i]; h[i] = h[np - i - 1]; h[np - i - 1] = t; }
     }
 }
@@ -644,6 +714,7 @@ struct OracleEncoder {
     int32_t *buffer_int[ORACLE_MAX_CHANNELS];
     int32_t *residual[ORACLE_MAX_CHANNELS];
     double (*part_mean)[RICE_MAX_PARTS];
+    uint32_t af_iters;              /* num_afmethod_iterations (linne_encoder.c:462), 0 unless oracle_encoder_set_af_iterations */
     void *arena;
 };
 
@@ -671,7 +742,8 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
     total = 64 + sizeof(double) * ((size_t)(maxp + 2) * 3 + (maxp + 1) * 3 + 64)
           + sizeof(double) * (size_t)e->block * (3 + ORACLE_MAX_LAYERS) + sizeof(double) * ORACLE_MAX_LAYERS * (maxp + 2)
           + sizeof(int32_t) * (size_t)e->block * 2 * param->num_channels + 64 * 64
-          + sizeof(double) * (RICE_LOG2_MAX_PARTS + 1) * RICE_MAX_PARTS;
+          + sizeof(double) * (RICE_LOG2_MAX_PARTS + 1) * RICE_MAX_PARTS
+          + (sizeof(double) * (maxp + 1) + sizeof(double *)) * (maxp + 1) + 64;
     /* the reference allocates its work area with malloc (linne_encoder.c:280); a fresh large malloc is
      * zero pages, which is what calloc gives here deterministically (matters for Q1/Q2 on the first block) */
     e->arena = calloc(1, total);
@@ -685,6 +757,8 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
     e->lpc.lpc_coef = arena_take(&w, sizeof(double) * (maxp + 1));
     e->lpc.parcor = arena_take(&w, sizeof(double) * (maxp + 1));
     e->lpc.buffer = arena_take(&w, sizeof(double) * e->block);
+    e->lpc.r_mat = arena_take(&w, sizeof(double *) * (maxp + 1));
+    for (l = 0; l < maxp + 1; l++) e->lpc.r_mat[l] = arena_take(&w, sizeof(double) * (maxp + 1));
     for (l = 0; l < ps->num_layers; l++) {
         e->layer[l].din = arena_take(&w, sizeof(double) * e->block);
         e->layer[l].params = arena_take(&w, sizeof(double) * ps->layers[l]);
@@ -701,9 +775,10 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
     return e;
 }
 void oracle_encoder_destroy(struct OracleEncoder *e) { if (e) { free(e->arena); free(e); } }
+void oracle_encoder_set_af_iterations(struct OracleEncoder *e, uint32_t n) { if (e) e->af_iters = n; }
 
 /* linne_network.c:582-602 */
-static double network_search_set(struct OracleEncoder *e, const double *input, uint32_t n, double reg)
+static double network_search_set(struct OracleEncoder *e, const double *input, uint32_t n, uint32_t af_iters, double reg)
 {
     uint32_t l;
     const uint32_t max_units = 1u << ((1u << LOG2_UNITS_BITWIDTH) - 1);
@@ -711,7 +786,7 @@ static double network_search_set(struct OracleEncoder *e, const double *input, u
     for (l = 0; l < e->preset->num_layers; l++) {
         struct Layer *L = &e->layer[l];
         L->num_units = layer_search_units(L, &e->lpc, e->data_buffer, n, (max_units < L->num_params) ? max_units : L->num_params, reg);
-        layer_set_parameter(L, &e->lpc, e->data_buffer, n, reg);
+        layer_set_parameter(L, &e->lpc, e->data_buffer, n, af_iters, reg);
         layer_forward(L, e->data_buffer, n);
     }
     return l1_loss(e->data_buffer, n);
@@ -722,12 +797,12 @@ static void network_set_units_and_parameters(struct OracleEncoder *e, const doub
     uint32_t i, best_i = 0;
     double min_loss = FLT_MAX;
     for (i = 0; i < e->preset->num_regs; i++) {
-        const double loss = network_search_set(e, input, n, e->preset->regs[i]);
+        const double loss = network_search_set(e, input, n, 0, e->preset->regs[i]);
         if (tap) tap->pass_loss[i] = loss;
         if (loss < min_loss) { min_loss = loss; best_i = i; }
     }
     if (tap) tap->best_pass = best_i;
-    (void)network_search_set(e, input, n, e->preset->regs[best_i]);
+    (void)network_search_set(e, input, n, e->af_iters, e->preset->regs[best_i]);      /* the user's -a N applies to this pass only */
 }
 
 /* linne_encoder.c:480-529 */

@@ -72,6 +72,8 @@ extern "C" {
 
 struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *param);
 void oracle_encoder_destroy(struct OracleEncoder *enc);
+/* -a N: auxiliary-function iterations of the final pass (lpc.c:578-633, linne_network.c:605-630); default 0 */
+void oracle_encoder_set_af_iterations(struct OracleEncoder *enc, uint32_t n);
 
 /* == LINNEEncoder_EncodeBlock (libs/linne_encoder/src/linne_encoder.c:774-862).
  * tap (optional) receives the hot-path intermediates; residual_out (optional) receives

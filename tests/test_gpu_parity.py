@@ -603,3 +603,27 @@ def test_odd_block_sizes(product, oracle, reference, nch, bits, block, preset, t
     assert product.encode_blocks(x, bits, 44100, block, preset, ms) == want
     ret, dec = product.decode_whole(mine)
     assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("nch,bits,block,preset,total,af", [(2, 16, 1024, 7, 4 * 1024 + 300, 1), (2, 16, 1024, 7, 4 * 1024 + 300, 3), (1, 16, 2048, 4, 3 * 2048, 2),
+                                                            (2, 24, 1024, 0, 3000, 2), (2, 16, 10240, 7, 2 * 10240 + 2000, 1), (2, 16, 1024, 7, 4096, 10),
+                                                            (3, 16, 4096, 6, 2 * 4096 + 1001, 2)])
+def test_auxiliary_function_iterations(product, oracle, reference, nch, bits, block, preset, total, af):
+    """`-a N` (num_afmethod_iterations): the IRLS refinement of every layer's coefficients in the final
+    pass (lpc.c:452-509, 578-633; linne_network.c:350-376, 605-630) -- residual reciprocals, the normal matrix as 8384 ordered
+    chains, Cholesky with the host's pow(), the final pass run for real.  Bytes equal the reference's"""
+    x = music(nch, total, bits, seed=block + af)
+    ms = nch >= 2
+    want = reference.encode_whole(x, bits, 44100, block, preset, ms, af_iters=af)
+    assert oracle.encode_whole(x, bits, 44100, block, preset, ms, af_iters=af) == want
+    mine = product.encode_whole(x, bits, 44100, block, preset, ms, af_iters=af)
+    assert mine == want
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("kind", ["silence", "positive_const", "nyquist", "white_noise", "sine", "chirp"])
+def test_auxiliary_function_on_degenerate_signals(product, reference, kind):
+    """zero problems (lag 0 below FLT_EPSILON), singular normal matrices, exact fits: the branches of lpc.c:594-618"""
+    x = waveform(kind, 2, 4096, 16, seed=1)
+    assert product.encode_whole(x, 16, 44100, 1024, 7, True, af_iters=2) == reference.encode_whole(x, 16, 44100, 1024, 7, True, af_iters=2)
