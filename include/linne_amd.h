@@ -92,6 +92,9 @@ int LINNEAmd_SetStream(struct LINNEAmdContext *ctx, void *hip_stream);
  * the following EncodeFramesDevice / Host calls of this context; 0 (the default) = off.  With N > 0 a call synchronises the
  * host: every Cholesky pivot's pow(x, -0.5) is taken from the host's libm, whose bits no device routine can promise. */
 int LINNEAmd_SetAfIterations(struct LINNEAmdContext *ctx, uint32_t iterations);
+/* `-l` (struct LINNEEncodeParameter.enable_learning; linne_encoder.c:669-675): after the analysis every channel-frame's parameters go
+ * through LINNENetworkTrainer_Train (linne_network.c:805-873: up to 2000 momentum-SGD steps on the L1 loss).  Synchronises the host. */
+int LINNEAmd_SetLearning(struct LINNEAmdContext *ctx, uint32_t enable);
 
 /* ENCODE hot path, device resident.  Replaces, for every frame of the batch, the numeric core of
  * LINNEEncoder_EncodeCompressData (linne_encoder.c:613-696) and the analysis half of

@@ -40,7 +40,7 @@ AMD_SYMBOLS = [
     "LINNEAmd_ReserveScratch", "LINNEAmd_ScratchBytesPerFrame", "LINNEAmd_SetStream", "LINNEAmd_EncodeFramesDevice", "LINNEAmd_DecodeFramesDevice",
     "LINNEAmd_EncodeFramesHost", "LINNEAmd_DecodeFramesHost", "LINNEAmd_Synchronize", "LINNEAmd_GetLastFallbackCount", "LINNEAmd_GetLastTimingMs",
     "LINNEAmd_GetLastTimingLaunches", "LINNEAmd_EnableTiming", "LINNEAmd_PackFrames",
-    "LINNEAmd_GetLastMinMargin", "LINNEAmd_SetAfIterations", "LINNEAmd_MultiCreate", "LINNEAmd_MultiDestroy", "LINNEAmd_MultiNumDevices", "LINNEAmd_MultiDevice",
+    "LINNEAmd_GetLastMinMargin", "LINNEAmd_SetAfIterations", "LINNEAmd_SetLearning", "LINNEAmd_MultiCreate", "LINNEAmd_MultiDestroy", "LINNEAmd_MultiNumDevices", "LINNEAmd_MultiDevice",
     "LINNEAmd_MultiContext", "LINNEAmd_MultiGetLastError", "LINNEAmd_MultiEncodeFramesHost", "LINNEAmd_MultiDecodeFramesHost", "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
     "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_SlotCreateEx", "LINNEAmd_SlotFlags", "LINNEAmd_SlotPcm16", "LINNEAmd_SlotPacked", "LINNEAmd_SlotOffsets",
     "LINNEAmd_SlotFetchResidual", "LINNEAmd_RiceEmitDevice", "LINNEAmd_PackFramesEmitted", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
@@ -85,6 +85,7 @@ def _load():
     L.LINNEAmd_GetLastFallbackCount.restype = C.c_int64
     L.LINNEAmd_GetLastFallbackCount.argtypes = [C.c_void_p]
     L.LINNEAmd_SetAfIterations.argtypes = [C.c_void_p, C.c_uint32]
+    L.LINNEAmd_SetLearning.argtypes = [C.c_void_p, C.c_uint32]
     L.LINNEAmd_GetLastMinMargin.restype = C.c_double
     L.LINNEAmd_GetLastMinMargin.argtypes = [C.c_void_p]
     L.LINNEAmd_GetLastTimingMs.restype = C.c_double
@@ -172,6 +173,9 @@ class Context:
 
     def last_fallback_count(self):
         return int(lib.LINNEAmd_GetLastFallbackCount(self.h))
+
+    def set_learning(self, on):
+        self._check(lib.LINNEAmd_SetLearning(self.h, int(bool(on))), "SetLearning")
 
     def set_af_iterations(self, n):
         self._check(lib.LINNEAmd_SetAfIterations(self.h, int(n)), "SetAfIterations")

@@ -88,9 +88,9 @@ class LinneApi:
             raise RuntimeError(f"SetEncodeParameter -> {ret}")
         return enc
 
-    def encode_whole(self, x, bits, rate, block, preset, ms, af_iters=0):
+    def encode_whole(self, x, bits, rate, block, preset, ms, af_iters=0, learning=0):
         x = np.ascontiguousarray(x, dtype=np.int32)
-        enc = self.new_encoder(x.shape[0], bits, rate, block, preset, ms, af_iters=af_iters)
+        enc = self.new_encoder(x.shape[0], bits, rate, block, preset, ms, af_iters=af_iters, learning=learning)
         ptrs, keep = _planar_ptrs(x)
         cap = x.size * 4 * 2 + 65536
         out = np.zeros(cap, dtype=np.uint8)

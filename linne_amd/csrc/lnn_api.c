@@ -150,7 +150,7 @@ struct LINNEEncoder {
     struct lnn_layers layers;
     struct lnn_gpus gpus;               /* GPU resources: outside the work area, released by Destroy */
     double parcor_state;                /* oracle quirk Q2, carried from block to block */
-    uint32_t af_iters;                  /* num_afmethod_iterations of the last SetEncodeParameter */
+    uint32_t af_iters, learning;        /* num_afmethod_iterations / enable_learning of the last SetEncodeParameter */
     int32_t *pcm, *residual, *params;   /* one-frame staging, inside the work area */
     double *stats;
 };
@@ -251,11 +251,7 @@ LINNEApiResult LINNEEncoder_SetEncodeParameter(struct LINNEEncoder *encoder, con
     if (encoder->max_num_samples_per_block < parameter->num_samples_per_block || encoder->max_num_channels < parameter->num_channels) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
     if (encoder->max_num_layers < ly.num_layers) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
     for (l = 0; l < ly.num_layers; l++) if (encoder->max_num_parameters_per_layer < ly.size[l]) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
-    /* -l, the SGD trainer (linne_network.c:805-873), is the one refinement this build does not provide */
-    if (parameter->enable_learning != 0) {
-        fprintf(stderr, "liblinne_amd: -l (learning) is not offered by the MI355X path\n");
-        return LINNE_APIRESULT_INVALID_FORMAT;
-    }
+    encoder->learning = parameter->enable_learning ? 1u : 0u;   /* -l: linne_network.c:805-873 on the device (lnn_k_train.h) */
     encoder->af_iters = parameter->num_afmethod_iterations;       /* -a N: lpc.c:578-633 on the device (lnn_k_af.h) */
     if (parameter->num_channels > LINNE_MAX_NUM_CHANNELS) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
     memset(&h, 0, sizeof(h));
@@ -270,7 +266,7 @@ static LINNEApiResult encoder_device(struct LINNEEncoder *enc, int all)
 {
     uint32_t d;
     if (open_gpus(&enc->gpus, "LINNEEncoder", all) != LNN_OK) return LINNE_APIRESULT_NG;
-    for (d = 0; d < LNN_MAX_DEVICES; d++) if (enc->gpus.ctx[d]) (void)LINNEAmd_SetAfIterations(enc->gpus.ctx[d], enc->af_iters);
+    for (d = 0; d < LNN_MAX_DEVICES; d++) if (enc->gpus.ctx[d]) { (void)LINNEAmd_SetAfIterations(enc->gpus.ctx[d], enc->af_iters); (void)LINNEAmd_SetLearning(enc->gpus.ctx[d], enc->learning); }
     return LINNE_APIRESULT_OK;
 }
 static void report(const struct LINNEAmdContext *ctx, const char *what, int ret)

@@ -35,6 +35,7 @@
 #include "lnn_k_search.h"
 #include "lnn_k_fwdloss.h"
 #include "lnn_k_af.h"
+#include "lnn_k_train.h"
 #include "lnn_k_finalize.h"
 #include "lnn_k_decode.h"
 #include "lnn_k_rice.h"
@@ -72,6 +73,7 @@ struct LINNEAmdContext {
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
     int prod_ok;                        /* set per batch by build_classes, bit l: in layer l every class has all its trials and even unit lengths (k_autocorr_prod) */
     int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
+    uint32_t learning;                  /* -l: the SGD trainer after the analysis (LINNEAmd_SetLearning), 0 = off */
     uint32_t af_iters;                  /* -a N: auxiliary-function iterations of the final pass (LINNEAmd_SetAfIterations), 0 = off */
     double *af_h; uint32_t af_h_cap;    /* pinned: a Cholesky step's pivots on their way through the host's pow() */
     int pcm16_next;                     /* the next EncodeFramesDevice call reads int16 samples (set by the staging slots, cleared by the call) */
@@ -239,6 +241,12 @@ extern "C" int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx)
     return LNN_OK;
 }
 
+extern "C" int LINNEAmd_SetLearning(struct LINNEAmdContext *ctx, uint32_t enable)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->learning = enable ? 1u : 0u;
+    return LNN_OK;
+}
 extern "C" int LINNEAmd_SetAfIterations(struct LINNEAmdContext *ctx, uint32_t iterations)
 {
     if (!ctx) return LNN_INVALID_ARGUMENT;
@@ -526,7 +534,7 @@ static void build_runs(RowRuns *rr, const uint32_t *idx, uint32_t F, uint32_t rp
 }
 
 /* bytes of scratch one frame needs (C channel-frames, R passes each) */
-static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const HostShape *hs, uint32_t af_iters = 0)
+static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const HostShape *hs, uint32_t af_iters = 0, uint32_t learning = 0)
 {
     const uint64_t C = shape->num_channels, S = shape->num_samples_per_block, J = C * hs->R;
     uint64_t b = 0;
@@ -543,6 +551,9 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     b += J * 2 * sizeof(double);
     if (af_iters)       /* the auxiliary-function pass: per channel-frame the normal matrices, reciprocals, vectors, problem lists */
         b += C * (sizeof(double) * ((uint64_t)hs->maxP * hs->maxP + S + 3 * LNN_MAXP + 3 * LNN_MAXU + 2) + sizeof(uint32_t) * (2 * LNN_MAXU + 1)) + 8192;
+    if (af_iters || learning) b += C * (sizeof(uint32_t) + 2 * sizeof(double)) + 1024;        /* the winners of the search passes */
+    if (learning)       /* the trainer: two layer inputs and two gradient-signal buffers, gradients and momenta per channel-frame */
+        b += C * (sizeof(double) * (4 * S + 2 * LNN_MAXL * LNN_MAXP + 2) + sizeof(uint32_t)) + 4096;
     return b + 4096;
 }
 
@@ -590,7 +601,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames)) != LNN_OK) return ret;
 
     const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
-    const uint64_t per_frame = frame_scratch_bytes(shape, &hs, ctx->af_iters);
+    const uint64_t per_frame = frame_scratch_bytes(shape, &hs, ctx->af_iters, ctx->learning);
     if (ctx->arena_bytes < per_frame * 4 + 65536) {       /* grow the arena to hold at least a few frames */
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(ctx->arena)); ctx->arena = NULL; ctx->arena_bytes = 0;
@@ -680,8 +691,13 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TAKE(p.tloss, double, J * LNN_MAXT); p.npart = ((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64); TAKE(p.tsum, double, J * LNN_MAXT * p.npart); TAKE(p.txmax, double, J * p.npart); TAKE(p.thsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
         uint32_t *af_best = NULL; double *af_loss = NULL, *af_reg = NULL;
+        TrainArgs tr; memset(&tr, 0, sizeof(tr));
+        if (ctx->af_iters || ctx->learning) { TAKE(af_best, uint32_t, CF); TAKE(af_loss, double, CF); TAKE(af_reg, double, CF); }
+        if (ctx->learning) {
+            TAKE(tr.buf, double, CF * 4 * S); TAKE(tr.dparams, double, CF * LNN_MAXL * LNN_MAXP); TAKE(tr.momentum, double, CF * LNN_MAXL * LNN_MAXP);
+            TAKE(tr.loss, double, CF); TAKE(tr.prev, double, CF); TAKE(tr.active, uint32_t, CF); TAKE(tr.nactive, uint32_t, 64);
+        }
         if (ctx->af_iters) {      /* the final pass works on CF jobs */
-            TAKE(af_best, uint32_t, CF); TAKE(af_loss, double, CF); TAKE(af_reg, double, CF);
             TAKE(p.af_a, double, CF * LNN_MAXP); TAKE(p.af_inv, double, CF * S); TAKE(p.af_R, double, CF * hs.maxP * hs.maxP);
             TAKE(p.af_rv, double, CF * LNN_MAXP); TAKE(p.af_invd, double, CF * LNN_MAXP);
             TAKE(p.af_obj, double, CF * LNN_MAXU); TAKE(p.af_prev, double, CF * LNN_MAXU); TAKE(p.af_state, uint32_t, CF * LNN_MAXU);
@@ -813,11 +829,42 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             cur_final = cur;
             return ret;
         };
+        /* -l: LINNENetworkTrainer_Train on the parameters the analysis left (lnn_k_train.h); synchronous: the host reads after every
+         * step how many channel-frames go on */
+        auto run_train = [&](const Plan &q, const uint32_t *best) -> int {
+            tr.p = q; tr.best = best; tr.CF = (uint32_t)CF;
+            const uint32_t tiles = (S + TR_THREADS * 4 - 1) / (TR_THREADS * 4);
+            const int sp_ = span_begin(ctx, 27, st);
+            hipLaunchKernelGGL(k_tr_init, dim3(((uint32_t)CF + 255) / 256), dim3(256), 0, st, tr);
+            for (uint32_t it = 0; it < 2000u; it++) {                      /* LINNE_TRAINING_PARAMETER_MAX_NUM_ITRATION, linne_internal.h:29 */
+                HIPCHK(ctx, hipMemsetAsync(tr.nactive, 0, sizeof(uint32_t), st));
+                for (uint32_t l = 0; l < hs.L; l++) hipLaunchKernelGGL(k_tr_forward, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr, l);
+                hipLaunchKernelGGL(k_tr_loss, dim3(((uint32_t)CF + 63) / 64), dim3(64), 0, st, tr);
+                hipLaunchKernelGGL(k_tr_l1back, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr);
+                uint32_t g = TR_GA;
+                for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
+                    hipLaunchKernelGGL(k_tr_gradp, dim3((uint32_t)CF, (hs.P[l] + 63) / 64), dim3(64), 0, st, tr, (uint32_t)l, g);
+                    if (l > 0) { const uint32_t d = (g == TR_GA) ? TR_GB : TR_GA; hipLaunchKernelGGL(k_tr_back, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr, (uint32_t)l, g, d); g = d; }
+                }
+                hipLaunchKernelGGL(k_tr_update, dim3((uint32_t)CF), dim3(128), 0, st, tr, (double)0.8f, (double)0.1f, 1.0e-7);     /* linne_network.c:829, linne_internal.h:31-33 */
+                uint32_t left = 0;
+                HIPCHK(ctx, hipMemcpyAsync(&left, tr.nactive, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                if (left == 0) break;
+            }
+            span_end(ctx, sp_, st);
+            HIPCHK(ctx, hipGetLastError());
+            return LNN_OK;
+        };
         const uint32_t af_iters = ctx->af_iters;
         if ((ret = run_layers(p, J, true, hist_all, fuse_cfg, fuse_all, 0u, false)) != LNN_OK) return ret;
         uint32_t cur = cur_final;
         if (!fuse_all) { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
         if (af_iters == 0) {        /* the final pass of linne_network.c:628-629 repeats the winning pass bit for bit: skipped */
+            if (ctx->learning) {
+                hipLaunchKernelGGL(k_af_best, dim3(((uint32_t)CF + 255) / 256), dim3(256), 0, st, p, af_best, af_loss, af_reg);
+                if ((ret = run_train(p, af_best)) != LNN_OK) return ret;
+            }
             const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st);
         } else {
             /* -a N: the final pass is real -- the winner's regulariser, the refinement after every layer's search, and therefore
@@ -832,6 +879,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             const int sp_ = span_begin(ctx, 26, st);
             if ((ret = run_layers(q, CF, false, none, false, false, af_iters, true)) != LNN_OK) return ret;
             span_end(ctx, sp_, st);
+            if (ctx->learning && (ret = run_train(q, NULL)) != LNN_OK) return ret;
             { const int sp2_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_finalize, dim3((uint32_t)CF), dim3(FIN_THREADS), 0, st, q); span_end(ctx, sp2_, st); }
         }
         HIPCHK(ctx, hipGetLastError());

@@ -63,6 +63,7 @@ class Oracle:
         L.oracle_encoder_create.argtypes = [C.POINTER(EncodeParameter)]
         L.oracle_encoder_destroy.argtypes = [C.c_void_p]
         L.oracle_encoder_set_af_iterations.argtypes = [C.c_void_p, C.c_uint32]
+        L.oracle_encoder_set_learning.argtypes = [C.c_void_p, C.c_uint32]
         L.oracle_encode_block.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32,
                                           C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p]
         L.oracle_encode_whole.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32)]
@@ -85,12 +86,13 @@ class Oracle:
     def param(nch, bits, rate, block, preset, ms):
         return EncodeParameter(nch, bits, rate, block, preset, int(ms))
 
-    def encode_whole(self, x, bits, rate, block, preset, ms, af_iters=0):
+    def encode_whole(self, x, bits, rate, block, preset, ms, af_iters=0, learning=0):
         x = np.ascontiguousarray(x, dtype=np.int32)
         p = self.param(x.shape[0], bits, rate, block, preset, ms)
         enc = self.L.oracle_encoder_create(C.byref(p))
         assert enc, "oracle_encoder_create failed"
         self.L.oracle_encoder_set_af_iterations(enc, af_iters)
+        self.L.oracle_encoder_set_learning(enc, learning)
         ptrs, keep = _planar_ptrs(x)
         cap = x.size * 4 * 2 + 65536
         out = np.zeros(cap, dtype=np.uint8)

@@ -512,7 +512,7 @@ static void lpc_quantize(const double *dcoef, uint32_t order, uint32_t nbits, in
 /* ---------------------------------------------------------------------------------------------
  * the layer cascade: libs/linne_network/src/linne_network.c
  * ------------------------------------------------------------------------------------------- */
-struct Layer { double *din; double *params; uint32_t num_params, num_units; };
+struct Layer { double *din; double *params; uint32_t num_params, num_units; double *dout, *dparams, *momentum; };
 
 /* linne_network.c:50-63 */
 static double l1_loss(const double *d, uint32_t n)
@@ -593,6 +593,36 @@ static void layer_set_parameter(struct Layer *L, struct Lpc *c, const double *in
         for (i = 0; i < np / 2; i++) { double t = h[i]; h[i] = h[np - i - 1]; h[np - i - 1] = t; }
     }
 }
+
+/* linne_network.c:213-265: gradients of one layer; data holds the gradient w.r.t. the layer's output on entry and w.r.t. its
+ * input on return */
+static void layer_backward(struct Layer *L, double *data, uint32_t n)
+{
+    uint32_t unit, i, j;
+    const uint32_t ns = n / L->num_units, np = L->num_params / L->num_units;
+    memcpy(L->dout, data, sizeof(double) * n);
+    for (unit = 0; unit < L->num_units; unit++) {
+        const double *pin = &L->din[unit * ns], *pout = &L->dout[unit * ns], *h = &L->params[unit * np];
+        double *pback = &data[unit * ns], *pd = &L->dparams[unit * np];
+        for (i = 0; i < np; i++) {
+            pd[i] = 0.0f;
+            for (j = 0; j < (ns - np + i); j++) pd[i] += pin[j] * pout[np - i + j];
+        }
+        for (i = 0; i < (ns - np); i++) {
+            double back = 0.0f;
+            for (j = 0; j < np; j++) back += h[j] * pout[np + i - j];
+            pback[i] += back / np;
+        }
+        for (; i < ns; i++) {
+            double back = 0.0f;
+            for (j = 0; j < np; j++) if ((np + i - j) < ns) back += h[j] * pout[np + i - j];
+            pback[i] += back / np;
+        }
+    }
+}
+/* LINNENetworkTrainer_Train, linne_network.c:805-873 (momentum SGD on the L1 loss; `-l`), with LINNENetwork_CalculateGradient
+ * (:558-579) and LINNEL1Norm_Backward (:66-75) */
+static void network_train(struct OracleEncoder *e, const double *input, uint32_t n, uint32_t max_iter, double lr, double eps);
 
 /* ---------------------------------------------------------------------------------------------
  * integer filters and channel utilities
@@ -714,6 +744,7 @@ struct OracleEncoder {
     int32_t *buffer_int[ORACLE_MAX_CHANNELS];
     int32_t *residual[ORACLE_MAX_CHANNELS];
     double (*part_mean)[RICE_MAX_PARTS];
+    uint32_t learning;              /* enable_learning (linne_encoder.c:459), 0 unless oracle_encoder_set_learning */
     uint32_t af_iters;              /* num_afmethod_iterations (linne_encoder.c:462), 0 unless oracle_encoder_set_af_iterations */
     void *arena;
 };
@@ -740,7 +771,7 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
     if (!e) return NULL;
     e->p = *param; e->preset = ps; e->block = param->num_samples_per_block; e->max_params = maxp;
     total = 64 + sizeof(double) * ((size_t)(maxp + 2) * 3 + (maxp + 1) * 3 + 64)
-          + sizeof(double) * (size_t)e->block * (3 + ORACLE_MAX_LAYERS) + sizeof(double) * ORACLE_MAX_LAYERS * (maxp + 2)
+          + sizeof(double) * (size_t)e->block * (3 + 2 * ORACLE_MAX_LAYERS) + sizeof(double) * 3 * ORACLE_MAX_LAYERS * (maxp + 2) + 1024
           + sizeof(int32_t) * (size_t)e->block * 2 * param->num_channels + 64 * 64
           + sizeof(double) * (RICE_LOG2_MAX_PARTS + 1) * RICE_MAX_PARTS
           + (sizeof(double) * (maxp + 1) + sizeof(double *)) * (maxp + 1) + 64;
@@ -762,6 +793,9 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
     for (l = 0; l < ps->num_layers; l++) {
         e->layer[l].din = arena_take(&w, sizeof(double) * e->block);
         e->layer[l].params = arena_take(&w, sizeof(double) * ps->layers[l]);
+        e->layer[l].dout = arena_take(&w, sizeof(double) * e->block);
+        e->layer[l].dparams = arena_take(&w, sizeof(double) * ps->layers[l]);
+        e->layer[l].momentum = arena_take(&w, sizeof(double) * ps->layers[l]);
         e->layer[l].num_params = ps->layers[l];
         e->layer[l].num_units = 1;
     }
@@ -776,6 +810,33 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
 }
 void oracle_encoder_destroy(struct OracleEncoder *e) { if (e) { free(e->arena); free(e); } }
 void oracle_encoder_set_af_iterations(struct OracleEncoder *e, uint32_t n) { if (e) e->af_iters = n; }
+void oracle_encoder_set_learning(struct OracleEncoder *e, uint32_t on) { if (e) e->learning = on; }
+
+static void network_train(struct OracleEncoder *e, const double *input, uint32_t n, uint32_t max_iter, double lr, double eps)
+{
+    uint32_t itr, i, s_;
+    int32_t l;
+    const int32_t nl = (int32_t)e->preset->num_layers;
+    const double alpha = 0.8f;                               /* trainer->momentum_alpha = 0.8f */
+    double loss, prev_loss = FLT_MAX;
+    for (l = 0; l < nl; l++) for (i = 0; i < e->layer[l].num_params; i++) e->layer[l].momentum[i] = 0.0f;
+    for (itr = 0; itr < max_iter; itr++) {
+        memcpy(e->data_buffer, input, sizeof(double) * n);
+        for (l = 0; l < nl; l++) layer_forward(&e->layer[l], e->data_buffer, n);          /* LINNENetwork_CalculateLoss */
+        loss = l1_loss(e->data_buffer, n);
+        for (s_ = 0; s_ < n; s_++) { const double d = e->data_buffer[s_]; e->data_buffer[s_] = (double)((d > 0) - (d < 0)) / n; }
+        for (l = nl - 1; l >= 0; l--) layer_backward(&e->layer[l], e->data_buffer, n);
+        for (l = 0; l < nl; l++) {
+            struct Layer *L = &e->layer[l];
+            for (i = 0; i < L->num_params; i++) {
+                L->momentum[i] = alpha * L->momentum[i] + lr * L->dparams[i];
+                L->params[i] -= L->momentum[i];
+            }
+        }
+        if (fabs(loss - prev_loss) < eps) break;
+        prev_loss = loss;
+    }
+}
 
 /* linne_network.c:582-602 */
 static double network_search_set(struct OracleEncoder *e, const double *input, uint32_t n, uint32_t af_iters, double reg)
@@ -858,6 +919,7 @@ static void compress_hotpath(struct OracleEncoder *e, const int32_t *const *inpu
         struct OracleChannelTap *ct = tap ? &tap->ch[ch] : NULL;
         for (s = 0; s < na; s++) e->buffer_double[s] = e->buffer_int[ch][s] * pow(2.0, -(int32_t)(bits - 1));
         network_set_units_and_parameters(e, e->buffer_double, na, ct);
+        if (e->learning) network_train(e, e->buffer_double, na, 2000, 0.1f, 1.0e-7);      /* linne_encoder.c:669-675, linne_internal.h:29-33 */
         for (l = 0; l < nl; l++) {
             units[ch][l] = e->layer[l].num_units;
             lpc_quantize(e->layer[l].params, e->layer[l].num_params, COEF_BITWIDTH, icoef[ch][l], &rshifts[ch][l]);

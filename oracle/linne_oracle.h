@@ -74,6 +74,8 @@ struct OracleEncoder *oracle_encoder_create(const struct OracleEncodeParameter *
 void oracle_encoder_destroy(struct OracleEncoder *enc);
 /* -a N: auxiliary-function iterations of the final pass (lpc.c:578-633, linne_network.c:605-630); default 0 */
 void oracle_encoder_set_af_iterations(struct OracleEncoder *enc, uint32_t n);
+/* -l: the momentum-SGD trainer after the analysis (linne_network.c:805-873, linne_encoder.c:669-675); default off */
+void oracle_encoder_set_learning(struct OracleEncoder *enc, uint32_t on);
 
 /* == LINNEEncoder_EncodeBlock (libs/linne_encoder/src/linne_encoder.c:774-862).
  * tap (optional) receives the hot-path intermediates; residual_out (optional) receives

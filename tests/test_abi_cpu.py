@@ -107,7 +107,7 @@ def test_set_encode_parameter_errors(api):
                              ("num_samples_per_block", 0, INVALID_FORMAT), ("preset", 8, INVALID_FORMAT), ("ch_process_method", 2, INVALID_FORMAT),
                              ("num_samples_per_block", 100, INVALID_FORMAT),       # block <= largest layer (128 at -m 7)
                              ("num_channels", 3, INSUFFICIENT_BUFFER), ("num_samples_per_block", 8192, INSUFFICIENT_BUFFER),
-                             ("enable_learning", 1, INVALID_FORMAT),                    # -l: the one option this build refuses (loudly)
+                             ("enable_learning", 1, OK),                                # -l is served (lnn_k_train.h)
                              ("num_afmethod_iterations", 2, OK)]:                       # -a N is served (lnn_k_af.h)
         prm = good()
         setattr(prm, field, bad)

@@ -51,15 +51,13 @@ def test_usage_version_and_option_errors():
     assert r.returncode == 1 and "Failed to open" in r.stderr
 
 
-def test_refused_refinements(tmp_path):
-    """-l is not offered: SetEncodeParameter refuses it before any GPU work.  -a N is served by the device path (lnn_k_af.h): its
-    parameter is accepted, and without a GPU the encode then fails loudly like any other (no CPU fallback)"""
+def test_refinement_options_are_accepted(tmp_path):
+    """-l and -a N are served by the device path (lnn_k_train.h, lnn_k_af.h): SetEncodeParameter accepts them, and without a GPU
+    the encode then fails loudly like any other (no CPU fallback)"""
     x = np.zeros((1, 4096), dtype=np.int32)
     w = tmp_path / "z.wav"
     w.write_bytes(wav_bytes(x, 16, 8000))
-    r = run("-e", "-m", "3", "-l", str(w), str(tmp_path / "z.lnn"))
-    assert r.returncode == 1 and "Failed to set encode parameter" in r.stderr
-    for extra in (["-a", "2"], ["--auxiliary-function-iteration=1"]):
+    for extra in (["-l"], ["-a", "2"], ["--auxiliary-function-iteration=1"]):
         r = run("-e", "-m", "3", *extra, str(w), str(tmp_path / "z.lnn"))
         assert "Failed to set encode parameter" not in r.stderr
         assert r.returncode == 0 or "no CPU fallback" in r.stderr

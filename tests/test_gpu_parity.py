@@ -627,3 +627,25 @@ def test_auxiliary_function_on_degenerate_signals(product, reference, kind):
     """zero problems (lag 0 below FLT_EPSILON), singular normal matrices, exact fits: the branches of lpc.c:594-618"""
     x = waveform(kind, 2, 4096, 16, seed=1)
     assert product.encode_whole(x, 16, 44100, 1024, 7, True, af_iters=2) == reference.encode_whole(x, 16, 44100, 1024, 7, True, af_iters=2)
+
+
+@pytest.mark.parametrize("nch,bits,block,preset,total,af", [(1, 16, 1024, 7, 1024 + 300, 0), (2, 16, 1024, 4, 2 * 1024, 0), (2, 16, 512, 0, 1200, 1),
+                                                            (1, 24, 1024, 5, 2048, 0), (2, 16, 2048, 7, 2 * 2048 + 999, 2)])
+def test_network_trainer(product, oracle, reference, nch, bits, block, preset, total, af):
+    """`-l` (enable_learning): LINNENetworkTrainer_Train (linne_network.c:805-873) after the analysis --
+    forward, L1 loss, back-propagation through the cascade, momentum step, until the loss stands still -- alone and behind `-a N`.
+    Bytes equal the reference's"""
+    x = music(nch, total, bits, seed=block + af)
+    ms = nch >= 2
+    want = reference.encode_whole(x, bits, 44100, block, preset, ms, af_iters=af, learning=1)
+    assert oracle.encode_whole(x, bits, 44100, block, preset, ms, af_iters=af, learning=1) == want
+    mine = product.encode_whole(x, bits, 44100, block, preset, ms, af_iters=af, learning=1)
+    assert mine == want
+    ret, dec = product.decode_whole(mine)
+    assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("kind", ["silence", "nyquist", "sine", "white_noise"])
+def test_network_trainer_on_degenerate_signals(product, reference, kind):
+    x = waveform(kind, 1, 1024, 16, seed=1)
+    assert product.encode_whole(x, 16, 44100, 512, 4, False, learning=1) == reference.encode_whole(x, 16, 44100, 512, 4, False, learning=1)
