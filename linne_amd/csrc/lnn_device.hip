@@ -1052,7 +1052,8 @@ extern "C" int LINNEAmd_RicePlanDevice(struct LINNEAmdContext *ctx, const struct
         RicePlanArgs b = a;
         b.resid = d_residual + c0 * a.S; b.plan = d_plan + c0 * LINNE_AMD_RICE_PLAN_BYTES; b.nsmp = ctx->d_plan_nsmp + c0 / a.C;
         const int sp_ = span_begin(ctx, 17, ctx->stream);
-        hipLaunchKernelGGL(k_rice_plan, dim3((uint32_t)cnt), dim3(RICE_THREADS), 0, ctx->stream, b);
+        if (b.S <= REMIT_LDS_SAMPLES) hipLaunchKernelGGL(k_rice_plan<true>, dim3((uint32_t)cnt), dim3(RICE_THREADS), sizeof(uint32_t) * (b.S + 1025u), ctx->stream, b);
+        else hipLaunchKernelGGL(k_rice_plan<false>, dim3((uint32_t)cnt), dim3(RICE_THREADS), 0, ctx->stream, b);
         span_end(ctx, sp_, ctx->stream);
         c0 += cnt;
     }

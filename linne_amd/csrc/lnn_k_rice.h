@@ -10,6 +10,7 @@
  * record's flag and the host searches that channel-frame itself), code lengths are uint32 with wrap-around.
  * ============================================================================================== */
 #define RICE_THREADS 256
+#define REMIT_LDS_SAMPLES 12288u            /* frames up to this length are staged in LDS (48 KB + padding) by k_rice_plan / k_rice_emit */
 struct RicePlanArgs {
     const int32_t *resid; const uint32_t *nsmp; uint8_t *plan; uint32_t C, S, nsteps;
     double steps[32];
@@ -17,8 +18,13 @@ struct RicePlanArgs {
 __device__ __forceinline__ uint32_t rp_zz(int32_t v) { const uint32_t d = (uint32_t)v << 1; return (v < 0) ? ((0u - d) - 1u) : d; }
 __device__ __forceinline__ uint32_t rp_gamma_len(uint32_t u) { return u ? (2u * (32u - (uint32_t)__clz((int)(u + 1u))) - 1u) : 1u; }   /* 2*ceil_log2(u+2)-1 */
 
-__global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(RicePlanArgs a)
+/* LDS: a thread walks the nsf consecutive samples of its finest partition; straight from global memory that is a 4 * nsf byte
+ * stride between lanes (every load instruction touches 64 cache lines), so frames up to REMIT_LDS_SAMPLES are first brought into
+ * LDS with coalesced loads, zig-zagged on the way; run r starts at r * (nsf + 1) so that the lanes' strided reads spread over
+ * the banks */
+template <bool LDS> __global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(RicePlanArgs a)
 {
+    extern __shared__ uint32_t zbuf[];
     __shared__ double mean[2048];            /* level o (2^o partitions) at [2^o - 1, 2^(o+1) - 1) */
     __shared__ uint8_t kk[2048];
     __shared__ uint32_t tot[12];
@@ -33,10 +39,12 @@ __global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(RicePlanArgs a)
     const uint32_t parts = 1u << max_order, nsf = n / parts;
     if (tid < 12) tot[tid] = 0;
     if (tid == 0) flag = 0;
+    if (LDS) { for (uint32_t s = tid; s < n; s += RICE_THREADS) zbuf[s + s / nsf] = rp_zz(x[s]); __syncthreads(); }
     for (uint32_t p = tid; p < parts; p += RICE_THREADS) {
         const int32_t *q = x + (size_t)p * nsf;
+        const uint32_t *zq = zbuf + (size_t)p * (nsf + 1u);
         uint64_t sum = 0;
-        for (uint32_t j = 0; j < nsf; j++) sum += rp_zz(q[j]);
+        for (uint32_t j = 0; j < nsf; j++) sum += LDS ? zq[j] : rp_zz(q[j]);
         mean[parts - 1 + p] = (double)sum / (double)nsf;
     }
     __syncthreads();
@@ -68,11 +76,12 @@ __global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(RicePlanArgs a)
     /* per finest partition: the excess of its samples under the parameter of each order's enclosing partition */
     for (uint32_t p = tid; p < parts; p += RICE_THREADS) {
         const int32_t *q = x + (size_t)p * nsf;
+        const uint32_t *zq = zbuf + (size_t)p * (nsf + 1u);
         uint32_t kc[11], acc[11];
 #pragma unroll
         for (uint32_t o = 0; o < 11; o++) { acc[o] = 0; kc[o] = (o <= max_order) ? kk[((1u << o) - 1u) + (p >> (max_order - o))] : 0u; }
         for (uint32_t j = 0; j < nsf; j++) {
-            const uint32_t v = rp_zz(q[j]);
+            const uint32_t v = LDS ? zq[j] : rp_zz(q[j]);
 #pragma unroll
             for (uint32_t o = 0; o < 11; o++) { const uint32_t k1pow = 1u << ((kc[o] + 1u) & 31u); acc[o] += ((v > k1pow) ? (v - k1pow) : 0u) >> kc[o]; }
         }
@@ -172,7 +181,6 @@ struct RiceBW {
 };
 
 #define REMIT_THREADS 256
-#define REMIT_LDS_SAMPLES 12288u            /* frames up to this length are staged in LDS (48 KB + padding) */
 /* A thread codes `ipt` consecutive samples.  Read straight from global memory that is a 4 * ipt byte stride between lanes --
  * every load instruction touches 64 cache lines -- so the block first brings the channel-frame into LDS with coalesced loads
  * (zig-zagged on the way) and the two passes read it from there; run r starts at r * (ipt + 1) so that the lanes' strided reads

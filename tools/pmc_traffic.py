@@ -4,13 +4,14 @@ prescribes) of tools/kbench.py --frames F: writes profiles/pmc_latest.json.  Cou
 usage: pmc_traffic.py fetch.csv write.csv frames channels"""
 import csv, json, sys, collections
 fetch_csv, write_csv, frames, channels = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-KIND = [("k_fir2<2, false, true>", "k_fir2<2,false,true> (search of the long layer + fused one-unit forward)"),
+KIND = [("k_search_long", "k_search_long<P> (search of the long layer in one window pass + fused one-unit forward)"),
+        ("k_fir2<2, false, true>", "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)"),
         ("k_fir_small<16, false", "k_fir_small<P,false,*> (search of the last, short layer)"), ("k_fir_small<8, false", "k_fir_small<P,false,*> (search of the last, short layer)"),
         ("k_fir_small<4, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"), ("k_fir_small<2, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"),
         ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_fwd_loss", "k_fwd_loss<P> (last layer: forward pass + ordered loss)"),
         ("k_fir2<1, true", "k_fir2<1,true,*> (forward of layer 0, jobs with several units)"),
         ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"),
-        ("k_synth", "k_synth_small+k_synth_big (all layers, de-emphasis)"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan")]
+        ("k_synth", "k_synth_small+k_synth_big (all layers, de-emphasis)"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan"), ("k_rice_emit", "k_rice_emit")]
 def load(path, counter):
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
