@@ -145,6 +145,13 @@ int LINNEAmd_RiceEmitDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdSh
         const int32_t *d_residual, uint32_t num_frames, const uint8_t *d_plan,
         uint32_t *d_offsets, uint8_t *d_packed, uint64_t packed_capacity);
 
+/* Rice DECODING on the device (linne_coder.c:306-327): lanes = frames, every lane walks its block's channels from d_bitpos[f] on.
+ * d_stream must be 4-byte aligned and readable up to the next multiple of 8 behind stream_bytes.  d_endbit[f] = the bit position
+ * behind the frame's last code, ~0 for a frame whose code holds something no encoder writes (decode it on the host). */
+int LINNEAmd_RiceDecodeDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_bitpos, const uint32_t *h_num_samples, uint32_t num_frames,
+        int32_t *d_residual, uint64_t *d_endbit);
+
 /* Staging slots: what a whole-stream caller (LINNEEncoder_EncodeWhole / LINNEDecoder_DecodeWhole,
  * linne_encoder.c:865-932, linne_decoder.c:671-742) uses instead of the synchronous host forms.  A slot owns pinned
  * host buffers and device buffers for up to max_frames frames of one shape.  The caller fills SlotPcm (encode) or
@@ -164,6 +171,7 @@ struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx, const stru
  *                         bit length at LINNE_AMD_RICE_PLAN_NBITS.  The residual is not copied to the host (SlotData is NULL). */
 #define LINNE_AMD_SLOT_PCM16  1u
 #define LINNE_AMD_SLOT_EMIT   2u
+#define LINNE_AMD_SLOT_STREAM 4u       /* decode slots: see LINNEAmd_SlotDecodeStreamSubmit */
 struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         uint32_t max_frames, int for_encode, uint32_t flags);
 uint32_t  LINNEAmd_SlotFlags(const struct LINNEAmdSlot *slot);
@@ -171,6 +179,20 @@ int16_t  *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *slot);                   /* [F
 const uint8_t  *LINNEAmd_SlotPacked(struct LINNEAmdSlot *slot);
 const uint32_t *LINNEAmd_SlotOffsets(struct LINNEAmdSlot *slot);           /* [F * C + 1], the last entry = bytes used */
 int LINNEAmd_SlotFetchResidual(struct LINNEAmdSlot *slot, uint32_t frame, int32_t *dst /* [C][S] */);
+/* Decode slots with less PCIe traffic and no Rice decoding on the host (what LINNEDecoder_DecodeWhole uses for streams whose CRCs
+ * it checks): created with LINNE_AMD_SLOT_STREAM (| LINNE_AMD_SLOT_PCM16 for <= 16-bit audio).  The caller copies the bytes of a group
+ * of blocks into SlotStream, sets SlotBitPos[f] = the bit offset in that buffer at which frame f's first channel's Rice code starts
+ * (behind the parameter bits; lnn_parse_block_head), fills SlotParams, and submits: H2D, LINNEAmd_RiceDecodeDevice, the synthesis
+ * kernels, D2H.  After SlotWait: SlotEndBits[f] = the bit position behind frame f's last code (from which the bytes the block
+ * consumed follow, linne_decoder.c:495-499), or ~0 when the stream held something no encoder writes -- the host must then decode
+ * the group itself (SlotDecodeSubmit); PCM in SlotData, or in SlotPcm16 when SlotPcm16Valid (every sample fitted). */
+uint8_t  *LINNEAmd_SlotStream(struct LINNEAmdSlot *slot);
+uint64_t  LINNEAmd_SlotStreamCapacity(const struct LINNEAmdSlot *slot);
+uint64_t *LINNEAmd_SlotBitPos(struct LINNEAmdSlot *slot);
+const uint64_t *LINNEAmd_SlotEndBits(struct LINNEAmdSlot *slot);
+int LINNEAmd_SlotPcm16Valid(const struct LINNEAmdSlot *slot);
+int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *slot, uint64_t stream_bytes, const uint32_t *num_samples, uint32_t num_frames);
+int LINNEAmd_SlotFetchPcm32(struct LINNEAmdSlot *slot, uint32_t num_frames);
 void      LINNEAmd_SlotDestroy(struct LINNEAmdSlot *slot);
 int32_t  *LINNEAmd_SlotPcm(struct LINNEAmdSlot *slot);       /* [F][C][S] int32, encode input (NULL for a decode slot) */
 int32_t  *LINNEAmd_SlotData(struct LINNEAmdSlot *slot);      /* [F][C][S] int32, residual (encode out, decode in) / PCM (decode out) */
@@ -251,6 +273,12 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
         uint32_t num_frames, const int32_t *residual, const int32_t *params, const double *stats, const uint8_t *rice_plan,
         uint8_t *blocks_out, uint64_t blocks_capacity, uint32_t *block_sizes, double *parcor_state,
         uint32_t num_threads);
+
+/* How the calling thread's last LINNEDecoder_DecodeWhole ran.  Bit 0: it finished with the device decoding the Rice codes
+ * (LINNEAmd_SlotDecodeStreamSubmit; LINNE_AMD_DECODE_STREAM=1 asks for it, CRC-checked streams only).  Bit 1: it had
+ * started that way, met a block no encoder writes (or 16-bit PCM out of range) and went over the stream again with the host's Rice
+ * decoder, which is the reference's decoder restated (linne_coder.c:304-345). */
+uint32_t LINNEAmd_LastDecodeWholeMode(void);
 
 /* The host stage when the device wrote the Rice codes (LINNEAmd_RiceEmitDevice, or an encode slot with LINNE_AMD_SLOT_EMIT): block
  * types in stream order, then per block the header, the parameter bits (linne_encoder.c:698-735), the channels' codes appended at

@@ -135,6 +135,12 @@ class LinneApi:
         self.L.LINNEDecoder_Destroy(dec)
         return ret, keep
 
+    def last_decode_whole_mode(self):
+        """liblinne_amd only: bit 0 = the last decode_whole let the device decode the Rice codes, bit 1 = it started over on the host"""
+        fn = self.L.LINNEAmd_LastDecodeWholeMode
+        fn.restype = C.c_uint32
+        return int(fn())
+
 
 
 

@@ -86,9 +86,11 @@ static void drop_slots(struct lnn_gpus *g)
         for (i = 0; i < LNN_SLOTS; i++) { if (g->slot[d][i]) LINNEAmd_SlotDestroy(g->slot[d][i]); g->slot[d][i] = NULL; }
 }
 /* (re)creates the staging slots of a handle for `frames` frames per slot, `count` per device; keeps what already fits */
-static int want_slots(struct lnn_gpus *g, const struct LINNEAmdShape *shape, uint32_t frames, uint32_t count, int for_encode)
+static int want_slots(struct lnn_gpus *g, const struct LINNEAmdShape *shape, uint32_t frames, uint32_t count, int mode)
 {
-    uint32_t d, i, flags = 0;
+    /* mode: 1 encode, 0 decode (residual in, PCM out), 2 decode in stream mode (the blocks' bytes in, int16 PCM out where it fits) */
+    const int for_encode = (mode == 1);
+    uint32_t d, i, flags = (mode == 2) ? (LINNE_AMD_SLOT_STREAM | (shape->bits_per_sample <= 16 ? LINNE_AMD_SLOT_PCM16 : 0u)) : 0;
     if (for_encode) {       /* 16-bit staging and Rice emission on the device (LINNE_AMD_EMIT=0: int32 both ways, the host codes the residual) */
         const char *e = getenv("LINNE_AMD_EMIT");
         if (!e || atoi(e) != 0) flags = LINNE_AMD_SLOT_PCM16 | LINNE_AMD_SLOT_EMIT;
@@ -540,11 +542,13 @@ LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint
  * blocks on the host threads straight into a staging slot, synthesise it on the GPU while the next group is being
  * entropy-decoded, then scatter the PCM into the caller's planes ---- */
 struct dgroup {
-    uint32_t nblk, ncomp;
+    uint32_t nblk, ncomp; int streamed; uint64_t seg_first, seg_bytes;
     uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn, *cons; int *rets;
 };
 struct unpack_job {
     const struct LINNEDecoder *dec; const uint8_t *data; struct dgroup *g; int32_t *sdata, *sprm; int32_t **buffer;
+    /* stream mode (the device decodes the Rice codes): the group's bytes go to the slot as they are, from seg_first on */
+    uint8_t *sstream; uint64_t *sbitpos; uint64_t seg_first, seg_bytes; const int16_t *s16;
 };
 static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
 {
@@ -556,6 +560,13 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
     int32_t *tmp = NULL, tprm[LINNE_MAX_NUM_CHANNELS * LINNE_AMD_PARAM_WORDS];
     uint32_t f, ch;
     for (f = first; f < first + count; f++) {
+        if (g->cidx[f] != 0xFFFFFFFFu && j->sstream) {      /* stream mode: header, CRC and parameters here, the Rice code on the device */
+            uint64_t rbit = 0;
+            g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
+                    &g->types[f], &g->ns[f], &g->cons[f], NULL, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS, &rbit);
+            j->sbitpos[g->cidx[f]] = (g->offs[f] - j->seg_first) * 8u + rbit;
+            continue;
+        }
         if (g->cidx[f] != 0xFFFFFFFFu) {            /* COMPRESS by its header: residual and parameters go to the slot */
             g->rets[f] = lnn_parse_block(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
                     &g->types[f], &g->ns[f], &g->cons[f], j->sdata + g->cidx[f] * CS, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS);
@@ -577,9 +588,21 @@ static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
     uint32_t f, ch;
     for (f = first; f < first + count; f++) {
         if (g->types[f] != LNN_BLOCK_COMPRESS) continue;
-        for (ch = 0; ch < C; ch++)
-            memcpy(j->buffer[ch] + g->prog[f], j->sdata + ((size_t)g->cidx[f] * C + ch) * S, sizeof(int32_t) * g->ns[f]);
+        for (ch = 0; ch < C; ch++) {
+            if (j->s16) {               /* the PCM came back as int16: widen on the way into the caller's planes */
+                const int16_t *src = j->s16 + ((size_t)g->cidx[f] * C + ch) * S;
+                int32_t *dst = j->buffer[ch] + g->prog[f];
+                uint32_t s_;
+                for (s_ = 0; s_ < g->ns[f]; s_++) dst[s_] = src[s_];
+            } else memcpy(j->buffer[ch] + g->prog[f], j->sdata + ((size_t)g->cidx[f] * C + ch) * S, sizeof(int32_t) * g->ns[f]);
+        }
     }
+}
+static void copy_segment(void *arg, uint32_t first, uint32_t count)     /* the group's bytes -> the slot's pinned stream buffer, 1 MiB pieces */
+{
+    struct unpack_job *j = arg;
+    const uint64_t a = (uint64_t)first << 20, b0 = (uint64_t)(first + count) << 20, b = (b0 < j->seg_bytes) ? b0 : j->seg_bytes;
+    if (a < b) memcpy(j->sstream + a, j->data + j->seg_first + a, b - a);
 }
 static int dgroup_alloc(struct dgroup *g, uint32_t n)
 {
@@ -593,6 +616,11 @@ static void dgroup_free(struct dgroup *g)
 {
     free(g->offs); free(g->avail); free(g->room); free(g->types); free(g->ns); free(g->prog); free(g->cidx); free(g->cn); free(g->rets); free(g->cons);
 }
+
+static __thread uint32_t g_last_decode_mode;
+/* how this thread's last LINNEDecoder_DecodeWhole ran: bit 0 = it finished with the device decoding the Rice codes, bit 1 = it
+ * had started that way and went over everything again with the host's Rice decoder */
+uint32_t LINNEAmd_LastDecodeWholeMode(void) { return g_last_decode_mode; }
 
 LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint8_t *data, uint32_t data_size,
         int32_t **buffer, uint32_t buffer_num_channels, uint32_t buffer_num_samples)
@@ -608,6 +636,15 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     uint64_t off;
     double t_begin = now_s(), t_parse = 0, t_submit = 0, t_wait = 0, t_scatter = 0, t0;
     int ret = LNN_OK, scanning = 1;
+    /* stream mode (LINNE_AMD_DECODE_STREAM=1; off by default): the device decodes the Rice codes (LINNEAmd_SlotDecodeStreamSubmit).
+     * Only for streams whose CRCs are checked: a block that passes is what an encoder wrote.  Should the device still meet
+     * something no encoder writes, or PCM beyond the 16-bit range, the whole call starts over with the host's Rice decoder
+     * (stream_mode = 0).  Off by default because it is the slower way on one GPU with 16 host threads: k_rice_decode is one lane
+     * per block (the second channel's code starts where the first one's ends), 21 ms per group of 3 100 blocks against 13 ms of
+     * host parsing (profiles/r02_decode_stream.txt); it takes 2/3 of the decoder's work off the host, which is what counts when
+     * several GPUs share those threads. */
+    int stream_mode;
+    { const char *e_ = getenv("LINNE_AMD_DECODE_STREAM"); stream_mode = (e_ ? atoi(e_) != 0 : 0); }
     if (decoder == NULL || data == NULL || buffer == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if ((r = LINNEDecoder_DecodeHeader(data, data_size, &h)) != LINNE_APIRESULT_OK) return r;
     if ((r = LINNEDecoder_SetHeader(decoder, &h)) != LINNE_APIRESULT_OK) return r;
@@ -622,9 +659,13 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
         ndev = gp->ndev; window = ndev * LNN_SLOTS;
         group = default_group((F + ndev - 1) / ndev, &decoder->shape, &decoder->layers, 0); if (group > F) group = F ? F : 1;
     }
+    if (!decoder->check_crc) stream_mode = 0;
+    g_last_decode_mode = 0;
     for (ngalloc = 0; ngalloc < window; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
+restart:
+    memset(&uj, 0, sizeof(uj));
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;
-    off = LINNE_HEADER_SIZE;
+    off = LINNE_HEADER_SIZE; produced = 0; consumed_groups = 0; progress = 0; scanning = 1; ret = LNN_OK;
     while (scanning || consumed_groups < produced) {
         if (scanning && produced - consumed_groups < window && progress < hd->num_samples && off < data_size) {
             struct dgroup *g = &grp[produced % window];
@@ -647,13 +688,21 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
             if (ncomp) {
                 int wret;
                 if (decoder_device(decoder, 1) != LINNE_APIRESULT_OK) { ret = LNN_NG; goto done; }
-                if ((wret = want_slots(gp, &decoder->shape, group, LNN_SLOTS, 0)) != 0) {
+                if ((wret = want_slots(gp, &decoder->shape, group, LNN_SLOTS, stream_mode ? 2 : 0)) != 0) {
                     report(gp->ctx[wret - 1], "SlotCreate", LNN_NG); ret = LNN_NG; goto done;
                 }
             }
             sl = gp->slot[produced % ndev][(produced / ndev) % LNN_SLOTS];
             uj.g = g; uj.sdata = sl ? LINNEAmd_SlotData(sl) : NULL; uj.sprm = sl ? LINNEAmd_SlotParams(sl) : NULL;
+            uj.sstream = NULL; uj.sbitpos = NULL; uj.s16 = NULL;
+            g->seg_first = g->nblk ? g->offs[0] : off; g->seg_bytes = 0;
             t0 = now_s();
+            if (stream_mode && sl && ncomp) {
+                g->seg_bytes = off - g->seg_first;                /* the scan above stopped at `off`: the group's bytes are [seg_first, off) */
+                if (g->seg_bytes > LINNEAmd_SlotStreamCapacity(sl)) { stream_mode = 0; g_last_decode_mode |= 2u; for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]); goto restart; }
+                uj.sstream = LINNEAmd_SlotStream(sl); uj.sbitpos = LINNEAmd_SlotBitPos(sl); uj.seg_first = g->seg_first; uj.seg_bytes = g->seg_bytes;
+                lnn_parallel_for((uint32_t)((g->seg_bytes + 1048575u) >> 20), threads, copy_segment, &uj);
+            }
             lnn_parallel_for(g->nblk, threads, unpack_blocks, &uj);
             t_parse += now_s() - t0;
             for (f = 0; f < g->nblk; f++) {
@@ -675,7 +724,8 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
             if (g->ncomp) {
                 int dret;
                 t0 = now_s();
-                dret = LINNEAmd_SlotDecodeSubmit(sl, g->cn, g->ncomp);
+                g->streamed = (uj.sstream != NULL);
+                dret = g->streamed ? LINNEAmd_SlotDecodeStreamSubmit(sl, g->seg_bytes, g->cn, g->ncomp) : LINNEAmd_SlotDecodeSubmit(sl, g->cn, g->ncomp);
                 t_submit += now_s() - t0;
                 if (dret != LNN_OK) { report(gp->ctx[produced % ndev], "SlotDecodeSubmit", dret); ret = dret; goto done; }
             }
@@ -692,7 +742,26 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
                 dret = LINNEAmd_SlotWait(sl);
                 t_wait += now_s() - t0;
                 if (dret != LNN_OK) { report(gp->ctx[consumed_groups % ndev], "SlotWait", dret); ret = dret; goto done; }
-                uj.g = g; uj.sdata = LINNEAmd_SlotData(sl); uj.sprm = NULL;
+                uj.g = g; uj.sdata = LINNEAmd_SlotData(sl); uj.sprm = NULL; uj.s16 = NULL;
+                if (g->streamed) {      /* did the device's decoder walk every block to the end its size field names? */
+                    const uint64_t *eb = LINNEAmd_SlotEndBits(sl);
+                    int anomaly = 0;
+                    for (f = 0; f < g->nblk && !anomaly; f++) {
+                        uint64_t pay;
+                        if (g->types[f] != LNN_BLOCK_COMPRESS) continue;
+                        pay = (g->offs[f] - g->seg_first + 11u) * 8u;
+                        if (eb[g->cidx[f]] == ~(uint64_t)0 || eb[g->cidx[f]] < pay || 11u + ((eb[g->cidx[f]] - pay + 7u) >> 3) != g->cons[f]) anomaly = 1;
+                    }
+                    if (!anomaly && LINNEAmd_SlotPcm16(sl)) {
+                        if (LINNEAmd_SlotPcm16Valid(sl)) uj.s16 = LINNEAmd_SlotPcm16(sl);
+                        else if (LINNEAmd_SlotFetchPcm32(sl, g->ncomp) != LNN_OK) anomaly = 1;
+                    }
+                    if (anomaly) {      /* not what an encoder writes: the host's decoder defines the result */
+                        stream_mode = 0; g_last_decode_mode |= 2u;
+                        for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]);
+                        goto restart;
+                    }
+                }
                 t0 = now_s();
                 lnn_parallel_for(g->nblk, threads, scatter_blocks, &uj);
                 t_scatter += now_s() - t0;
@@ -701,8 +770,9 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
             if (ret == LNN_OK && progress < hd->num_samples && off < data_size) scanning = 1;
         }
     }
-    if (trace_on()) fprintf(stderr, "liblinne_amd: DecodeWhole %u threads: parse %.1f ms, submit %.1f, wait %.1f, scatter %.1f, total %.1f ms\n",
-            threads, t_parse * 1e3, t_submit * 1e3, t_wait * 1e3, t_scatter * 1e3, (now_s() - t_begin) * 1e3);
+    if (stream_mode && produced) g_last_decode_mode |= 1u;
+    if (trace_on()) fprintf(stderr, "liblinne_amd: DecodeWhole %u threads%s: parse %.1f ms, submit %.1f, wait %.1f, scatter %.1f, total %.1f ms\n",
+            threads, stream_mode ? ", Rice codes decoded on the device" : "", t_parse * 1e3, t_submit * 1e3, t_wait * 1e3, t_scatter * 1e3, (now_s() - t_begin) * 1e3);
 done:
     for (f = 0; f < LNN_MAX_DEVICES; f++) for (i = 0; i < LNN_SLOTS; i++) if (gp->slot[f][i]) (void)LINNEAmd_SlotWait(gp->slot[f][i]);
     for (i = 0; i < ngalloc; i++) dgroup_free(&grp[i]);

@@ -1088,6 +1088,31 @@ extern "C" int LINNEAmd_RiceEmitDevice(struct LINNEAmdContext *ctx, const struct
     return LNN_OK;
 }
 
+/* Rice decoding on the device: see lnn_k_rice.h.  d_stream: the bytes of a group of blocks (4-byte aligned; stream_bytes of it
+ * valid, readable up to the next multiple of 8); d_bitpos[f]: where frame f's first channel's code starts (~0: skip the frame);
+ * d_endbit[f] receives the bit position behind its last channel's code (~0: the stream held something no encoder writes: the host
+ * must decode this group itself).  Enqueues on the context's stream. */
+extern "C" int LINNEAmd_RiceDecodeDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
+        const uint8_t *d_stream, uint64_t stream_bytes, const uint64_t *d_bitpos, const uint32_t *h_num_samples, uint32_t num_frames,
+        int32_t *d_residual, uint64_t *d_endbit)
+{
+    if (!ctx) return LNN_INVALID_ARGUMENT;
+    ctx->err[0] = 0;
+    if (!shape || !d_stream || !d_bitpos || !d_residual || !d_endbit || ((uintptr_t)d_stream & 3u)) { snprintf(ctx->err, sizeof(ctx->err), "RiceDecodeDevice: null or misaligned argument"); return LNN_INVALID_ARGUMENT; }
+    if (num_frames == 0) return LNN_OK;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    int ret = upload_lengths(ctx, shape, h_num_samples, num_frames);
+    if (ret != LNN_OK) return ret;
+    RiceDecodeArgs a; memset(&a, 0, sizeof(a));
+    a.words = (const uint32_t *)d_stream; a.nbytes = stream_bytes; a.bitpos = d_bitpos; a.nsmp = ctx->d_nsmp; a.resid = d_residual; a.endbit = d_endbit;
+    a.F = num_frames; a.C = shape->num_channels; a.S = shape->num_samples_per_block;
+    const int sp_ = span_begin(ctx, 28, ctx->stream);
+    hipLaunchKernelGGL(k_rice_decode, dim3((num_frames + RDEC_THREADS - 1) / RDEC_THREADS), dim3(RDEC_THREADS), 0, ctx->stream, a);
+    span_end(ctx, sp_, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return LNN_OK;
+}
+
 /* ================================================================================================
  * staging slots: pinned host buffers + device buffers for a group of frames.  Submit enqueues H2D (copy-in
  * stream), the kernels (context stream) and D2H (copy-out stream) chained by events and returns at once, so a
@@ -1099,6 +1124,8 @@ struct LINNEAmdSlot {
     int32_t *d_pcm, *d_data, *d_prm; double *d_st; uint8_t *d_plan;
     /* emit mode: the channels' Rice code, packed back to back, instead of the residual */
     uint8_t *h_packed, *d_packed; uint64_t packed_cap; uint32_t *h_offsets, *d_offsets;
+    /* decode, stream mode: the blocks' bytes instead of the residual; PCM optionally as int16 */
+    uint8_t *h_stream, *d_stream; uint64_t stream_cap; uint64_t *h_bitpos, *d_bitpos, *h_endbit, *d_endbit; int16_t *h_out16, *d_out16; uint32_t *d_flag, *h_flag;
     hipEvent_t ev_in, ev_k, ev_done; int pending;
 };
 
@@ -1126,6 +1153,16 @@ extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
     if (s->d_packed) hipFree(s->d_packed);
     if (s->h_offsets) hipHostFree(s->h_offsets);
     if (s->d_offsets) hipFree(s->d_offsets);
+    if (s->h_stream) hipHostFree(s->h_stream);
+    if (s->d_stream) hipFree(s->d_stream);
+    if (s->h_bitpos) hipHostFree(s->h_bitpos);
+    if (s->d_bitpos) hipFree(s->d_bitpos);
+    if (s->h_endbit) hipHostFree(s->h_endbit);
+    if (s->d_endbit) hipFree(s->d_endbit);
+    if (s->h_out16) hipHostFree(s->h_out16);
+    if (s->d_out16) hipFree(s->d_out16);
+    if (s->h_flag) hipHostFree(s->h_flag);
+    if (s->d_flag) hipFree(s->d_flag);
     if (s->d_pcm) hipFree(s->d_pcm);
     if (s->d_data) hipFree(s->d_data);
     if (s->d_prm) hipFree(s->d_prm);
@@ -1152,7 +1189,7 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
     if (hipSetDevice(ctx->device) != hipSuccess || ctx_copy_streams(ctx) != LNN_OK) return NULL;
     LINNEAmdSlot *s = (LINNEAmdSlot *)calloc(1, sizeof(*s));
     if (!s) return NULL;
-    if (!for_encode) flags = 0;
+    if (!for_encode) flags &= (LINNE_AMD_SLOT_STREAM | LINNE_AMD_SLOT_PCM16); else flags &= ~(uint32_t)LINNE_AMD_SLOT_STREAM;
     if (shape->bits_per_sample > 16) flags &= ~(uint32_t)LINNE_AMD_SLOT_PCM16;
     s->ctx = ctx; s->shape = *shape; s->max_frames = max_frames; s->for_encode = for_encode; s->flags = flags;
     const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
@@ -1183,6 +1220,21 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames);
     }
+    if (!for_encode && (flags & LINNE_AMD_SLOT_STREAM)) {
+        s->stream_cap = ((uint64_t)max_frames * (nb / max_frames + 1024u) + 4095u) & ~(uint64_t)4095u;       /* a block is smaller than its int32 residual */
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_stream, s->stream_cap + 16, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_stream, s->stream_cap + 16);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_bitpos, sizeof(uint64_t) * max_frames, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_bitpos, sizeof(uint64_t) * max_frames);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_endbit, sizeof(uint64_t) * max_frames, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_endbit, sizeof(uint64_t) * max_frames);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_flag, sizeof(uint32_t) * 4, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_flag, sizeof(uint32_t) * 4);
+        if (flags & LINNE_AMD_SLOT_PCM16) {
+            if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out16, nb / 2, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_out16, nb / 2);
+        }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_k, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming);
@@ -1191,7 +1243,12 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
 }
 
 extern "C" int32_t *LINNEAmd_SlotPcm(struct LINNEAmdSlot *s) { return (s && !(s->flags & LINNE_AMD_SLOT_PCM16)) ? s->h_pcm : NULL; }
-extern "C" int16_t *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *s) { return (s && (s->flags & LINNE_AMD_SLOT_PCM16)) ? (int16_t *)s->h_pcm : NULL; }
+extern "C" int16_t *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *s) { return (s && (s->flags & LINNE_AMD_SLOT_PCM16)) ? (s->for_encode ? (int16_t *)s->h_pcm : s->h_out16) : NULL; }
+extern "C" uint8_t *LINNEAmd_SlotStream(struct LINNEAmdSlot *s) { return s ? s->h_stream : NULL; }
+extern "C" uint64_t LINNEAmd_SlotStreamCapacity(const struct LINNEAmdSlot *s) { return s ? s->stream_cap : 0; }
+extern "C" uint64_t *LINNEAmd_SlotBitPos(struct LINNEAmdSlot *s) { return s ? s->h_bitpos : NULL; }
+extern "C" const uint64_t *LINNEAmd_SlotEndBits(struct LINNEAmdSlot *s) { return s ? s->h_endbit : NULL; }
+extern "C" int LINNEAmd_SlotPcm16Valid(const struct LINNEAmdSlot *s) { return (s && s->h_out16 && s->h_flag) ? (s->h_flag[0] == 0u) : 0; }
 extern "C" const uint8_t *LINNEAmd_SlotPacked(struct LINNEAmdSlot *s) { return s ? s->h_packed : NULL; }
 extern "C" const uint32_t *LINNEAmd_SlotOffsets(struct LINNEAmdSlot *s) { return s ? s->h_offsets : NULL; }
 extern "C" uint32_t LINNEAmd_SlotFlags(const struct LINNEAmdSlot *s) { return s ? s->flags : 0; }
@@ -1283,5 +1340,52 @@ extern "C" int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *s, const uint32_t 
     HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipEventRecord(s->ev_done, ctx->copy_out));
     s->pending = 1;
+    return LNN_OK;
+}
+
+/* decode slot in stream mode: SlotStream holds the blocks' bytes (stream_bytes of them), SlotBitPos[f] where frame f's Rice code
+ * starts, SlotParams the parameters; H2D, Rice decoding, synthesis, [int16 narrowing], D2H are enqueued; after SlotWait:
+ * SlotEndBits (~0 anywhere: decode this group on the host instead), SlotData or -- if SlotPcm16Valid -- SlotPcm16 */
+extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t stream_bytes, const uint32_t *num_samples, uint32_t num_frames)
+{
+    if (!s || s->for_encode || !s->h_stream) return LNN_INVALID_ARGUMENT;
+    LINNEAmdContext *ctx = s->ctx;
+    if (num_frames == 0 || num_frames > s->max_frames || stream_bytes > s->stream_cap) { snprintf(ctx->err, sizeof(ctx->err), "SlotDecodeStreamSubmit: %u frames / %llu bytes in a slot of %u / %llu", num_frames, (unsigned long long)stream_bytes, s->max_frames, (unsigned long long)s->stream_cap); return LNN_INVALID_ARGUMENT; }
+    int ret = LINNEAmd_SlotWait(s);
+    if (ret != LNN_OK) return ret;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
+    const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames;
+    memset(s->h_stream + stream_bytes, 0, 16);                 /* the reader loads whole 8-byte words */
+    HIPCHK(ctx, hipMemcpyAsync(s->d_stream, s->h_stream, (stream_bytes + 15u) & ~(uint64_t)7u, hipMemcpyHostToDevice, ctx->copy_in));
+    HIPCHK(ctx, hipMemcpyAsync(s->d_bitpos, s->h_bitpos, sizeof(uint64_t) * num_frames, hipMemcpyHostToDevice, ctx->copy_in));
+    HIPCHK(ctx, hipMemcpyAsync(s->d_prm, s->h_prm, pb, hipMemcpyHostToDevice, ctx->copy_in));
+    HIPCHK(ctx, hipEventRecord(s->ev_in, ctx->copy_in));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
+    if ((ret = LINNEAmd_RiceDecodeDevice(ctx, &s->shape, s->d_stream, stream_bytes, s->d_bitpos, num_samples, num_frames, s->d_data, s->d_endbit)) != LNN_OK) return ret;
+    if ((ret = LINNEAmd_DecodeFramesDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_prm)) != LNN_OK) return ret;
+    if (s->d_out16) {
+        HIPCHK(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(uint32_t), ctx->stream));
+        hipLaunchKernelGGL(k_narrow16, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, s->d_out16, CS * num_frames, s->d_flag);
+    }
+    HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
+    HIPCHK(ctx, hipMemcpyAsync(s->h_endbit, s->d_endbit, sizeof(uint64_t) * num_frames, hipMemcpyDeviceToHost, ctx->copy_out));
+    if (s->d_out16) {
+        HIPCHK(ctx, hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->copy_out));
+        HIPCHK(ctx, hipMemcpyAsync(s->h_out16, s->d_out16, nb / 2, hipMemcpyDeviceToHost, ctx->copy_out));
+    } else
+        HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
+    HIPCHK(ctx, hipEventRecord(s->ev_done, ctx->copy_out));
+    s->pending = 1;
+    return LNN_OK;
+}
+
+/* the int32 PCM of a stream-mode decode slot whose int16 copy is not valid (LINNEAmd_SlotPcm16Valid == 0): synchronous */
+extern "C" int LINNEAmd_SlotFetchPcm32(struct LINNEAmdSlot *s, uint32_t num_frames)
+{
+    if (!s || s->for_encode || num_frames > s->max_frames) return LNN_INVALID_ARGUMENT;
+    const uint64_t nb = sizeof(int32_t) * (uint64_t)s->shape.num_channels * s->shape.num_samples_per_block * num_frames;
+    if (hipSetDevice(s->ctx->device) != hipSuccess || hipMemcpy(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost) != hipSuccess) return LNN_NG;
     return LNN_OK;
 }

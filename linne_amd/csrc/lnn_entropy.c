@@ -812,6 +812,16 @@ int lnn_parse_block(const struct LINNEAmdShape *shape, const struct lnn_layers *
         int check_crc, uint32_t max_samples, uint32_t *type_out, uint32_t *n_out, uint32_t *consumed_out,
         int32_t *samples /* [C][S]: residual (COMPRESS) or PCM (RAW/SILENT) */, int32_t *params)
 {
+    return lnn_parse_block_head(shape, ly, data, avail, check_crc, max_samples, type_out, n_out, consumed_out, samples, params, NULL);
+}
+
+/* The same; with rice_bit_out != NULL a COMPRESS block is parsed up to its parameters only: *rice_bit_out = the bit offset (from the
+ * block's first byte) at which the first channel's Rice code starts, `samples` is left alone and *consumed_out is the block's size
+ * field + 6 (what a well-formed block consumes; the device's decoder reports the real figure, LINNEAmd_RiceDecodeDevice). */
+int lnn_parse_block_head(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, const uint8_t *data, uint64_t avail,
+        int check_crc, uint32_t max_samples, uint32_t *type_out, uint32_t *n_out, uint32_t *consumed_out,
+        int32_t *samples, int32_t *params, uint64_t *rice_bit_out)
+{
     const uint32_t C = shape->num_channels, bits = shape->bits_per_sample, S = shape->num_samples_per_block;
     uint32_t bsize, type, n, ch, l, i, s;
     if (avail < 11) return LNN_INSUFFICIENT_DATA;
@@ -859,6 +869,7 @@ int lnn_parse_block(const struct LINNEAmdShape *shape, const struct lnn_layers *
                 for (i = 0; i < ly->size[l]; i++) rec[LINNE_AMD_PRM_COEF + ly->offset[l] + i] = unzz(huff_get(&r));
             }
         }
+        if (rice_bit_out) { *rice_bit_out = 88u + r.consumed; *consumed_out = bsize + 6u; return LNN_OK; }
         for (ch = 0; ch < C; ch++) if (rice_decode(&r, samples + (size_t)ch * S, n) != 0) return LNN_INVALID_FORMAT;
         *consumed_out = 11 + (uint32_t)br_bytes(&r);
     } else return LNN_INVALID_FORMAT;

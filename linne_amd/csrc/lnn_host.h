@@ -30,4 +30,8 @@ int lnn_parse_block(const struct LINNEAmdShape *shape, const struct lnn_layers *
         int check_crc, uint32_t max_samples, uint32_t *type_out, uint32_t *n_out, uint32_t *consumed_out,
         int32_t *samples, int32_t *params);
 
+int lnn_parse_block_head(const struct LINNEAmdShape *shape, const struct lnn_layers *ly, const uint8_t *data, uint64_t avail,
+        int check_crc, uint32_t max_samples, uint32_t *type_out, uint32_t *n_out, uint32_t *consumed_out,
+        int32_t *samples, int32_t *params, uint64_t *rice_bit_out);
+
 #endif

@@ -252,6 +252,119 @@ template <bool LDS> __global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit
     bw.finish();
 }
 
+/* ================================================================================================
+ * Rice DECODING on the device (the decode side of SURVEY 8f-1; linne_coder.c:306-327, bit_stream.h:305-394).  A channel's code
+ * is one serial bit stream and the next channel of a block starts where this one ends, so the unit of parallel work is the
+ * BLOCK: lanes = frames, every lane walks its block's channels in order from the bit position the host found behind the
+ * parameter bits.  The host stage then only scans block headers and decodes the parameters (a few hundred Huffman symbols per
+ * block); the compressed stream itself travels over PCIe (0.76 x 2 bytes per sample here) instead of 4-byte residuals, and the
+ * 67 ms of host Rice decoding of a 60-minute stream become ~4 ms beside the synthesis kernels.
+ * A lane reads its bytes through a 128-bit window refilled 64 bits at a time (two aligned 32-bit loads, zeros past the end of the
+ * data).  Anything a well-formed stream cannot contain -- a partition order above 31, a parameter step of more than 32 digits,
+ * a read past the end of the data -- ends the lane with end_bit = ~0: the host decodes that group itself (lnn_parse_block keeps
+ * the reference's behaviour for damaged streams).  Otherwise end_bit is the bit position behind the last channel's code, from
+ * which the host derives the bytes the block consumed (linne_decoder.c:495-499).
+ * ============================================================================================== */
+struct RiceDecodeArgs {
+    const uint32_t *words; uint64_t nbytes;          /* the stream segment of the group, 4-byte aligned, zero padded to 8 bytes */
+    const uint64_t *bitpos;                          /* [F] bit position of the first channel's code (~0: not a COMPRESS block: skip) */
+    const uint32_t *nsmp;                            /* [F] */
+    int32_t *resid;                                  /* [F][C][S] */
+    uint64_t *endbit;                                /* [F] */
+    uint32_t F, C, S;
+};
+
+/* hi:lo = the next `have` bits of the stream, MSB first; after every operation have > 64, i.e. all of hi is valid.  The stream is
+ * read as aligned big-endian 64-bit words (two 32-bit loads), zeros past the end of the data. */
+struct RiceBR {
+    const uint32_t *words; uint64_t nbits_total, nwords64;
+    uint64_t pos;                                    /* bits consumed, from the segment's start */
+    uint64_t hi, lo, next;                           /* next: index of the 64-bit word to load next */
+    uint32_t have;
+    bool over;
+    __device__ __forceinline__ uint64_t load64(uint64_t i) const {
+        if (i >= nwords64) return 0u;
+        const uint32_t a = words[2 * i], b = words[2 * i + 1];
+        return ((uint64_t)__builtin_bswap32(a) << 32) | (uint64_t)__builtin_bswap32(b);
+    }
+    __device__ __forceinline__ void refill() {
+        while (have <= 64u) {
+            const uint64_t w = load64(next++);
+            if (have == 64u) lo = w;
+            else if (have == 0u) { hi = w; lo = 0u; }
+            else { hi |= w >> have; lo = w << (64u - have); }
+            have += 64u;
+        }
+    }
+    __device__ __forceinline__ void open(const uint32_t *w, uint64_t nbytes, uint64_t bit) {
+        words = w; nbits_total = nbytes * 8u; nwords64 = (nbytes + 7u) >> 3; pos = bit; over = false;
+        const uint32_t sh = (uint32_t)(bit & 63u);
+        next = bit >> 6;
+        const uint64_t first = load64(next++);
+        hi = sh ? (first << sh) : first; lo = 0u; have = 64u - sh;
+        refill();
+    }
+    __device__ __forceinline__ void consume(uint32_t n) {                  /* 1 <= n <= 64 */
+        if (n == 64u) { hi = lo; lo = 0u; } else { hi = (hi << n) | (lo >> (64u - n)); lo <<= n; }
+        have -= n; pos += n;
+        if (pos > nbits_total) over = true;
+        refill();
+    }
+    __device__ __forceinline__ uint32_t get(uint32_t n) {                  /* n <= 32 */
+        if (n == 0u) return 0u;
+        const uint32_t v = (uint32_t)(hi >> (64u - n));
+        consume(n);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t zero_run(bool &bad) {              /* zeros up to the next 1, which is consumed too */
+        uint32_t run = 0;
+        for (;;) {
+            if (hi != 0u) { const uint32_t z = (uint32_t)__clzll((long long)hi); consume(z + 1u); return run + z; }
+            if (pos >= nbits_total) { bad = true; return run; }
+            consume(64u); run += 64u;
+        }
+    }
+};
+
+#define RDEC_THREADS 64
+__global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
+{
+    const uint32_t f = blockIdx.x * RDEC_THREADS + threadIdx.x;
+    if (f >= a.F) return;
+    const uint64_t start = a.bitpos[f];
+    if (start == ~0ull) { a.endbit[f] = 0u; return; }
+    const uint32_t n = a.nsmp[f];
+    RiceBR r; r.open(a.words, a.nbytes, start);
+    bool bad = false;
+    for (uint32_t ch = 0; ch < a.C && !bad; ch++) {
+        int32_t *out = a.resid + ((size_t)f * a.C + ch) * a.S;
+        const uint32_t order = r.get(10);
+        if (order > 10u || (n & ((1u << order) - 1u)) != 0u) { bad = true; break; }     /* no encoder writes that (lnn_entropy.c rice_emit): the host's decoder defines it */
+        const uint32_t ns = n >> order, parts = 1u << order;
+        uint32_t k2 = 0;
+        for (uint32_t part = 0; part < parts && !bad; part++) {
+            if (part == 0) k2 = r.get(5);
+            else {
+                const uint32_t nd = r.zero_run(bad) + 1u;
+                if (bad || nd > 32u) { bad = true; break; }
+                const uint32_t g = (nd == 1u) ? 0u : (uint32_t)((1ull << (nd - 1u)) + r.get(nd - 1u) - 1u);
+                k2 = (uint32_t)((int32_t)k2 + (int32_t)((g >> 1) ^ (0u - (g & 1u))));
+            }
+            k2 &= 31u;
+            const uint32_t k1 = k2 + 1u, k1pow = 1u << (k1 & 31u);
+            int32_t *q = out + (size_t)part * ns;
+            for (uint32_t s = 0; s < ns && !bad; s++) {
+                const uint32_t quot = r.zero_run(bad);
+                const uint32_t v = (quot == 0u) ? r.get(k1) : (r.get(k2) + k1pow + ((quot - 1u) << k2));
+                q[s] = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
+            }
+            if (r.over) bad = true;
+        }
+    }
+    a.endbit[f] = (bad || r.over) ? ~0ull : r.pos;
+}
+
+
 /* the used part of the packed buffer -> pinned host memory (the device knows the size, the host does not yet) */
 __global__ __launch_bounds__(256) void k_copy_out(const uint4 *src, uint4 *dst, const uint32_t *total_bytes)
 {

@@ -649,3 +649,71 @@ def test_network_trainer(product, oracle, reference, nch, bits, block, preset, t
 def test_network_trainer_on_degenerate_signals(product, reference, kind):
     x = waveform(kind, 1, 1024, 16, seed=1)
     assert product.encode_whole(x, 16, 44100, 512, 4, False, learning=1) == reference.encode_whole(x, 16, 44100, 512, 4, False, learning=1)
+
+
+def _blocks(stream):
+    off = 30
+    while off + 11 <= len(stream):
+        size = int.from_bytes(stream[off + 2:off + 6], "big") + 6
+        yield off, size, stream[off + 8]
+        off += size
+
+
+@pytest.mark.parametrize("nch,bits,block,preset,total,group", [(2, 16, 4096, 7, 11 * 4096 + 1500, "3"), (1, 16, 2048, 4, 9 * 2048 + 777, "2"), (3, 24, 2048, 5, 6 * 2048 + 99, "4"),
+                                                               (8, 8, 1024, 2, 5 * 1024 + 1000, "2"), (2, 16, 1023, 7, 5 * 1023 + 400, "5"), (2, 16, 10240, 7, 40 * 10240 + 9280, None)])
+def test_decode_whole_with_rice_decoding_on_the_device(product, monkeypatch, nch, bits, block, preset, total, group):
+    """LINNEDecoder_DecodeWhole hands the blocks' bytes to the device, whose k_rice_decode reads the partitioned recursive Rice codes
+    (linne_coder.c:304-345) -- LINNE_AMD_DECODE_STREAM=1 -- or decodes them on the host threads (0, the default).  Same PCM either
+    way (the encoder's input), SILENT and RAW blocks in between, a ragged tail, int16 (<= 16 bits) and int32 PCM on the way back"""
+    if group:
+        monkeypatch.setenv("LINNE_AMD_GROUP", group)
+    parts = [music(nch, total - 3 * block, bits, seed=61 + nch), np.zeros((nch, block), dtype=np.int32), waveform("white_noise", nch, block, bits, seed=8)]
+    parts.append(music(nch, total - sum(p.shape[1] for p in parts), bits, seed=62))
+    x = np.concatenate(parts, axis=1)
+    stream = product.encode_whole(x, bits, 44100, block, preset, nch >= 2)
+    for mode in ("1", "0"):
+        monkeypatch.setenv("LINNE_AMD_DECODE_STREAM", mode)
+        ret, dec = product.decode_whole(stream)
+        assert ret == 0 and np.array_equal(dec, x)
+        assert product.last_decode_whole_mode() == int(mode)
+    # a stream cut inside a block: the error is reported, the blocks before it are delivered
+    monkeypatch.setenv("LINNE_AMD_DECODE_STREAM", "1")
+    ret, dec = product.decode_whole(stream[:len(stream) * 2 // 3])
+    whole = 0
+    for off, size, _ in _blocks(stream):
+        if off + size > len(stream) * 2 // 3:
+            break
+        whole += 1
+    assert ret == 4 and np.array_equal(dec[:, :whole * block], x[:, :whole * block])
+
+
+def test_decode_whole_meets_blocks_no_encoder_writes(product, oracle, monkeypatch):
+    """Blocks whose CRC is right but whose payload is not an encoder's (here: damaged, then the CRC recomputed): the device's Rice
+    decoder either reads them as the host's does or reports them (orders above 10, codes running past the block, a block that
+    ends before its size field says), and the call starts over on the host -- the result is the host decoder's in every case"""
+    import ctypes as C
+    monkeypatch.setenv("LINNE_AMD_GROUP", "3")
+    block = 2048
+    x = music(2, 12 * block + 500, 16, seed=77)
+    good = product.encode_whole(x, 16, 44100, block, 7, True)
+    rng = np.random.default_rng(5)
+    restarted = same = 0
+    for trial in range(24):
+        bad = bytearray(good)
+        blocks = [b for b in _blocks(good) if b[2] == 0]
+        for off, size, _ in [blocks[i] for i in rng.choice(len(blocks), size=2, replace=False)]:
+            lo = off + 11 + (0 if trial % 3 == 0 else size // 3)                # now and then inside the parameters
+            for pos in rng.integers(lo, off + size, size=int(rng.integers(1, 4))):
+                bad[pos] ^= 1 << int(rng.integers(0, 8))
+            body = np.frombuffer(bytes(bad[off + 8:off + size]), dtype=np.uint8)
+            bad[off + 6:off + 8] = int(oracle.L.oracle_crc16(body.ctypes.data, len(body))).to_bytes(2, "big")
+        bad = bytes(bad)
+        monkeypatch.setenv("LINNE_AMD_DECODE_STREAM", "0")
+        want = product.decode_whole(bad)
+        monkeypatch.setenv("LINNE_AMD_DECODE_STREAM", "1")
+        got = product.decode_whole(bad)
+        mode = product.last_decode_whole_mode()
+        assert got[0] == want[0] and np.array_equal(got[1], want[1]), f"trial {trial}"
+        restarted += (mode & 2) != 0
+        same += (mode == 1)
+    assert restarted > 0 and same > 0
