@@ -16,6 +16,7 @@ struct RicePlanArgs {
     double steps[32];
 };
 __device__ __forceinline__ uint32_t rp_zz(int32_t v) { const uint32_t d = (uint32_t)v << 1; return (v < 0) ? ((0u - d) - 1u) : d; }
+__device__ __forceinline__ uint32_t rp_wave_sum(uint32_t v) { for (int m = 32; m >= 1; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64); return v; }    /* every lane gets the wave's total */
 __device__ __forceinline__ uint32_t rp_gamma_len(uint32_t u) { return u ? (2u * (32u - (uint32_t)__clz((int)(u + 1u))) - 1u) : 1u; }   /* 2*ceil_log2(u+2)-1 */
 
 /* LDS: a thread walks the nsf consecutive samples of its finest partition; straight from global memory that is a 4 * nsf byte
@@ -65,28 +66,44 @@ template <bool LDS> __global__ __launch_bounds__(RICE_THREADS) void k_rice_plan(
         kk[e] = (uint8_t)(k & 31u);
     }
     __syncthreads();
-    /* per entry: the samples' fixed part and the parameter's own code */
-    for (uint32_t e = tid; e < nent; e += RICE_THREADS) {
-        const uint32_t o = 31u - (uint32_t)__clz((int)(e + 1u)), p = e - ((1u << o) - 1u);
-        const uint32_t k = kk[e];
-        uint32_t bits = (n >> o) * (k + 2u);
-        bits += p ? rp_gamma_len(rp_zz((int32_t)k - (int32_t)kk[e - 1])) : 5u;
-        atomicAdd(&tot[o], bits);
+    /* The totals per order are sums of uint32 with wrap-around: their order is free, so a wave adds up its lanes' shares across
+     * the lanes and issues ONE LDS atomic per order (64 lanes adding to the same word one by one was most of this kernel's time).
+     * Per entry: the samples' fixed part and the parameter's own code.  Entry e = e1 - 1 belongs to order floor(log2 e1): the 64
+     * entries of an aligned group of e1 >= 64 share their order. */
+    for (uint32_t base = 0; base <= nent; base += RICE_THREADS) {       /* (every lane takes every turn: the wave sum needs them all) */
+        const uint32_t e1 = base + tid;
+        uint32_t bits = 0, o = 31u - (uint32_t)__clz((int)(e1 | 1u));
+        if (e1 != 0u && e1 <= nent) {
+            const uint32_t e = e1 - 1u;
+            const uint32_t p = e - ((1u << o) - 1u), k = kk[e];
+            bits = (n >> o) * (k + 2u) + (p ? rp_gamma_len(rp_zz((int32_t)k - (int32_t)kk[e - 1])) : 5u);
+        }
+        if ((e1 & ~63u) == 0u) { if (e1 != 0u && e1 <= nent) atomicAdd(&tot[o], bits); }      /* (wave-uniform branch: e1 - lane is a multiple of 64) */
+        else {
+            const uint32_t s = rp_wave_sum(bits);
+            if ((tid & 63u) == 0u) atomicAdd(&tot[o], s);
+        }
     }
     /* per finest partition: the excess of its samples under the parameter of each order's enclosing partition */
-    for (uint32_t p = tid; p < parts; p += RICE_THREADS) {
-        const int32_t *q = x + (size_t)p * nsf;
-        const uint32_t *zq = zbuf + (size_t)p * (nsf + 1u);
-        uint32_t kc[11], acc[11];
+    {
+        uint32_t acc[11];
 #pragma unroll
-        for (uint32_t o = 0; o < 11; o++) { acc[o] = 0; kc[o] = (o <= max_order) ? kk[((1u << o) - 1u) + (p >> (max_order - o))] : 0u; }
-        for (uint32_t j = 0; j < nsf; j++) {
-            const uint32_t v = LDS ? zq[j] : rp_zz(q[j]);
+        for (uint32_t o = 0; o < 11; o++) acc[o] = 0;
+        for (uint32_t p = tid; p < parts; p += RICE_THREADS) {
+            const int32_t *q = x + (size_t)p * nsf;
+            const uint32_t *zq = zbuf + (size_t)p * (nsf + 1u);
+            uint32_t kc[11];
 #pragma unroll
-            for (uint32_t o = 0; o < 11; o++) { const uint32_t k1pow = 1u << ((kc[o] + 1u) & 31u); acc[o] += ((v > k1pow) ? (v - k1pow) : 0u) >> kc[o]; }
+            for (uint32_t o = 0; o < 11; o++) kc[o] = (o <= max_order) ? kk[((1u << o) - 1u) + (p >> (max_order - o))] : 0u;
+            for (uint32_t j = 0; j < nsf; j++) {
+                const uint32_t v = LDS ? zq[j] : rp_zz(q[j]);
+#pragma unroll
+                for (uint32_t o = 0; o < 11; o++) { const uint32_t k1pow = 1u << ((kc[o] + 1u) & 31u); acc[o] += ((v > k1pow) ? (v - k1pow) : 0u) >> kc[o]; }
+            }
         }
 #pragma unroll
-        for (uint32_t o = 0; o < 11; o++) if (o <= max_order) atomicAdd(&tot[o], acc[o]);
+        for (uint32_t o = 0; o < 11; o++)
+            if (o <= max_order) { const uint32_t s = rp_wave_sum(acc[o]); if ((tid & 63u) == 0u) atomicAdd(&tot[o], s); }
     }
     __syncthreads();
     if (tid == 0) {
