@@ -552,8 +552,8 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     if (af_iters)       /* the auxiliary-function pass: per channel-frame the normal matrices, reciprocals, vectors, problem lists */
         b += C * (sizeof(double) * ((uint64_t)hs->maxP * hs->maxP + S + 3 * LNN_MAXP + 3 * LNN_MAXU + 2) + sizeof(uint32_t) * (2 * LNN_MAXU + 1)) + 8192;
     if (af_iters || learning) b += C * (sizeof(uint32_t) + 2 * sizeof(double)) + 1024;        /* the winners of the search passes */
-    if (learning)       /* the trainer: two layer inputs and two gradient-signal buffers, gradients and momenta per channel-frame */
-        b += C * (sizeof(double) * (4 * S + 2 * LNN_MAXL * LNN_MAXP + 2) + sizeof(uint32_t)) + 4096;
+    if (learning)       /* the trainer: two layer inputs and a gradient-signal buffer per layer (TR_NBUF), gradients and momenta per channel-frame */
+        b += C * (sizeof(double) * ((2 + LNN_MAXL) * S + 2 * LNN_MAXL * LNN_MAXP + 2) + sizeof(uint32_t)) + 4096;
     return b + 4096;
 }
 
@@ -694,7 +694,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TrainArgs tr; memset(&tr, 0, sizeof(tr));
         if (ctx->af_iters || ctx->learning) { TAKE(af_best, uint32_t, CF); TAKE(af_loss, double, CF); TAKE(af_reg, double, CF); }
         if (ctx->learning) {
-            TAKE(tr.buf, double, CF * 4 * S); TAKE(tr.dparams, double, CF * LNN_MAXL * LNN_MAXP); TAKE(tr.momentum, double, CF * LNN_MAXL * LNN_MAXP);
+            TAKE(tr.buf, double, CF * TR_NBUF * S); TAKE(tr.dparams, double, CF * LNN_MAXL * LNN_MAXP); TAKE(tr.momentum, double, CF * LNN_MAXL * LNN_MAXP);
             TAKE(tr.loss, double, CF); TAKE(tr.prev, double, CF); TAKE(tr.active, uint32_t, CF); TAKE(tr.nactive, uint32_t, 64);
         }
         if (ctx->af_iters) {      /* the final pass works on CF jobs */
@@ -723,11 +723,12 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 HIPCHK(ctx, hipHostMalloc((void **)&ctx->af_h, sizeof(double) * (size_t)nprob, hipHostMallocDefault));
                 ctx->af_h_cap = nprob;
             }
-            const uint32_t M = P * (P + 1u) / 2u + P;
+            uint32_t mblocks = 0;                                                      /* k_af_matrix: blocks per job, whatever unit count it chose */
+            for (uint32_t uu = 1; uu <= P; uu <<= 1) { const uint32_t b_ = uu * afm_blocks_per_unit(P / uu); if (b_ > mblocks) mblocks = b_; }
             for (uint32_t it = 0; it < iters; it++) {
                 hipLaunchKernelGGL(k_af_resid, dim3((uint32_t)Jq, (S + AFR_THREADS * 4 - 1) / (AFR_THREADS * 4)), dim3(AFR_THREADS), 0, st, q, l, cur);
-                hipLaunchKernelGGL(k_af_obj, dim3((nprob + 63) / 64), dim3(64), 0, st, q, l, cur);
-                hipLaunchKernelGGL(k_af_matrix, dim3((uint32_t)Jq, (M + AFM_THREADS - 1) / AFM_THREADS), dim3(AFM_THREADS), 0, st, q, l, cur);
+                hipLaunchKernelGGL(k_af_obj, dim3(nprob), dim3(64), 0, st, q, l, cur);
+                hipLaunchKernelGGL(k_af_matrix, dim3((uint32_t)Jq, mblocks), dim3(AFM_THREADS), 0, st, q, l, cur);
                 for (uint32_t i = 0; i < P; i++) {
                     hipLaunchKernelGGL(k_af_pivot, dim3((nprob + 63) / 64), dim3(64), 0, st, q, l, i);
                     HIPCHK(ctx, hipMemcpyAsync(ctx->af_h, q.af_pivot, sizeof(double) * (size_t)nprob, hipMemcpyDeviceToHost, st));
@@ -833,19 +834,15 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
          * step how many channel-frames go on */
         auto run_train = [&](const Plan &q, const uint32_t *best) -> int {
             tr.p = q; tr.best = best; tr.CF = (uint32_t)CF;
-            const uint32_t tiles = (S + TR_THREADS * 4 - 1) / (TR_THREADS * 4);
+            const uint32_t tiles = (S + TR_TILE - 1) / TR_TILE;
             const int sp_ = span_begin(ctx, 27, st);
             hipLaunchKernelGGL(k_tr_init, dim3(((uint32_t)CF + 255) / 256), dim3(256), 0, st, tr);
             for (uint32_t it = 0; it < 2000u; it++) {                      /* LINNE_TRAINING_PARAMETER_MAX_NUM_ITRATION, linne_internal.h:29 */
                 HIPCHK(ctx, hipMemsetAsync(tr.nactive, 0, sizeof(uint32_t), st));
                 for (uint32_t l = 0; l < hs.L; l++) hipLaunchKernelGGL(k_tr_forward, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr, l);
-                hipLaunchKernelGGL(k_tr_loss, dim3(((uint32_t)CF + 63) / 64), dim3(64), 0, st, tr);
-                hipLaunchKernelGGL(k_tr_l1back, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr);
-                uint32_t g = TR_GA;
-                for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
-                    hipLaunchKernelGGL(k_tr_gradp, dim3((uint32_t)CF, (hs.P[l] + 63) / 64), dim3(64), 0, st, tr, (uint32_t)l, g);
-                    if (l > 0) { const uint32_t d = (g == TR_GA) ? TR_GB : TR_GA; hipLaunchKernelGGL(k_tr_back, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr, (uint32_t)l, g, d); g = d; }
-                }
+                hipLaunchKernelGGL(k_tr_loss, dim3((uint32_t)CF), dim3(64), 0, st, tr);                                   /* the loss and, in place, its gradient */
+                for (uint32_t l = hs.L - 1; l >= 1; l--) hipLaunchKernelGGL(k_tr_back, dim3((uint32_t)CF, tiles), dim3(TR_THREADS), 0, st, tr, l);
+                hipLaunchKernelGGL(k_tr_gradp, dim3((uint32_t)CF, hs.L), dim3(128), 0, st, tr);
                 hipLaunchKernelGGL(k_tr_update, dim3((uint32_t)CF), dim3(128), 0, st, tr, (double)0.8f, (double)0.1f, 1.0e-7);     /* linne_network.c:829, linne_internal.h:31-33 */
                 uint32_t left = 0;
                 HIPCHK(ctx, hipMemcpyAsync(&left, tr.nactive, sizeof(uint32_t), hipMemcpyDeviceToHost, st));

@@ -86,10 +86,12 @@ __global__ __launch_bounds__(AFR_THREADS) void k_af_resid(Plan p, uint32_t layer
     }
 }
 
-/* the objective of every live problem: one ordered chain (lpc.c:486, :503) */
-__global__ void k_af_obj(Plan p, uint32_t layer, uint32_t cur)
+/* the objective of every live problem: one ordered chain (lpc.c:486, :503).  A wave per problem: 256 magnitudes at a time go to
+ * LDS with coalesced loads, and the chain adds them up from there (every lane runs the same chain). */
+__global__ __launch_bounds__(64) void k_af_obj(Plan p, uint32_t layer, uint32_t cur)
 {
-    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ __attribute__((aligned(16))) double mag[256];
+    const uint32_t k = blockIdx.x, lane = threadIdx.x;
     if (k >= *p.af_nprob) return;
     const uint32_t job = p.af_prob[k] / LNN_MAXU, un = p.af_prob[k] % LNN_MAXU;
     if (p.af_state[(size_t)job * LNN_MAXU + un] != 0u) return;
@@ -97,37 +99,67 @@ __global__ void k_af_obj(Plan p, uint32_t layer, uint32_t cur)
     const uint32_t u = p.lunits[(size_t)job * LNN_MAXL + layer], np = p.P[layer] / u, n = c.na / u;
     const double *absr = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + (size_t)un * n;
     double obj = 0.0;
-    for (uint32_t s = np; s < n; s++) obj += absr[s];
-    p.af_obj[(size_t)job * LNN_MAXU + un] = obj / (double)(n - np);
+    for (uint32_t s0 = np; s0 < n; s0 += 256u) {
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; r++) { const uint32_t s = s0 + r * 64u + lane; mag[r * 64u + lane] = (s < n) ? absr[s] : 0.0; }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cnt = (n - s0 < 256u) ? (n - s0) : 256u;
+        if (cnt == 256u) {
+#pragma unroll 8
+            for (uint32_t q = 0; q < 256u; q += 2u) { const lnn_d2 v = *(const lnn_d2 *)(mag + q); obj += v.x; obj += v.y; }
+        } else for (uint32_t q = 0; q < cnt; q++) obj += mag[q];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) p.af_obj[(size_t)job * LNN_MAXU + un] = obj / (double)(n - np);
 }
 
 #define AFM_THREADS 256
-/* r_mat (upper triangle) and r_vec of every live problem: grid = (jobs, entries / 256); entry e of a job: unit e / M, M = np
- * (np + 1) / 2 + np; the first np entries of a unit are r_vec, the others the pairs (i, j >= i) in row order */
+#define AFM_T 1024                      /* chain steps per staged tile */
+/* blocks per job: a block works on ONE unit (its samples are staged in LDS for all its threads), 256 entries of it */
+__host__ __device__ inline uint32_t afm_entries(uint32_t np) { return np * (np + 1u) / 2u + np; }
+__host__ __device__ inline uint32_t afm_blocks_per_unit(uint32_t np) { return (afm_entries(np) + AFM_THREADS - 1u) / AFM_THREADS; }
+/* r_mat (upper triangle) and r_vec of every live problem: grid = (jobs, max over unit counts of units x blocks per unit); entry r
+ * of a unit: the first np entries are r_vec, the others the pairs (i, j >= i) in row order.  The unit's samples and reciprocals
+ * are staged in LDS AFM_T steps at a time (coalesced loads); a wave's lanes read x[s-i-1] at one or two addresses (same row) and
+ * x[s-j-1] at consecutive ones. */
 __global__ __launch_bounds__(AFM_THREADS) void k_af_matrix(Plan p, uint32_t layer, uint32_t cur)
 {
-    const uint32_t job = blockIdx.x, e = blockIdx.y * AFM_THREADS + threadIdx.x;
+    __shared__ double xs[AFM_T + LNN_MAXP];      /* xs[k] = x[base + s0 - np + k] */
+    __shared__ double iv[AFM_T];                 /* iv[k] = inv[s0 + k] */
+    const uint32_t job = blockIdx.x, tid = threadIdx.x;
     const DevClass &c = job_class(p, job);
     const uint32_t P = p.P[layer], u = p.lunits[(size_t)job * LNN_MAXL + layer], np = P / u, n = c.na / u;
-    const uint32_t M = np * (np + 1u) / 2u + np;
-    if (e >= u * M) return;
-    const uint32_t un = e / M, r = e - un * M;
-    if (p.af_state[(size_t)job * LNN_MAXU + un] != 0u) return;
+    const uint32_t M = afm_entries(np), bpu = afm_blocks_per_unit(np);
+    const uint32_t un = blockIdx.y / bpu, r = (blockIdx.y - un * bpu) * AFM_THREADS + tid;
+    if (un >= u || p.af_state[(size_t)job * LNN_MAXU + un] != 0u) return;
     const double *inv = p.af_inv + (size_t)job * p.S + (size_t)un * n;
     const uint32_t base = un * n;
-    if (r < np) {                                            /* r_vec[i] -= (x[s] * x[s-i-1]) * inv */
-        const uint32_t i = r;
-        double acc = 0.0;
-        for (uint32_t s = np; s < n; s++) acc -= af_x(p, layer, cur, job, base + s) * af_x(p, layer, cur, job, base + s - i - 1) * inv[s];
-        p.af_rv[(size_t)job * LNN_MAXP + un * np + i] = acc;
-    } else {                                                 /* r_mat[i][j] += (x[s-i-1] * x[s-j-1]) * inv */
-        uint32_t q = r - np, i = 0;
+    const bool valid = r < M, vec = r < np;
+    uint32_t i = r, j = 0;
+    if (valid && !vec) {
+        uint32_t q = r - np; i = 0;
         while (q >= np - i) { q -= np - i; i++; }
-        const uint32_t j = i + q;
-        double acc = 0.0;
-        for (uint32_t s = np; s < n; s++) acc += af_x(p, layer, cur, job, base + s - i - 1) * af_x(p, layer, cur, job, base + s - j - 1) * inv[s];
-        p.af_R[(size_t)job * LNN_MAXP * LNN_MAXP + (size_t)un * np * np + (size_t)i * np + j] = acc;
+        j = i + q;
     }
+    /* r_vec[i] -= (x[s] * x[s-i-1]) * inv;   r_mat[i][j] += (x[s-i-1] * x[s-j-1]) * inv */
+    const double *xa = xs + (vec ? np : (np - i - 1u)), *xb = xs + (vec ? (np - i - 1u) : (np - j - 1u));
+    double acc = 0.0;
+    for (uint32_t s0 = np; s0 < n; s0 += AFM_T) {
+        __syncthreads();
+        for (uint32_t k = tid; k < AFM_T + np; k += AFM_THREADS) { const uint32_t pos = s0 - np + k; xs[k] = (pos < n) ? af_x(p, layer, cur, job, base + pos) : 0.0; }
+        for (uint32_t k = tid; k < AFM_T; k += AFM_THREADS) iv[k] = (s0 + k < n) ? inv[s0 + k] : 0.0;
+        __syncthreads();
+        const uint32_t cnt = (n - s0 < AFM_T) ? (n - s0) : AFM_T;
+        if (!valid) continue;
+        if (vec) { for (uint32_t k = 0; k < cnt; k++) acc -= xa[k] * xb[k] * iv[k]; }
+        else if (cnt == AFM_T) {
+#pragma unroll 8
+            for (uint32_t k = 0; k < AFM_T; k++) acc += xa[k] * xb[k] * iv[k];
+        } else for (uint32_t k = 0; k < cnt; k++) acc += xa[k] * xb[k] * iv[k];
+    }
+    if (!valid) return;
+    if (vec) p.af_rv[(size_t)job * LNN_MAXP + un * np + i] = acc;
+    else p.af_R[(size_t)job * LNN_MAXP * LNN_MAXP + (size_t)un * np * np + (size_t)i * np + j] = acc;
 }
 
 /* Cholesky step i, first half: the pivot sum of every live problem of order > i (lpc.c:416-420) */
