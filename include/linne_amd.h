@@ -275,7 +275,7 @@ int LINNEAmd_PackFramesPlanned(const struct LINNEAmdShape *shape, const int32_t 
         uint32_t num_threads);
 
 /* How the calling thread's last LINNEDecoder_DecodeWhole ran.  Bit 0: it finished with the device decoding the Rice codes
- * (LINNEAmd_SlotDecodeStreamSubmit; LINNE_AMD_DECODE_STREAM=1 asks for it, CRC-checked streams only).  Bit 1: it had
+ * (LINNEAmd_SlotDecodeStreamSubmit; the default for CRC-checked streams, LINNE_AMD_DECODE_STREAM=0 turns it off).  Bit 1: it had
  * started that way, met a block no encoder writes (or 16-bit PCM out of range) and went over the stream again with the host's Rice
  * decoder, which is the reference's decoder restated (linne_coder.c:304-345). */
 uint32_t LINNEAmd_LastDecodeWholeMode(void);

@@ -650,20 +650,19 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     struct dgroup grp[LNN_MAX_DEVICES * LNN_SLOTS];
     struct unpack_job uj;
     struct lnn_gpus *gp = &decoder->gpus;
-    uint32_t group, f, produced = 0, consumed_groups = 0, progress = 0, i, ngalloc = 0, ndev = 1, window = LNN_SLOTS;
+    uint32_t group, f, produced = 0, consumed_groups = 0, progress = 0, i, ngalloc = 0, ndev = 1, window = LNN_SLOTS, nslots = LNN_SLOTS;
     const uint32_t threads = default_threads();
     uint64_t off;
     double t_begin = now_s(), t_parse = 0, t_submit = 0, t_wait = 0, t_scatter = 0, t0;
     int ret = LNN_OK, scanning = 1;
-    /* stream mode (LINNE_AMD_DECODE_STREAM=1; off by default): the device decodes the Rice codes (LINNEAmd_SlotDecodeStreamSubmit).
+    /* stream mode (the default; LINNE_AMD_DECODE_STREAM=0 turns it off): the device decodes the Rice codes
+     * (LINNEAmd_SlotDecodeStreamSubmit), the host threads only scan the block headers, check the CRCs and decode the parameters.
      * Only for streams whose CRCs are checked: a block that passes is what an encoder wrote.  Should the device still meet
      * something no encoder writes, or PCM beyond the 16-bit range, the whole call starts over with the host's Rice decoder
-     * (stream_mode = 0).  Off by default because it is the slower way on one GPU with 16 host threads: k_rice_decode is one lane
-     * per block (the second channel's code starts where the first one's ends), 21 ms per group of 3 100 blocks against 13 ms of
-     * host parsing (profiles/r02_decode_stream.txt); it takes 2/3 of the decoder's work off the host, which is what counts when
-     * several GPUs share those threads. */
+     * (stream_mode = 0), which restates the reference's.  60-minute stream, one GPU, 16 host threads: 62 ms against 94 with the
+     * host's Rice decoder (profiles/r02_decode_stream.txt). */
     int stream_mode;
-    { const char *e_ = getenv("LINNE_AMD_DECODE_STREAM"); stream_mode = (e_ ? atoi(e_) != 0 : 0); }
+    { const char *e_ = getenv("LINNE_AMD_DECODE_STREAM"); stream_mode = (e_ ? atoi(e_) != 0 : 1); }
     if (decoder == NULL || data == NULL || buffer == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if ((r = LINNEDecoder_DecodeHeader(data, data_size, &h)) != LINNE_APIRESULT_OK) return r;
     if ((r = LINNEDecoder_SetHeader(decoder, &h)) != LINNE_APIRESULT_OK) return r;
@@ -679,6 +678,22 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
         group = default_group((F + ndev - 1) / ndev, &decoder->shape, &decoder->layers, 0); if (group > F) group = F ? F : 1;
     }
     if (!decoder->check_crc) stream_mode = 0;
+    if (stream_mode) {
+        /* The device's Rice decoder and the synthesis are serial per block / per channel: a launch takes as long for 3 000 blocks as
+         * for 30 000 (9 + 11 ms), so the stream goes in FEW groups -- two per device, the second one's host parsing and Rice
+         * decoding beside the first one's synthesis (LINNE_AMD_DECODE_GROUPS) */
+        const char *eg = getenv("LINNE_AMD_DECODE_GROUPS");
+        const uint32_t S_ = decoder->shape.num_samples_per_block, F_ = (uint32_t)(((uint64_t)hd->num_samples + S_ - 1) / S_);
+        const uint32_t ng = (eg && atoi(eg) > 0) ? (uint32_t)atoi(eg) : 2u;
+        const uint64_t cap = (1ull << 30) / ((uint64_t)decoder->shape.num_channels * S_ * sizeof(int32_t)) + 1;
+        uint32_t g_ = (F_ + ng * ndev - 1) / (ng * ndev);
+        if (g_ > cap) g_ = (uint32_t)cap;
+        if (g_ > group && !getenv("LINNE_AMD_GROUP")) group = g_;
+        nslots = (((F_ + group - 1) / group) + ndev - 1) / ndev;          /* slots per device: as many as it will see groups */
+        if (nslots < 1) nslots = 1;
+        if (nslots > LNN_SLOTS) nslots = LNN_SLOTS;
+        window = ndev * nslots;
+    }
     g_last_decode_mode = 0;
     for (ngalloc = 0; ngalloc < window; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
 restart:
@@ -707,11 +722,11 @@ restart:
             if (ncomp) {
                 int wret;
                 if (decoder_device(decoder, 1) != LINNE_APIRESULT_OK) { ret = LNN_NG; goto done; }
-                if ((wret = want_slots(gp, &decoder->shape, group, LNN_SLOTS, stream_mode ? 2 : 0)) != 0) {
+                if ((wret = want_slots(gp, &decoder->shape, group, nslots, stream_mode ? 2 : 0)) != 0) {
                     report(gp->ctx[wret - 1], "SlotCreate", LNN_NG); ret = LNN_NG; goto done;
                 }
             }
-            sl = gp->slot[produced % ndev][(produced / ndev) % LNN_SLOTS];
+            sl = gp->slot[produced % ndev][(produced / ndev) % nslots];
             uj.g = g; uj.sdata = sl ? LINNEAmd_SlotData(sl) : NULL; uj.sprm = sl ? LINNEAmd_SlotParams(sl) : NULL;
             uj.sstream = NULL; uj.sbitpos = NULL; uj.s16 = NULL;
             g->seg_first = g->nblk ? g->offs[0] : off; g->seg_bytes = 0;
@@ -754,7 +769,7 @@ restart:
         scanning = 0;
         if (consumed_groups < produced) {
             struct dgroup *g = &grp[consumed_groups % window];
-            struct LINNEAmdSlot *sl = gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % LNN_SLOTS];
+            struct LINNEAmdSlot *sl = gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % nslots];
             if (g->ncomp) {
                 int dret;
                 t0 = now_s();
@@ -772,8 +787,9 @@ restart:
                         if (eb[g->cidx[f]] == ~(uint64_t)0 || eb[g->cidx[f]] < pay || 11u + ((eb[g->cidx[f]] - pay + 7u) >> 3) != g->cons[f]) anomaly = 1;
                     }
                     if (!anomaly && LINNEAmd_SlotPcm16(sl)) {
-                        if (LINNEAmd_SlotPcm16Valid(sl)) uj.s16 = LINNEAmd_SlotPcm16(sl);
+                        if (LINNEAmd_SlotPcm16Valid(sl) && !getenv("LINNE_AMD_DEBUG_NO_PCM16")) uj.s16 = LINNEAmd_SlotPcm16(sl);      /* (the knob: tests take the int32 way) */
                         else if (LINNEAmd_SlotFetchPcm32(sl, g->ncomp) != LNN_OK) anomaly = 1;
+                        else uj.sdata = LINNEAmd_SlotData(sl);             /* (allocated by the fetch) */
                     }
                     if (anomaly) {      /* not what an encoder writes: the host's decoder defines the result */
                         stream_mode = 0; g_last_decode_mode |= 2u;

@@ -1123,6 +1123,7 @@ struct LINNEAmdSlot {
     uint8_t *h_packed, *d_packed; uint64_t packed_cap; uint32_t *h_offsets, *d_offsets;
     /* decode, stream mode: the blocks' bytes instead of the residual; PCM optionally as int16 */
     uint8_t *h_stream, *d_stream; uint64_t stream_cap; uint64_t *h_bitpos, *d_bitpos, *h_endbit, *d_endbit; int16_t *h_out16, *d_out16; uint32_t *d_flag, *h_flag;
+    hipStream_t in_stream;      /* stream mode: this slot's own copy-in stream (H2D + k_rice_decode), so that the slots' Rice decoders -- a few dozen waves each -- run side by side */
     hipEvent_t ev_in, ev_k, ev_done; int pending;
 };
 
@@ -1140,6 +1141,7 @@ extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
     if (!s) return;
     hipSetDevice(s->ctx->device);
     if (s->pending) hipEventSynchronize(s->ev_done);
+    if (s->in_stream) { hipStreamSynchronize(s->in_stream); hipStreamDestroy(s->in_stream); }
     if (s->h_pcm) hipHostFree(s->h_pcm);
     if (s->h_data) hipHostFree(s->h_data);
     if (s->h_prm) hipHostFree(s->h_prm);
@@ -1194,7 +1196,10 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
                    sb = sizeof(double) * LINNE_AMD_STAT_WORDS * (uint64_t)shape->num_channels * max_frames;
     hipError_t e = hipSuccess;
     const bool emit = (flags & LINNE_AMD_SLOT_EMIT) != 0, pcm16 = (flags & LINNE_AMD_SLOT_PCM16) != 0;
-    if (e == hipSuccess && !emit) e = hipHostMalloc((void **)&s->h_data, nb, hipHostMallocDefault);       /* emit mode: the residual stays on the device */
+    /* emit mode: the residual stays on the device; stream-mode decode with int16 PCM: the int32 PCM is only fetched when a block's
+     * samples leave the 16-bit range (LINNEAmd_SlotFetchPcm32 allocates then) */
+    const bool lazy_data = !for_encode && (flags & LINNE_AMD_SLOT_STREAM) && pcm16;
+    if (e == hipSuccess && !emit && !lazy_data) e = hipHostMalloc((void **)&s->h_data, nb, hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_prm, pb, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_data, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_prm, pb);
@@ -1218,11 +1223,14 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_plan, (uint64_t)LINNE_AMD_RICE_PLAN_BYTES * shape->num_channels * max_frames);
     }
     if (!for_encode && (flags & LINNE_AMD_SLOT_STREAM)) {
-        s->stream_cap = ((uint64_t)max_frames * (nb / max_frames + 1024u) + 4095u) & ~(uint64_t)4095u;       /* a block is smaller than its int32 residual */
+        /* room for the blocks' bytes: what RAW blocks take, and a little more (a COMPRESS block is chosen on an estimate and may
+         * come out larger: a group that does not fit is decoded the other way, lnn_api.c) */
+        s->stream_cap = ((uint64_t)max_frames * (CS * ((shape->bits_per_sample + 7u) / 8u) + CS / 8u + 1024u) + 4095u) & ~(uint64_t)4095u;
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->in_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_stream, s->stream_cap + 16, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_stream, s->stream_cap + 16);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_bitpos, sizeof(uint64_t) * max_frames, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->d_bitpos, sizeof(uint64_t) * max_frames);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_bitpos, (sizeof(uint64_t) + sizeof(uint32_t)) * max_frames, hipHostMallocDefault);      /* + the frames' lengths behind the positions */
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_bitpos, (sizeof(uint64_t) + sizeof(uint32_t)) * max_frames);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_endbit, sizeof(uint64_t) * max_frames, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_endbit, sizeof(uint64_t) * max_frames);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_flag, sizeof(uint32_t) * 4, hipHostMallocDefault);
@@ -1351,19 +1359,38 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
     int ret = LINNEAmd_SlotWait(s);
     if (ret != LNN_OK) return ret;
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    hipStream_t cin = s->in_stream ? s->in_stream : ctx->copy_in;
     const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames;
     memset(s->h_stream + stream_bytes, 0, 16);                 /* the reader loads whole 8-byte words */
-    HIPCHK(ctx, hipMemcpyAsync(s->d_stream, s->h_stream, (stream_bytes + 15u) & ~(uint64_t)7u, hipMemcpyHostToDevice, ctx->copy_in));
-    HIPCHK(ctx, hipMemcpyAsync(s->d_bitpos, s->h_bitpos, sizeof(uint64_t) * num_frames, hipMemcpyHostToDevice, ctx->copy_in));
-    HIPCHK(ctx, hipMemcpyAsync(s->d_prm, s->h_prm, pb, hipMemcpyHostToDevice, ctx->copy_in));
-    HIPCHK(ctx, hipEventRecord(s->ev_in, ctx->copy_in));
+    HIPCHK(ctx, hipMemcpyAsync(s->d_stream, s->h_stream, (stream_bytes + 15u) & ~(uint64_t)7u, hipMemcpyHostToDevice, cin));
+    {   /* the frames' lengths travel with the bit positions: the Rice decoder runs on the copy-in stream, beside the synthesis of
+         * the group before (k_rice_decode has a wave per 64 frames -- a few dozen waves -- and leaves the chip to it) */
+        uint32_t *h_nsm = (uint32_t *)(s->h_bitpos + s->max_frames);
+        const uint32_t S_ = s->shape.num_samples_per_block;
+        for (uint32_t f = 0; f < num_frames; f++) {
+            const uint32_t n_ = num_samples ? num_samples[f] : S_;
+            if (n_ == 0 || n_ > S_) { snprintf(ctx->err, sizeof(ctx->err), "frame %u: num_samples %u out of range", f, n_); return LNN_INVALID_ARGUMENT; }
+            h_nsm[f] = n_;
+        }
+    }
+    HIPCHK(ctx, hipMemcpyAsync(s->d_bitpos, s->h_bitpos, sizeof(uint64_t) * s->max_frames + sizeof(uint32_t) * num_frames, hipMemcpyHostToDevice, cin));
+    HIPCHK(ctx, hipMemcpyAsync(s->d_prm, s->h_prm, pb, hipMemcpyHostToDevice, cin));
+    {
+        RiceDecodeArgs a; memset(&a, 0, sizeof(a));
+        a.words = (const uint32_t *)s->d_stream; a.nbytes = stream_bytes; a.bitpos = s->d_bitpos; a.nsmp = (const uint32_t *)(s->d_bitpos + s->max_frames);
+        a.resid = s->d_data; a.endbit = s->d_endbit; a.F = num_frames; a.C = s->shape.num_channels; a.S = s->shape.num_samples_per_block;
+        const int sp_ = span_begin(ctx, 28, cin);
+        hipLaunchKernelGGL(k_rice_decode, dim3((num_frames + RDEC_THREADS - 1) / RDEC_THREADS), dim3(RDEC_THREADS), 0, cin, a);
+        span_end(ctx, sp_, cin);
+    }
+    HIPCHK(ctx, hipEventRecord(s->ev_in, cin));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
-    if ((ret = LINNEAmd_RiceDecodeDevice(ctx, &s->shape, s->d_stream, stream_bytes, s->d_bitpos, num_samples, num_frames, s->d_data, s->d_endbit)) != LNN_OK) return ret;
     if ((ret = LINNEAmd_DecodeFramesDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_prm)) != LNN_OK) return ret;
     if (s->d_out16) {
         HIPCHK(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_narrow16, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, s->d_out16, CS * num_frames, s->d_flag);
+        hipLaunchKernelGGL(k_narrow16, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, s->d_out16, CS * num_frames, s->d_flag,
+                (const uint32_t *)(s->d_bitpos + s->max_frames), (uint32_t)C, s->shape.num_samples_per_block);
     }
     HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
@@ -1383,6 +1410,8 @@ extern "C" int LINNEAmd_SlotFetchPcm32(struct LINNEAmdSlot *s, uint32_t num_fram
 {
     if (!s || s->for_encode || num_frames > s->max_frames) return LNN_INVALID_ARGUMENT;
     const uint64_t nb = sizeof(int32_t) * (uint64_t)s->shape.num_channels * s->shape.num_samples_per_block * num_frames;
-    if (hipSetDevice(s->ctx->device) != hipSuccess || hipMemcpy(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost) != hipSuccess) return LNN_NG;
+    if (hipSetDevice(s->ctx->device) != hipSuccess) return LNN_NG;
+    if (!s->h_data && hipHostMalloc((void **)&s->h_data, sizeof(int32_t) * (uint64_t)s->shape.num_channels * s->shape.num_samples_per_block * s->max_frames, hipHostMallocDefault) != hipSuccess) { s->h_data = NULL; return LNN_NG; }
+    if (hipMemcpy(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost) != hipSuccess) return LNN_NG;
     return LNN_OK;
 }

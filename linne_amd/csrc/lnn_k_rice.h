@@ -274,13 +274,18 @@ template <bool LDS> __global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit
  * is one serial bit stream and the next channel of a block starts where this one ends, so the unit of parallel work is the
  * BLOCK: lanes = frames, every lane walks its block's channels in order from the bit position the host found behind the
  * parameter bits.  The host stage then only scans block headers and decodes the parameters (a few hundred Huffman symbols per
- * block); the compressed stream itself travels over PCIe (0.76 x 2 bytes per sample here) instead of 4-byte residuals, and the
- * 67 ms of host Rice decoding of a 60-minute stream become ~4 ms beside the synthesis kernels.
- * A lane reads its bytes through a 128-bit window refilled 64 bits at a time (two aligned 32-bit loads, zeros past the end of the
- * data).  Anything a well-formed stream cannot contain -- a partition order above 31, a parameter step of more than 32 digits,
- * a read past the end of the data -- ends the lane with end_bit = ~0: the host decodes that group itself (lnn_parse_block keeps
- * the reference's behaviour for damaged streams).  Otherwise end_bit is the bit position behind the last channel's code, from
- * which the host derives the bytes the block consumed (linne_decoder.c:495-499).
+ * block); the compressed stream itself travels over PCIe (0.76 x 2 bytes per sample here) instead of 4-byte residuals.
+ *
+ * A lane's reader is 32-bit throughout: two window words and one word read ahead (w0:w1 | pre), `sh` < 32 bits of w0 already
+ * consumed; peek() = the next 32 bits (one funnel shift), skip(n <= 32) = add to sh and, past 32, slide the words and load the next
+ * one ahead of its use.  A sample is a peek for the zero run, a skip, a peek for the binary part, a skip.  All lanes of a wave walk
+ * the SAME sample index (partition boundaries are handled inline, whatever order each lane's block chose), so 16 samples of 64
+ * frames at a time go through an LDS tile and reach the residual rows in 64-byte pieces instead of 64 scattered words per store.
+ *
+ * Anything an encoder's stream cannot contain -- a partition order above 10 or one that does not divide the block, a parameter
+ * step of more than 32 digits, a zero run into the end of the data -- ends the lane with end_bit = ~0: the host decodes that
+ * stream itself (lnn_parse_block keeps the reference's behaviour for damaged streams).  Otherwise end_bit is the bit position
+ * behind the last channel's code, from which the host derives the bytes the block consumed (linne_decoder.c:495-499).
  * ============================================================================================== */
 struct RiceDecodeArgs {
     const uint32_t *words; uint64_t nbytes;          /* the stream segment of the group, 4-byte aligned, zero padded to 8 bytes */
@@ -291,94 +296,157 @@ struct RiceDecodeArgs {
     uint32_t F, C, S;
 };
 
-/* hi:lo = the next `have` bits of the stream, MSB first; after every operation have > 64, i.e. all of hi is valid.  The stream is
- * read as aligned big-endian 64-bit words (two 32-bit loads), zeros past the end of the data. */
+#define RDEC_THREADS 64
+#define RDEC_TILE 16
+#define RDEC_RING 64                    /* words of its stream a lane keeps in LDS */
+#define RDEC_CHUNK 16                   /* words per refill (one 64-byte piece of the lane's stream) */
 struct RiceBR {
-    const uint32_t *words; uint64_t nbits_total, nwords64;
-    uint64_t pos;                                    /* bits consumed, from the segment's start */
-    uint64_t hi, lo, next;                           /* next: index of the 64-bit word to load next */
-    uint32_t have;
-    bool over;
-    __device__ __forceinline__ uint64_t load64(uint64_t i) const {
-        if (i >= nwords64) return 0u;
-        const uint32_t a = words[2 * i], b = words[2 * i + 1];
-        return ((uint64_t)__builtin_bswap32(a) << 32) | (uint64_t)__builtin_bswap32(b);
+    const uint32_t *words; uint32_t nwords;          /* words that may be loaded (zeros beyond) */
+    const uint32_t *ring;                            /* this lane's RDEC_RING words in LDS: stream words [hi - RDEC_RING, hi) at index & (RDEC_RING - 1) */
+    uint32_t hi;
+    uint32_t w0, w1, pre, widx, sh;                  /* widx: index of the word after `pre` */
+    __device__ __forceinline__ uint32_t load(uint32_t i) const {
+        if (i < hi) return ring[i & (RDEC_RING - 1u)];                     /* (never below hi - RDEC_RING: the refill rule of k_rice_decode) */
+        return (i < nwords) ? __builtin_bswap32(words[i]) : 0u;            /* beyond what is staged: a long run of zeros got ahead of the refills */
     }
-    __device__ __forceinline__ void refill() {
-        while (have <= 64u) {
-            const uint64_t w = load64(next++);
-            if (have == 64u) lo = w;
-            else if (have == 0u) { hi = w; lo = 0u; }
-            else { hi |= w >> have; lo = w << (64u - have); }
-            have += 64u;
-        }
+    __device__ __forceinline__ void open(uint64_t bit) {
+        const uint32_t i = (uint32_t)(bit >> 5);
+        sh = (uint32_t)bit & 31u; w0 = load(i); w1 = load(i + 1u); pre = load(i + 2u); widx = i + 3u;
     }
-    __device__ __forceinline__ void open(const uint32_t *w, uint64_t nbytes, uint64_t bit) {
-        words = w; nbits_total = nbytes * 8u; nwords64 = (nbytes + 7u) >> 3; pos = bit; over = false;
-        const uint32_t sh = (uint32_t)(bit & 63u);
-        next = bit >> 6;
-        const uint64_t first = load64(next++);
-        hi = sh ? (first << sh) : first; lo = 0u; have = 64u - sh;
-        refill();
-    }
-    __device__ __forceinline__ void consume(uint32_t n) {                  /* 1 <= n <= 64 */
-        if (n == 64u) { hi = lo; lo = 0u; } else { hi = (hi << n) | (lo >> (64u - n)); lo <<= n; }
-        have -= n; pos += n;
-        if (pos > nbits_total) over = true;
-        refill();
+    __device__ __forceinline__ uint64_t pos() const { return ((uint64_t)(widx - 3u) << 5) + sh; }
+    __device__ __forceinline__ uint32_t peek() const { return (uint32_t)(((((uint64_t)w0 << 32) | w1) << sh) >> 32); }
+    __device__ __forceinline__ void skip(uint32_t n) {                     /* n <= 32 */
+        sh += n;
+        if (sh >= 32u) { sh -= 32u; w0 = w1; w1 = pre; pre = load(widx); widx++; }
     }
     __device__ __forceinline__ uint32_t get(uint32_t n) {                  /* n <= 32 */
-        if (n == 0u) return 0u;
-        const uint32_t v = (uint32_t)(hi >> (64u - n));
-        consume(n);
+        const uint32_t v = n ? (peek() >> (32u - n)) : 0u;
+        skip(n);
         return v;
     }
-    __device__ __forceinline__ uint32_t zero_run(bool &bad) {              /* zeros up to the next 1, which is consumed too */
+    /* zeros up to the next 1, which is consumed too; `bad` if the data ends first */
+    __device__ __forceinline__ uint32_t zero_run(uint64_t nbits_total, bool &bad) {
         uint32_t run = 0;
         for (;;) {
-            if (hi != 0u) { const uint32_t z = (uint32_t)__clzll((long long)hi); consume(z + 1u); return run + z; }
-            if (pos >= nbits_total) { bad = true; return run; }
-            consume(64u); run += 64u;
+            const uint32_t t = peek();
+            if (t != 0u) { const uint32_t z = (uint32_t)__clz((int)t); skip(z + 1u); return run + z; }
+            if (pos() >= nbits_total) { bad = true; return run; }
+            skip(32u); run += 32u;
         }
     }
 };
 
-#define RDEC_THREADS 64
 __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
 {
-    const uint32_t f = blockIdx.x * RDEC_THREADS + threadIdx.x;
-    if (f >= a.F) return;
-    const uint64_t start = a.bitpos[f];
-    if (start == ~0ull) { a.endbit[f] = 0u; return; }
-    const uint32_t n = a.nsmp[f];
-    RiceBR r; r.open(a.words, a.nbytes, start);
+    __shared__ int32_t tile[64][RDEC_TILE + 1];
+    __shared__ uint32_t ring[64][RDEC_RING + 1];
+    const uint32_t lane = threadIdx.x, f0 = blockIdx.x * RDEC_THREADS, f = f0 + lane;
+    const bool have_frame = f < a.F;
+    const uint64_t start = have_frame ? a.bitpos[f] : ~0ull;
+    const bool live = have_frame && start != ~0ull;
+    const uint32_t n = live ? a.nsmp[f] : 0u;
+    const uint64_t nbits_total = a.nbytes * 8u;
+    uint32_t nmax = n;                                                      /* the wave walks the longest block's samples */
+    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)nmax, m, 64); nmax = (o > nmax) ? o : nmax; }
+    RiceBR r;
+    r.words = a.words; r.nwords = (uint32_t)((a.nbytes + 3u) >> 2); r.ring = ring[lane];
+    /* the lane's stream is staged RDEC_CHUNK words at a time: the loads of a chunk are issued at a tile boundary and land in the
+     * ring at the next one, 16 samples of work later -- every lane's loads touch lines of their own, so a load waited for on the
+     * spot costs the wave a full trip to memory */
+    const uint32_t readable = (uint32_t)((((a.nbytes + 15u) & ~(uint64_t)7u)) >> 2);        /* words the caller made readable behind the data */
+    uint4 inf[RDEC_CHUNK / 4];
+    bool inflight = false;
+    auto issue = [&]() {
+#pragma unroll
+        for (uint32_t k = 0; k < RDEC_CHUNK / 4; k++) {
+            const uint32_t w = r.hi + 4u * k;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (w + 4u <= readable) v = *(const uint4 *)(a.words + w);
+            else { if (w < readable) v.x = a.words[w]; if (w + 1u < readable) v.y = a.words[w + 1u]; if (w + 2u < readable) v.z = a.words[w + 2u]; }
+            inf[k] = v;
+        }
+        inflight = true;
+    };
+    auto commit = [&]() {
+        uint32_t *dst = ring[lane];
+#pragma unroll
+        for (uint32_t k = 0; k < RDEC_CHUNK / 4; k++) {
+            const uint32_t o = (r.hi + 4u * k) & (RDEC_RING - 1u);
+            dst[o] = __builtin_bswap32(inf[k].x); dst[o + 1u] = __builtin_bswap32(inf[k].y); dst[o + 2u] = __builtin_bswap32(inf[k].z); dst[o + 3u] = __builtin_bswap32(inf[k].w);
+        }
+        r.hi += RDEC_CHUNK; inflight = false;
+    };
+    r.hi = live ? ((uint32_t)(start >> 5) & ~(uint32_t)(RDEC_CHUNK - 1u)) : 0u;
+    if (live) { issue(); commit(); issue(); commit(); issue(); commit(); }
+    r.open(live ? start : 0u);
     bool bad = false;
-    for (uint32_t ch = 0; ch < a.C && !bad; ch++) {
-        int32_t *out = a.resid + ((size_t)f * a.C + ch) * a.S;
-        const uint32_t order = r.get(10);
-        if (order > 10u || (n & ((1u << order) - 1u)) != 0u) { bad = true; break; }     /* no encoder writes that (lnn_entropy.c rice_emit): the host's decoder defines it */
-        const uint32_t ns = n >> order, parts = 1u << order;
-        uint32_t k2 = 0;
-        for (uint32_t part = 0; part < parts && !bad; part++) {
-            if (part == 0) k2 = r.get(5);
-            else {
-                const uint32_t nd = r.zero_run(bad) + 1u;
-                if (bad || nd > 32u) { bad = true; break; }
-                const uint32_t g = (nd == 1u) ? 0u : (uint32_t)((1ull << (nd - 1u)) + r.get(nd - 1u) - 1u);
-                k2 = (uint32_t)((int32_t)k2 + (int32_t)((g >> 1) ^ (0u - (g & 1u))));
+    /* write-out of a tile: instruction i covers rows 4 i + lane / 16, columns lane % 16 */
+    const uint32_t wrow = lane >> 4, wcol = lane & 15u;
+    uint32_t rown[16];                                                      /* lengths of the rows this lane writes (0: not a row of this launch) */
+#pragma unroll
+    for (uint32_t i = 0; i < 16u; i++) { const uint32_t fr = f0 + 4u * i + wrow; rown[i] = (fr < a.F && a.bitpos[fr] != ~0ull) ? a.nsmp[fr] : 0u; }
+    for (uint32_t ch = 0; ch < a.C; ch++) {
+        uint32_t ns = 0, next_part = 0, k2 = 0, k1 = 1, k1pow = 2;
+        bool first = true;
+        if (live && !bad) {
+            const uint32_t order = r.get(10);
+            if (order > 10u || (n & ((1u << order) - 1u)) != 0u) bad = true;          /* no encoder writes that (lnn_entropy.c rice_emit): the host's decoder defines it */
+            else ns = n >> order;
+        }
+        for (uint32_t s0 = 0; s0 < nmax; s0 += RDEC_TILE) {
+            /* refill: a chunk goes out when the lane has at most half a ring ahead of its reader (so that the chunk, once in the
+             * ring, overwrites nothing the reader still needs) */
+            if (live && !bad && !inflight) {
+                const uint32_t at = r.widx - 3u;                           /* the reader's first window word */
+                if ((int32_t)(at - r.hi) >= (int32_t)RDEC_CHUNK) r.hi = at & ~(uint32_t)(RDEC_CHUNK - 1u);      /* (it ran ahead of the staged words) */
+                if ((int32_t)(r.hi - at) <= (int32_t)(RDEC_RING / 2u) && r.hi < readable) issue();
             }
-            k2 &= 31u;
-            const uint32_t k1 = k2 + 1u, k1pow = 1u << (k1 & 31u);
-            int32_t *q = out + (size_t)part * ns;
-            for (uint32_t s = 0; s < ns && !bad; s++) {
-                const uint32_t quot = r.zero_run(bad);
-                const uint32_t v = (quot == 0u) ? r.get(k1) : (r.get(k2) + k1pow + ((quot - 1u) << k2));
-                q[s] = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
+#pragma unroll 1
+            for (uint32_t i = 0; i < RDEC_TILE; i++) {
+                const uint32_t s = s0 + i;
+                int32_t val = 0;
+                if (live && !bad && s < n) {
+                    if (s == next_part) {                                   /* a partition starts: its parameter */
+                        if (first) { k2 = r.get(5); first = false; }
+                        else {
+                            const uint32_t nd = r.zero_run(nbits_total, bad) + 1u;
+                            if (bad || nd > 32u) bad = true;
+                            else {
+                                const uint32_t g = (nd == 1u) ? 0u : (uint32_t)((1ull << (nd - 1u)) + r.get(nd - 1u) - 1u);
+                                k2 = (uint32_t)((int32_t)k2 + (int32_t)((g >> 1) ^ (0u - (g & 1u))));
+                            }
+                        }
+                        k2 &= 31u; k1 = k2 + 1u; k1pow = 1u << (k1 & 31u);
+                        next_part += ns;
+                    }
+                    if (!bad) {
+                        const uint32_t t = r.peek();
+                        uint32_t quot;
+                        if (t >> 7) { quot = (uint32_t)__clz((int)t); r.skip(quot + 1u); }          /* the usual case: a short run */
+                        else quot = r.zero_run(nbits_total, bad);
+                        const uint32_t low = r.get((quot == 0u) ? k1 : k2);         /* (one read for both forms: the lanes differ) */
+                        const uint32_t v = (quot == 0u) ? low : (low + k1pow + ((quot - 1u) << k2));
+                        val = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
+                    }
+                }
+                tile[lane][i] = val;
             }
-            if (r.over) bad = true;
+            /* the chunk issued above lands now -- unless the reader ran past the staged words meanwhile (a long zero run): it
+             * reads straight from memory then, and the stale chunk is dropped by moving `hi` up to the reader */
+            if (inflight) {
+                if (r.widx - 3u >= r.hi + RDEC_CHUNK) { inflight = false; r.hi = (r.widx - 3u) & ~(uint32_t)(RDEC_CHUNK - 1u); }
+                else commit();
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (uint32_t i = 0; i < 16u; i++) {
+                const uint32_t row = 4u * i + wrow, s = s0 + wcol;
+                if (s < rown[i]) a.resid[((size_t)(f0 + row) * a.C + ch) * a.S + s] = tile[row][wcol];
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    a.endbit[f] = (bad || r.over) ? ~0ull : r.pos;
+    if (have_frame) a.endbit[f] = !live ? 0u : ((bad || r.pos() > nbits_total) ? ~0ull : r.pos());
 }
 
 

@@ -663,7 +663,7 @@ def _blocks(stream):
                                                                (8, 8, 1024, 2, 5 * 1024 + 1000, "2"), (2, 16, 1023, 7, 5 * 1023 + 400, "5"), (2, 16, 10240, 7, 40 * 10240 + 9280, None)])
 def test_decode_whole_with_rice_decoding_on_the_device(product, monkeypatch, nch, bits, block, preset, total, group):
     """LINNEDecoder_DecodeWhole hands the blocks' bytes to the device, whose k_rice_decode reads the partitioned recursive Rice codes
-    (linne_coder.c:304-345) -- LINNE_AMD_DECODE_STREAM=1 -- or decodes them on the host threads (0, the default).  Same PCM either
+    (linne_coder.c:304-345) -- LINNE_AMD_DECODE_STREAM=1, the default -- or decodes them on the host threads (0).  Same PCM either
     way (the encoder's input), SILENT and RAW blocks in between, a ragged tail, int16 (<= 16 bits) and int32 PCM on the way back"""
     if group:
         monkeypatch.setenv("LINNE_AMD_GROUP", group)
@@ -676,8 +676,13 @@ def test_decode_whole_with_rice_decoding_on_the_device(product, monkeypatch, nch
         ret, dec = product.decode_whole(stream)
         assert ret == 0 and np.array_equal(dec, x)
         assert product.last_decode_whole_mode() == int(mode)
-    # a stream cut inside a block: the error is reported, the blocks before it are delivered
+    # the int32 way back (taken when a sample leaves the 16-bit range: only a stream no encoder wrote decodes to one)
     monkeypatch.setenv("LINNE_AMD_DECODE_STREAM", "1")
+    monkeypatch.setenv("LINNE_AMD_DEBUG_NO_PCM16", "1")
+    ret, dec = product.decode_whole(stream)
+    assert ret == 0 and np.array_equal(dec, x) and product.last_decode_whole_mode() == 1
+    monkeypatch.delenv("LINNE_AMD_DEBUG_NO_PCM16")
+    # a stream cut inside a block: the error is reported, the blocks before it are delivered
     ret, dec = product.decode_whole(stream[:len(stream) * 2 // 3])
     whole = 0
     for off, size, _ in _blocks(stream):
