@@ -66,6 +66,7 @@ struct LINNEAmdContext {
     /* pinned ring for the per-call frame metadata (class index, length), so that a call enqueues without a host sync */
     int fwd_loss;                       /* LINNE_AMD_FWD_LOSS: last layer's forward pass and loss in one kernel (k_fwd_loss); -1 = by batch size */
     int lev_ride;                       /* short Levinson trials ride along with the one-unit trial (LINNE_AMD_LEV_RIDE, default 1) */
+    int lev_wave;                       /* batches of <= 64 jobs: a wave per Levinson problem (LINNE_AMD_LEV_WAVE, default 1) */
     const uint32_t *cur_idx;            /* class index per frame of the call being enqueued (host copy, in the meta ring) */
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
@@ -156,6 +157,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     { const char *ex = getenv("LINNE_AMD_EXACT"); ctx->force_exact = ex ? atoi(ex) : 0; }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
+    { const char *lw = getenv("LINNE_AMD_LEV_WAVE"); ctx->lev_wave = lw ? atoi(lw) : 1; }
     { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : -1; }
     { const char *sp = getenv("LINNE_AMD_FIR_SMALL"); ctx->fir_small = sp ? atoi(sp) : 1; }
     (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEV_LDS_BUDGET);
@@ -504,6 +506,14 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
             for (uint32_t k = 0; k < nlen; k++) { const DevClass &c = ctx->sig_cls[slot_of[k]]; if (c.ntrials[l] != nt || (c.na % (1u << nt)) != 0) ok = 0; }
             if (ok) ctx->prod_ok |= 1 << l;
         }
+        /* long layers by lanes = lags (k_autocorr_wide): a small batch, and every unit length of every trial a class has even */
+        const char *w_ = getenv("LINNE_AMD_WIDE");
+        for (uint32_t l = 0; l < hs->L; l++) {
+            if (hs->P[l] < 32u || hs->P[l] > 128u || !(w_ ? atoi(w_) : 1) || (uint64_t)F * shape->num_channels * (l == 0 ? 1u : hs->R) > 64u) continue;
+            int ok = 1;
+            for (uint32_t k = 0; k < nlen; k++) { const DevClass &c = ctx->sig_cls[slot_of[k]]; if (c.ntrials[l] == 0 || (c.na % (1u << c.ntrials[l])) != 0) ok = 0; }
+            if (ok) ctx->prod_ok |= 1 << l;
+        }
     }
     if ((ret = ensure_buf(ctx, (void **)&ctx->d_clsidx, &ctx->clsidx_cap, sizeof(uint32_t) * 2 * (uint64_t)(F ? F : 1))) != LNN_OK) return ret;
     ctx->d_map = ctx->d_clsidx + F;
@@ -779,6 +789,9 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
               /* one launch per trial, every order on LDS columns -- except that the short trials whose columns fit beside the
                * one-unit trial's ride along with it on a second wave (k_levinson_lds) */
               uint32_t ride = LNN_MAXT;
+              if (Jq <= 64u && ctx->lev_wave) {       /* a handful of jobs: a wave per problem, all trials in one launch */
+                  hipLaunchKernelGGL(k_levinson_wave, dim3((uint32_t)Jq, 2u * maxu - 1u), dim3(64), 0, st, q, l);
+              } else {
               for (uint32_t t = 1, u = 2; u <= maxu && ctx->lev_ride; u <<= 1, t++)
                   if (LEV_LDS(hs.P[l]) + LEV_MAXRIDE * LEV_LDS(hs.P[l] / u) <= LEV_LDS_BUDGET) { ride = t; break; }
               for (uint32_t t = 0, u = 1; u <= maxu && t < (ride < LNN_MAXT ? ride : LNN_MAXT); u <<= 1, t++) {
@@ -786,6 +799,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                   const bool carry = (t == 0 && ride < LNN_MAXT);
                   const size_t lds = LEV_LDS(np) + (carry ? LEV_MAXRIDE * LEV_LDS(hs.P[l] >> ride) : 0);
                   hipLaunchKernelGGL(k_levinson_lds, dim3(((uint32_t)Jq + 63) / 64, u), dim3(carry ? 64 * (1 + LEV_MAXRIDE) : 64), lds, st, q, l, t, carry ? ride : (uint32_t)LNN_MAXT);
+              }
               }
               span_end(ctx, sp_, st); }
             {   /* unit-count search.  Short layers: the register-window kernel.  The long layer: k_search_long for the frames it takes
@@ -856,7 +870,9 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         const uint32_t af_iters = ctx->af_iters;
         if ((ret = run_layers(p, J, true, hist_all, fuse_cfg, fuse_all, 0u, false)) != LNN_OK) return ret;
         uint32_t cur = cur_final;
-        if (!fuse_all) { const int sp_ = span_begin(ctx, 9, st); hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur); span_end(ctx, sp_, st); }
+        if (!fuse_all) { const int sp_ = span_begin(ctx, 9, st); if (J <= 1024u) hipLaunchKernelGGL(k_chain_sum_wave<1>, dim3((uint32_t)J), dim3(64), 0, st, p, 0u, cur);       /* few rows: a wave per row */
+            else hipLaunchKernelGGL(k_chain_sum<1>, dim3(((uint32_t)J + 63) / 64), dim3(SUM_THREADS), 0, st, p, 0u, cur);
+            span_end(ctx, sp_, st); }
         if (af_iters == 0) {        /* the final pass of linne_network.c:628-629 repeats the winning pass bit for bit: skipped */
             if (ctx->learning) {
                 hipLaunchKernelGGL(k_af_best, dim3(((uint32_t)CF + 255) / 256), dim3(256), 0, st, p, af_best, af_loss, af_reg);

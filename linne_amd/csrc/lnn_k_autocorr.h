@@ -727,15 +727,17 @@ template <int P> static void launch_autocorr_small(hipStream_t st, const Plan &p
 }
 
 /* Short layers when the batch is small and every unit length is even: one block per row (a job; for layer 0 a channel-frame,
- * whose lags serve every regulariser pass).  All threads window a chunk of samples for each trial and form the lag products
- * into LDS; then lane c adds the products of chain c = (trial, lag) in sample order and stores a unit's lag when the unit
- * ends.  The 10240-step dependent chain is nothing but adds fed from LDS, so a row takes ~0.1 ms where k_autocorr_lane's
- * waves take ~1 ms -- but only a few lanes are busy, so the lane kernel wins once the batch fills the chip. */
+ * whose lags serve every regulariser pass).  The lag products of a chunk of samples go to LDS, then lane c of wave 0 adds the
+ * products of chain c = (trial, lag) in sample order and stores a unit's lag when the unit ends: the 10240-step dependent chain
+ * is nothing but adds fed from LDS.  The three stages -- window the samples of chunk k + 2 (waves 1-3), multiply the pairs of
+ * chunk k + 1 (waves 1-3), add up chunk k (wave 0) -- run side by side on double buffers with ONE barrier per chunk, so a row
+ * takes about as long as its chains (~60 us; the single-buffered form with three barriers per chunk took 0.6 ms, the waves of
+ * k_autocorr_lane ~1 ms) -- but only a few lanes are busy, so the lane kernel wins once the batch fills the chip. */
 template <int P> struct ApCfg {
     static constexpr int NT = (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2;
     static constexpr int nch() { int s = 0; for (int t = 0; t < NT; t++) s += (P >> t) + 1; return s; }      /* 36, 19, 10, 5 */
     static constexpr int NCH = nch();
-    static constexpr int CHUNK = (P >= 16) ? 128 : (P >= 8) ? 256 : 512;
+    static constexpr int CHUNK = (P >= 16) ? 64 : (P >= 8) ? 128 : 256;
     static constexpr int trial_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return t; }
     static constexpr int lag_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return ch; }
 };
@@ -743,60 +745,104 @@ template <int P, bool L0>
 __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, uint32_t cur)
 {
     using Cfg = ApCfg<P>;
-    constexpr int NT = Cfg::NT, NCH = Cfg::NCH, CHUNK = Cfg::CHUNK;
-    __shared__ double sv[NT][CHUNK + P];
-    __shared__ double sprod[NCH][CHUNK];
+    constexpr int NT = Cfg::NT, NCH = Cfg::NCH, CHUNK = Cfg::CHUNK, NPROD = 192;      /* producer threads: waves 1 .. 3 */
+    static_assert(NCH <= 64, "one wave adds up all chains");
+    __shared__ double sv[2][NT][CHUNK + P];
+    __shared__ uint32_t srem[2][NT][CHUNK + P];
+    __shared__ double sprod[2][NCH][CHUNK];
     const uint32_t row = blockIdx.x, tid = threadIdx.x, job = L0 ? row * p.R : row;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
     const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
-    /* my chain (threads below NCH): trial, lag, unit length */
+    const uint32_t nchunks = (na + CHUNK - 1) / CHUNK;
+    const bool producer = tid >= 64u;
+    const uint32_t ptid = tid - 64u;
+    /* my chain (wave 0, lanes below NCH): trial, lag, unit length */
     uint32_t ct = 0, clag = tid;
     while (ct + 1 < (uint32_t)NT && clag >= ((uint32_t)P >> ct) + 1) { clag -= ((uint32_t)P >> ct) + 1; ct++; }
     const uint32_t cn = na >> ct, cnp = (uint32_t)P >> ct;
     double r = 0.0;
     uint32_t cloc = 0, cunit = 0;
     double *cout = p.acorr + ((size_t)job * LNN_MAXT + ct) * LNN_ACW + clag;
-    for (uint32_t base = 0; base < na; base += CHUNK) {
-        __syncthreads();
-        uint32_t loc0[NT];                                          /* place of sample base + tid inside its unit, per trial: one modulo each */
+    /* a producer's share of a chunk's CHUNK + P samples: the sample and its window weight under every trial, requested one
+     * iteration before they are multiplied and written to LDS (a load waited for on the spot would cost every chunk a trip to
+     * memory); beside each windowed sample goes the number of samples left in its unit: a pair (i, i + lag) counts while lag does
+     * not exceed it */
+    constexpr int NPRE = (CHUNK + P + NPROD - 1) / NPROD;
+    double px[NPRE], pw[NPRE][NT];
+    uint32_t wloc[NPRE][NT], prem[NPRE][NT];                    /* place inside the unit of my samples in the chunk to be requested next; samples left, of the requested ones */
 #pragma unroll
-        for (int t = 0; t < NT; t++) loc0[t] = (base + tid) % (na >> t);
+    for (int m = 0; m < NPRE; m++)
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const uint32_t nt = na >> t;
-            const double *wt = p.wtab + c.wt_off[layer][t];
-            uint32_t loc = loc0[t];
-            for (uint32_t i = tid; i < CHUNK + P; i += 256) {
-                const uint32_t g = base + i;
-                const double xv = (g < na) ? (L0 ? ((double)xi[g] * p.scale) : xd[g]) : 0.0;
-                sv[t][i] = (g < na) ? xv * wt[loc] : 0.0;
-                loc += 256; while (loc >= nt) loc -= nt;
+        for (int t = 0; t < NT; t++) wloc[m][t] = (ptid + (uint32_t)m * NPROD) % (na >> t);
+    auto prefetch = [&](uint32_t kk) {
+        const uint32_t base = kk * CHUNK;
+#pragma unroll
+        for (int m = 0; m < NPRE; m++) {
+            const uint32_t i = ptid + (uint32_t)m * NPROD, g = base + i;
+            const bool in = i < (uint32_t)(CHUNK + P) && g < na;
+            px[m] = in ? (L0 ? ((double)xi[g] * p.scale) : xd[g]) : 0.0;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const uint32_t nt = na >> t;
+                pw[m][t] = in ? p.wtab[c.wt_off[layer][t] + wloc[m][t]] : 0.0;
+                prem[m][t] = nt - 1u - wloc[m][t];
+                uint32_t l = wloc[m][t] + (uint32_t)CHUNK;
+                while (l >= nt) l -= nt;
+                wloc[m][t] = l;
             }
         }
-        __syncthreads();
+    };
+    /* a producer's share of a chunk's NCH x CHUNK pairs: element e = ptid + 192 m is chain e / CHUNK at sample e % CHUNK */
+    constexpr int NPM = (NCH * CHUNK + NPROD - 1) / NPROD;
+    uint32_t pe[NPM];                                            /* packed: sample (12 bits) | chain << 12 | lag << 20 | trial << 28; 0xFFFFFFFF: none */
 #pragma unroll
-        for (int ch = 0; ch < NCH; ch++) {                          /* chain ch = (trial, lag), constants after unrolling */
-            constexpr int dummy = 0; (void)dummy;
-            const int t = Cfg::trial_of(ch);
-            const uint32_t lag = (uint32_t)Cfg::lag_of(ch);
-            const uint32_t nt = na >> t;
-            uint32_t loc = loc0[t];
-            for (uint32_t i = tid; i < CHUNK; i += 256) {
-                const bool pair = (base + i < na) && (loc + lag < nt);   /* both samples inside the same unit */
-                sprod[ch][i] = pair ? sv[t][i] * sv[t][i + lag] : 0.0;
-                loc += 256; while (loc >= nt) loc -= nt;
+    for (int m = 0; m < NPM; m++) {
+        const uint32_t e = ptid + (uint32_t)m * NPROD, ch = e / (uint32_t)CHUNK, i = e % (uint32_t)CHUNK;
+        uint32_t t = 0, lag = ch;
+        while (t + 1 < (uint32_t)NT && lag >= ((uint32_t)P >> t) + 1) { lag -= ((uint32_t)P >> t) + 1; t++; }
+        pe[m] = (ch < (uint32_t)NCH) ? (i | (ch << 12) | (lag << 20) | (t << 28)) : 0xFFFFFFFFu;
+    }
+    if (producer) prefetch(0);
+    /* iteration k: window chunk k, multiply chunk k - 1, add chunk k - 2 */
+    for (uint32_t k = 0; k < nchunks + 2u; k++) {
+        if (producer) {
+            if (k < nchunks) {                                      /* the windowed samples base .. base + CHUNK + P - 1 of every trial */
+                double (*dst)[CHUNK + P] = sv[k & 1u];
+                uint32_t (*drem)[CHUNK + P] = srem[k & 1u];
+#pragma unroll
+                for (int m = 0; m < NPRE; m++) {
+                    const uint32_t i = ptid + (uint32_t)m * NPROD;
+                    if (i < (uint32_t)(CHUNK + P)) {
+#pragma unroll
+                        for (int t = 0; t < NT; t++) { dst[t][i] = px[m] * pw[m][t]; drem[t][i] = prem[m][t]; }     /* (0.0 * 0.0 beyond the frame's end) */
+                    }
+                }
+                if (k + 1u < nchunks) prefetch(k + 1u);
             }
-        }
-        __syncthreads();
-        if (tid < NCH) {
-            const uint32_t cnt = (na - base < CHUNK) ? (na - base) : CHUNK;
-            const double *q = sprod[tid];
+            if (k >= 1u && k - 1u < nchunks) {                      /* the pairs of chunk k - 1: both samples inside the same unit, else +0.0 (no effect on the bits) */
+                const double (*src)[CHUNK + P] = sv[(k - 1u) & 1u];
+                const uint32_t (*rem)[CHUNK + P] = srem[(k - 1u) & 1u];
+                double (*dst)[CHUNK] = sprod[(k - 1u) & 1u];
+#pragma unroll
+                for (int m = 0; m < NPM; m++) {
+                    const uint32_t e = pe[m];
+                    if (e != 0xFFFFFFFFu) {
+                        const uint32_t i = e & 0xFFFu, ch = (e >> 12) & 0xFFu, lag = (e >> 20) & 0xFFu, t = e >> 28;
+                        const double a = src[t][i], b = src[t][i + lag];
+                        dst[ch][i] = (lag <= rem[t][i]) ? a * b : 0.0;
+                    }
+                }
+            }
+        } else if (k >= 2u && tid < (uint32_t)NCH) {                /* add up chunk k - 2 */
+            const uint32_t base = (k - 2u) * CHUNK;
+            const uint32_t cnt = (na - base < (uint32_t)CHUNK) ? (na - base) : (uint32_t)CHUNK;
+            const double *q = sprod[k & 1u][tid];
             uint32_t i = 0;
             while (i < cnt) {                                       /* runs that end at the chunk's or the unit's end */
                 const uint32_t seg = (cnt - i < cn - cloc) ? (cnt - i) : (cn - cloc), end = i + seg;
-                for (; i + 8 <= end; i += 8) {                      /* +0.0 where the pair leaves the unit: no effect on the bits */
+                for (; i + 8 <= end; i += 8) {
                     const double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3], q4 = q[i + 4], q5 = q[i + 5], q6 = q[i + 6], q7 = q[i + 7];
                     r += q0; r += q1; r += q2; r += q3; r += q4; r += q5; r += q6; r += q7;
                 }
@@ -805,6 +851,7 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
                 if (cloc == cn) { cout[(size_t)cunit * (cnp + 1)] = r; r = 0.0; cloc = 0; cunit++; }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -838,6 +885,68 @@ static bool launch_autocorr_hist(hipStream_t st, const Plan &p, uint32_t layer, 
     return false;
 }
 
+/* Long layers when the batch is small (block-at-a-time calls) and every unit length is even: one block per (row, trial), lane =
+ * lag.  A unit's windowed samples are staged AW_TILE at a time with np zeros behind the unit's end (a pair that leaves the unit
+ * adds +-0.0: no effect on the bits), the next tile's samples and weights requested before this one is worked on; a lane adds
+ * xs[j] * xs[j + lag] in sample order -- one chain per lag, as the reference has it -- reading xs[j] at one address for the whole
+ * wave and xs[j + lag] at consecutive ones.  A trial takes ~50 us, the eight trials of a job run side by side; k_autocorr2,
+ * whose lanes own five lags each and walk the whole frame, takes 0.5 ms however few jobs there are. */
+#define AW_TILE 512
+template <int P>
+__global__ __launch_bounds__(64 * ((P + 64) / 64)) void k_autocorr_wide(Plan p, uint32_t layer, uint32_t cur)
+{
+    constexpr int NTHR = 64 * ((P + 64) / 64);                         /* lanes for P + 1 lags */
+    constexpr int NPRE = (AW_TILE + P + NTHR - 1) / NTHR;
+    __shared__ __attribute__((aligned(16))) double xs[AW_TILE + P + 8];
+    const uint32_t row = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    const bool l0 = (layer == 0);
+    const uint32_t job = l0 ? row * p.R : row;
+    const DevClass &c = job_class(p, job);
+    if (t >= c.ntrials[layer]) return;
+    const uint32_t na = c.na, u = 1u << t, np = (uint32_t)P >> t, nt = na >> t;
+    const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;
+    const double *xd = p.sig + ((size_t)job * 2 + cur) * p.S;
+    const double *wt = p.wtab + c.wt_off[layer][t];
+    double *out = p.acorr + ((size_t)job * LNN_MAXT + t) * LNN_ACW + tid;
+    const bool mine = tid <= np;                                        /* my lag */
+    const uint32_t tiles_per_unit = (nt + AW_TILE - 1) / AW_TILE, ntiles = u * tiles_per_unit;
+    double px[NPRE], pwv[NPRE];
+    auto prefetch = [&](uint32_t ti) {                                  /* tile ti: unit ti / tiles_per_unit, places loc0 .. loc0 + AW_TILE + np - 1 */
+        const uint32_t un = ti / tiles_per_unit, loc0 = (ti - un * tiles_per_unit) * AW_TILE;
+#pragma unroll
+        for (int m = 0; m < NPRE; m++) {
+            const uint32_t i = tid + (uint32_t)m * NTHR, loc = loc0 + i;
+            const bool in = i < (uint32_t)AW_TILE + np && loc < nt;
+            const uint32_t g = un * nt + loc;
+            px[m] = in ? (l0 ? ((double)xi[g] * p.scale) : xd[g]) : 0.0;
+            pwv[m] = in ? wt[loc] : 0.0;
+        }
+    };
+    prefetch(0);
+    double acc = 0.0;
+    for (uint32_t ti = 0; ti < ntiles; ti++) {
+        const uint32_t un = ti / tiles_per_unit, loc0 = (ti - un * tiles_per_unit) * AW_TILE;
+        __syncthreads();                                                /* the tile before is through */
+#pragma unroll
+        for (int m = 0; m < NPRE; m++) { const uint32_t i = tid + (uint32_t)m * NTHR; if (i < (uint32_t)AW_TILE + np) xs[i] = px[m] * pwv[m]; }
+        if (ti + 1 < ntiles) prefetch(ti + 1);
+        __syncthreads();
+        if (mine) {
+            const uint32_t cnt = (nt - loc0 < (uint32_t)AW_TILE) ? (nt - loc0) : (uint32_t)AW_TILE;
+            const double *xa = xs, *xb = xs + tid;
+            uint32_t j = 0;
+            for (; j + 8 <= cnt; j += 8) {
+                const lnn_d2 a0 = *(const lnn_d2 *)(xa + j), a1 = *(const lnn_d2 *)(xa + j + 2), a2 = *(const lnn_d2 *)(xa + j + 4), a3 = *(const lnn_d2 *)(xa + j + 6);
+                const double b0 = xb[j], b1 = xb[j + 1], b2 = xb[j + 2], b3 = xb[j + 3], b4 = xb[j + 4], b5 = xb[j + 5], b6 = xb[j + 6], b7 = xb[j + 7];
+                const double m0 = a0.x * b0, m1 = a0.y * b1, m2 = a1.x * b2, m3 = a1.y * b3, m4 = a2.x * b4, m5 = a2.y * b5, m6 = a3.x * b6, m7 = a3.y * b7;
+                acc += m0; acc += m1; acc += m2; acc += m3; acc += m4; acc += m5; acc += m6; acc += m7;
+            }
+            for (; j < cnt; j++) acc += xa[j] * xb[j];
+            if (loc0 + cnt == nt) { out[(size_t)un * (np + 1)] = acc; acc = 0.0; }     /* the unit is through */
+        }
+    }
+}
+
 static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, uint32_t cur, uint32_t na_max, bool prod_ok)
 {
     /* the product form has a short dependent chain but few busy lanes: it wins while the batch is too small to fill the chip
@@ -852,6 +961,16 @@ static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, ui
 #undef LNN_AP
             return;
         }
+    }
+    if (prod_ok && p.P[layer] >= 32u) {          /* (the host sets the bit for a long layer only when the batch is small: wide_ok) */
+        const uint32_t rows = (layer == 0) ? p.J / p.R : p.J;
+        uint32_t ntr = 0; for (uint32_t u = 1; u <= (p.P[layer] < (uint32_t)LNN_MAXU ? p.P[layer] : (uint32_t)LNN_MAXU); u <<= 1) ntr++;
+        switch (p.P[layer]) {
+        case 32: hipLaunchKernelGGL((k_autocorr_wide<32>), dim3(rows, ntr), dim3(64), 0, st, p, layer, cur); break;       /* (block = the kernel's launch bound: 64 lanes per 64 lags, rounded up from P + 1) */
+        case 64: hipLaunchKernelGGL((k_autocorr_wide<64>), dim3(rows, ntr), dim3(128), 0, st, p, layer, cur); break;
+        default: hipLaunchKernelGGL((k_autocorr_wide<128>), dim3(rows, ntr), dim3(192), 0, st, p, layer, cur); break;
+        }
+        return;
     }
     switch (p.P[layer]) {
     case 2: launch_autocorr_small<2>(st, p, layer, cur, na_max); break;

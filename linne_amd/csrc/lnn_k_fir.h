@@ -479,6 +479,39 @@ __global__ __launch_bounds__(SUM_THREADS) void k_chain_sum(Plan p, uint32_t laye
     }
 }
 
+/* The same sums for a SMALL batch (a few frames: block-at-a-time calls): a wave per row.  It loads 256 samples of its row at a
+ * time (coalesced; the next 256 are requested before these are added), leaves them in LDS and adds them in order -- every lane
+ * runs the same chain.  A row takes ~40 us; the 64-rows-per-wave form above spends a trip to memory per 64-sample tile when
+ * most of its rows are empty. */
+template <int MODE>
+__global__ __launch_bounds__(64) void k_chain_sum_wave(Plan p, uint32_t layer, uint32_t cur)
+{
+    __shared__ __attribute__((aligned(16))) double mag[256];
+    const uint32_t lane = threadIdx.x, myrow = blockIdx.x;
+    const uint32_t job = (MODE == 0) ? myrow / LNN_MAXT : myrow;
+    const DevClass &c = job_class(p, job);
+    if (!((MODE == 1 && !fwd_loss_takes(p, p.L - 1u, c.na)) || (MODE == 0 && (myrow % LNN_MAXT) < c.ntrials[layer] && p.uncertain[job]))) return;
+    const uint32_t na = c.na;
+    const double *src = p.sig + ((size_t)job * 2 + cur) * p.S;
+    double nx[4], sum = 0.0;
+#pragma unroll
+    for (uint32_t r = 0; r < 4u; r++) { const uint32_t s = r * 64u + lane; const double v = (s < na) ? src[s] : 0.0; nx[r] = (MODE == 1) ? fabs(v) : v; }
+    for (uint32_t s0 = 0; s0 < na; s0 += 256u) {
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; r++) mag[r * 64u + lane] = nx[r];
+#pragma unroll
+        for (uint32_t r = 0; r < 4u; r++) { const uint32_t s = s0 + 256u + r * 64u + lane; const double v = (s < na) ? src[s] : 0.0; nx[r] = (MODE == 1) ? fabs(v) : v; }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t cnt = (na - s0 < 256u) ? (na - s0) : 256u;
+        if (cnt == 256u) {
+#pragma unroll 8
+            for (uint32_t q = 0; q < 256u; q += 2u) { const lnn_d2 v = *(const lnn_d2 *)(mag + q); sum += v.x; sum += v.y; }
+        } else for (uint32_t q = 0; q < cnt; q++) sum += mag[q];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) { if (MODE == 0) p.tloss[myrow] = sum / (double)na; else p.jloss[myrow] = sum / (double)na; }
+}
+
 /* strict-< argmin over the trials (linne_network.c:338-341), keep its coefficients (== SetParameter,
  * :350-376, which recomputes the same values) and, for the last layer, the value the layer leaves in
  * parcor[P0] (Q2): the last call in reference order -- trials in order, then SetParameter's units -- that

@@ -113,4 +113,79 @@ __global__ __launch_bounds__(64 * (1 + LEV_MAXRIDE)) void k_levinson_lds(Plan p,
             if (q % nride == wave - 1u) levinson_problem(p, layer, tt, unit, mine, lane, job0);
 }
 
+/* The same recursion for a SMALL batch (block-at-a-time calls: a handful of jobs): a WAVE per (job, trial, unit) problem, all
+ * problems of a layer in one launch.  What is serial in the recursion -- the ordered sum a[0]r[k+1] + ... + a[k]r[1] -- stays one
+ * chain, but its products are formed by the lanes side by side (lane i: a[i] r[k+1-i], into LDS) and so is the update
+ * a[i] += gamma a[k+1-i]; the chain then is k + 1 adds fed from LDS.  An order-128 problem takes ~50 us (the lanes = jobs form
+ * above, with 8 of its 64 lanes busy: 0.32 ms, and its four launches follow one another).  Every operation is the one
+ * levinson_problem performs, on the same operands, in the same order.  grid = (jobs, problems of the layer). */
+__global__ __launch_bounds__(64) void k_levinson_wave(Plan p, uint32_t layer)
+{
+    __shared__ __attribute__((aligned(16))) double sa[2][LNN_MAXP + 2], sr[LNN_MAXP + 2], sprod[LNN_MAXP + 2];
+    const uint32_t job = blockIdx.x, lane = threadIdx.x;
+    const uint32_t t = 31u - (uint32_t)__clz((int)(blockIdx.y + 1u)), unit = blockIdx.y + 1u - (1u << t);
+    const DevClass &c = job_class(p, job);
+    if (t >= c.ntrials[layer]) return;
+    const uint32_t P = p.P[layer], u = 1u << t, np = P >> t, P0 = p.P[0];
+    const uint32_t n = c.na / u;
+    const double reg = p.job_reg ? p.job_reg[job] : p.regs[job % p.R];
+    const uint32_t ajob = (layer == 0) ? job - job % p.R : job;
+    const double *r = p.acorr + ((size_t)ajob * LNN_MAXT + t) * LNN_ACW + (size_t)unit * (np + 1);
+    double *h = p.tcoef + ((size_t)job * LNN_MAXT + t) * LNN_MAXP + (size_t)unit * np;
+    const bool last = (layer + 1 == p.L);
+    for (uint32_t i = lane; i <= np; i += 64u) sr[i] = r[i];
+    for (uint32_t i = lane; i < np + 2u; i += 64u) { sa[0][i] = 0.0; sa[1][i] = 0.0; }
+    __builtin_amdgcn_wave_barrier();
+    double tail = 0.0; int tail_set = 0;
+    const double r0 = sr[0] * (1.0 + reg);                    /* lpc.c:358 */
+    const bool zero = (n < np) || (fabs(r0) < (double)FLT_EPSILON);      /* lpc.c:349-355, 271-276 */
+    uint32_t cur = 0;
+    if (!zero) {
+        const double r1 = sr[1];
+        double ek = r0;
+        const double a1 = -r1 / r0;
+        ek += r1 * a1;
+        if (lane == 0) { sa[0][0] = 1.0; sa[0][1] = a1; }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = 1; k < np; k++) {
+            const double *a = sa[cur];
+            double *an = sa[cur ^ 1u];
+            for (uint32_t i = lane; i <= k; i += 64u) sprod[i] = a[i] * sr[k + 1u - i];
+            __builtin_amdgcn_wave_barrier();
+            double gamma = 0.0;
+            {
+                uint32_t i = 0;
+                for (; i + 8u <= k + 1u; i += 8u) {
+                    const lnn_d2 m0 = *(const lnn_d2 *)(sprod + i), m1 = *(const lnn_d2 *)(sprod + i + 2), m2 = *(const lnn_d2 *)(sprod + i + 4), m3 = *(const lnn_d2 *)(sprod + i + 6);
+                    gamma += m0.x; gamma += m0.y; gamma += m1.x; gamma += m1.y; gamma += m2.x; gamma += m2.y; gamma += m3.x; gamma += m3.y;
+                }
+                for (; i <= k; i++) gamma += sprod[i];
+            }
+            gamma /= -ek;
+            ek *= (1.0 - gamma * gamma);
+            for (uint32_t i = lane; i <= k + 1u; i += 64u) {
+                double v;
+                if (i == 0u) v = 1.0 + gamma * 0.0;                /* u[0]   + gamma*v[0]   */
+                else if (i == k + 1u) v = 0.0 + gamma * 1.0;       /* u[k+1] + gamma*v[k+1] */
+                else v = a[i] + gamma * a[k + 1u - i];
+                an[i] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            cur ^= 1u;
+            if (last && k == P0) { tail = -gamma; tail_set = 1; }
+        }
+    }
+    if (zero) {
+        for (uint32_t k = lane; k < np; k += 64u) h[k] = 0.0;
+        tail = 0.0; tail_set = (np >= P0) ? 1 : 0;             /* zero branches write parcor[0..order] */
+    } else {
+        for (uint32_t k = lane; k < np; k += 64u) h[k] = sa[cur][np - k];
+        if (!(last && np > P0)) { tail = 0.0; tail_set = 0; }
+    }
+    if (last && lane == 0) {
+        p.ptail[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = tail;
+        p.ptail_set[((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit] = (uint8_t)tail_set;
+    }
+}
+
 #endif
