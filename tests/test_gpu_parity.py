@@ -722,3 +722,32 @@ def test_decode_whole_meets_blocks_no_encoder_writes(product, oracle, monkeypatc
         restarted += (mode & 2) != 0
         same += (mode == 1)
     assert restarted > 0 and same > 0
+
+
+@pytest.mark.parametrize("wide,lev_wave", [("1", "1"), ("0", "1"), ("1", "0"), ("0", "0")])
+@pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (1, 24, 4096, 3, 1000), (2, 16, 1024, 0, 512), (2, 8, 2048, 5, 777)])
+def test_block_at_a_time_forms_agree(product, oracle, monkeypatch, wide, lev_wave, nch, bits, block, preset, tail):
+    """LINNEEncoder_EncodeBlock, block by block as the reference's tools/linne_codec calls it (linne_codec.c:133-161): a handful of
+    jobs per call, served by the latency forms -- k_autocorr_prod / k_autocorr_wide (LINNE_AMD_WIDE), k_levinson_wave
+    (LINNE_AMD_LEV_WAVE), k_chain_sum_wave -- or, with the knobs off, by the batch forms on the same few jobs.  Every block's
+    bytes equal the oracle's encoder's, the ragged last block included"""
+    import ctypes as C
+    monkeypatch.setenv("LINNE_AMD_WIDE", wide)
+    monkeypatch.setenv("LINNE_AMD_LEV_WAVE", lev_wave)
+    ms = nch >= 2
+    x = music(nch, 3 * block + tail, bits, seed=300 + preset)
+    want = oracle.encode_whole(x, bits, 44100, block, preset, ms)
+    enc = product.new_encoder(nch, bits, 44100, block, preset, ms)
+    out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
+    osz = C.c_uint32(0)
+    got = bytearray(want[:30])                                      # (the header carries the total length: EncodeWhole's business)
+    pos = 0
+    while pos < x.shape[1]:
+        n = min(block, x.shape[1] - pos)
+        planes = [np.ascontiguousarray(x[ch, pos:pos + n]) for ch in range(nch)]
+        ptrs = (C.POINTER(C.c_int32) * nch)(*[pl.ctypes.data_as(C.POINTER(C.c_int32)) for pl in planes])
+        assert product.L.LINNEEncoder_EncodeBlock(enc, ptrs, n, out.ctypes.data, out.size, C.byref(osz)) == 0
+        got += bytes(out[:osz.value])
+        pos += n
+    product.L.LINNEEncoder_Destroy(enc)
+    assert bytes(got) == want
