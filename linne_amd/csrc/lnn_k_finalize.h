@@ -67,12 +67,23 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
         const uint32_t units = s_units[l], np = p.P[l] / units, ns = n / units, rs = s_rshift[l];
         const uint32_t half = 1u << ((rs - 1u) & 31u);
         int32_t *out = (l + 1 == p.L) ? (p.resid + ocf * S) : dst;
+        /* the tile's samples are requested one tile ahead (registers), so that a block does not sit out a trip to memory per tile */
+        constexpr int NPF = (LNN_MAXP + 4 * FIN_THREADS + FIN_THREADS - 1) / FIN_THREADS;
+        int32_t pf[NPF];
+        auto prefetch = [&](uint32_t s0_) {
+#pragma unroll
+            for (int m = 0; m < NPF; m++) {
+                const uint32_t i = tid + (uint32_t)m * FIN_THREADS;
+                const int64_t g = (int64_t)s0_ - LNN_MAXP + i;
+                pf[m] = (i < LNN_MAXP + 4 * FIN_THREADS && g >= 0 && g < (int64_t)n) ? src[g] : 0;
+            }
+        };
+        prefetch(0);
         for (uint32_t s0 = 0; s0 < n; s0 += 4 * FIN_THREADS) {
             __syncthreads();
-            for (uint32_t i = tid; i < LNN_MAXP + 4 * FIN_THREADS; i += FIN_THREADS) {
-                const int64_t g = (int64_t)s0 - LNN_MAXP + i;
-                xt[i] = (g >= 0 && g < (int64_t)n) ? src[g] : 0;
-            }
+#pragma unroll
+            for (int m = 0; m < NPF; m++) { const uint32_t i = tid + (uint32_t)m * FIN_THREADS; if (i < LNN_MAXP + 4 * FIN_THREADS) xt[i] = pf[m]; }
+            if (s0 + 4 * FIN_THREADS < n) prefetch(s0 + 4 * FIN_THREADS);
             __syncthreads();
             {   /* a lane owns 4 consecutive samples: when they sit in one unit past its first np samples (the usual case) the
                  * taps slide a 4-wide register window over the tile, one coefficient and one new sample per tap for four
