@@ -67,6 +67,7 @@ struct LINNEAmdContext {
     int fwd_loss;                       /* LINNE_AMD_FWD_LOSS: last layer's forward pass and loss in one kernel (k_fwd_loss); -1 = by batch size */
     int lev_ride;                       /* short Levinson trials ride along with the one-unit trial (LINNE_AMD_LEV_RIDE, default 1) */
     int lev_wave;                       /* batches of <= 64 jobs: a wave per Levinson problem (LINNE_AMD_LEV_WAVE, default 1) */
+    int search_two;                     /* k_search_long in two passes over the window, five waves per SIMD (LINNE_AMD_SEARCH_TWO) */
     const uint32_t *cur_idx;            /* class index per frame of the call being enqueued (host copy, in the meta ring) */
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
@@ -158,6 +159,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
     { const char *lw = getenv("LINNE_AMD_LEV_WAVE"); ctx->lev_wave = lw ? atoi(lw) : 1; }
+    { const char *st_ = getenv("LINNE_AMD_SEARCH_TWO"); ctx->search_two = st_ ? atoi(st_) : 1; }
     { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : -1; }
     { const char *sp = getenv("LINNE_AMD_FIR_SMALL"); ctx->fir_small = sp ? atoi(sp) : 1; }
     (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEV_LDS_BUDGET);
@@ -809,7 +811,8 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 if (long_any) {
                     const int sp_ = span_begin(ctx, 25, st);
                     const dim3 grid((uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE), blk(FIR_THREADS);
-                    if (hs.P[l] == 128u) hipLaunchKernelGGL(k_search_long<128>, grid, blk, 0, st, q, l, cur); else hipLaunchKernelGGL(k_search_long<64>, grid, blk, 0, st, q, l, cur);
+                    if (ctx->search_two) { if (hs.P[l] == 128u) hipLaunchKernelGGL((k_search_long<128, true>), grid, blk, 0, st, q, l, cur); else hipLaunchKernelGGL((k_search_long<64, true>), grid, blk, 0, st, q, l, cur); }
+                    else { if (hs.P[l] == 128u) hipLaunchKernelGGL((k_search_long<128, false>), grid, blk, 0, st, q, l, cur); else hipLaunchKernelGGL((k_search_long<64, false>), grid, blk, 0, st, q, l, cur); }
                     span_end(ctx, sp_, st);
                 }
                 if (!(long_any && long_all)) {

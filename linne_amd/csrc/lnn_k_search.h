@@ -18,6 +18,11 @@
  *   - the tile image in LDS is padded (2 doubles behind every 8 samples): lane l's window is 80 bytes from lane l-1's, window
  *     reads are conflict-free, and with 8 taps per unrolled pair of steps every offset is a compile-time constant.
  *   - the five small trials (16, 8, 4, 2, 1 taps) run from ONE 24-sample register window.
+ * Two forms (template TWO; LINNE_AMD_SEARCH_TWO, default 1).  TWO = false: ONE pass, the joining trials ride on the one-unit
+ * trial's window registers (122 VGPRs: four waves per SIMD).  TWO = true: a pass per big trial -- the one-unit trial over the whole
+ * window, its output and search term, then the two-unit trial over the window's last half and the four-unit trial over its last
+ * quarter, each with the ring to itself (84 VGPRs: five waves per SIMD; the window's second half is read from LDS twice, which costs
+ * less than the fifth wave gains: 24.9 ms against 25.7).
  * The one-unit chain is the forward pass's (predict from 0.0, separate multiply and add, taps in order); everything else runs
  * on fused multiply-adds inside the certificate's slack (see k_select).  Zero history in front of sample 0 stands in for the
  * reference's skipped taps: adding +-0.0 products first leaves a chain's bits unchanged.
@@ -27,8 +32,8 @@
 
 #define SL_XPAD(i) ((i) + 2 * ((i) >> 3))
 
-template <int P>
-__global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t layer, uint32_t cur)
+template <int P, bool TWO>
+__global__ __launch_bounds__(FIR_THREADS, TWO ? 5 : 4) void k_search_long(Plan p, uint32_t layer, uint32_t cur)
 {
     constexpr int NT = (P == 128) ? 8 : 7;                 /* trials: u = 1 .. P (P = 128: u <= 128) */
     constexpr int NBIG = NT - 5;                           /* orders P, P/2 (, P/4): >= 32 taps */
@@ -121,6 +126,68 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
             SL_LOAD(G, Q, HN0, HN1) SL_T0(G, HC0, HC1) SL_TF(G, a1, p0_, p1_) SL_TF(G, a2, r0_, r1_) SL_RING(G) }
         lnn_d2 ha0 = *(const lnn_d2 *)(c0), ha1 = *(const lnn_d2 *)(c0 + 2), hb0, hb1;
         uint32_t q = 0;
+        if (TWO) {
+            /* two passes over the window: the one-unit trial alone (its accumulators, the ring and the coefficient pairs fit 96
+             * registers: a fifth wave per SIMD), its output and search term, then the joining trials over the window's second half */
+#pragma unroll 1
+            for (; q < (uint32_t)P; q += 16) {
+                SL_STEP1(0, q, ha0, ha1, hb0, hb1)      SL_STEP1(1, q + 4, hb0, hb1, ha0, ha1)
+                SL_STEP1(2, q + 8, ha0, ha1, hb0, hb1)  SL_STEP1(3, q + 12, hb0, hb1, ha0, ha1)
+            }
+            {
+                double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+                double ps0 = 0.0;
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j += 2) {
+                    const lnn_d2 xv = *(const lnn_d2 *)(xc + j);
+                    lnn_d2 o; o.x = (s + j == 0) ? xv.x : (xv.x + a0[j]); o.y = xv.y + a0[j + 1];
+                    *(lnn_d2 *)(dst + j) = o;
+                    ps0 += (s + j == 0) ? 0.0 : fabs(o.x); ps0 += fabs(o.y);
+                }
+                ps0 = wave_sum_f64_lane63(ps0);
+                if (last_lane) p.tsum[((size_t)job * LNN_MAXT + 0) * p.npart + part] = ps0;
+            }
+#define SL_LOADB(G) \
+            const lnn_d2 na_ = *(const lnn_d2 *)(xw + ((G & 1) ? 20 : 14)), nb_ = *(const lnn_d2 *)(xw + ((G & 1) ? 22 : 16)); \
+            if (G & 1) xw += 10;
+#define SL_STEPB(G, ACC, CP, K) { const lnn_d2 p0_ = *(const lnn_d2 *)(CP + (K)), p1_ = *(const lnn_d2 *)(CP + (K) + 2); \
+            SL_LOADB(G) SL_TF(G, ACC, p0_, p1_) SL_RING(G) }
+            /* the two-unit trial: the last P/2 samples of the window */
+            xw = xc - ((P / 2) >> 3) * 10;                                      /* -> x[s - P/2] */
+#pragma unroll
+            for (int j = 0; j < 12; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + SL_XPAD(j)); w[j] = v.x; w[j + 1] = v.y; }
+#pragma unroll
+            for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); a1[j] = v.x; a1[j + 1] = v.y; }
+#pragma unroll 1
+            for (uint32_t k1 = 0; k1 < (uint32_t)(P / 2); k1 += 16) {
+                SL_STEPB(0, a1, c1, k1)  SL_STEPB(1, a1, c1, k1 + 4)  SL_STEPB(2, a1, c1, k1 + 8)  SL_STEPB(3, a1, c1, k1 + 12)
+            }
+            {
+                double ps1 = 0.0;
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j += 2) { ps1 += (s + j == 0) ? 0.0 : fabs(a1[j]); ps1 += fabs(a1[j + 1]); }
+                ps1 = wave_sum_f64_lane63(ps1);
+                if (last_lane) p.tsum[((size_t)job * LNN_MAXT + 1) * p.npart + part] = ps1;
+            }
+            if (NBIG == 3) {                                                    /* the four-unit trial: the last P/4 */
+                xw = xc - ((P / 4) >> 3) * 10;
+#pragma unroll
+                for (int j = 0; j < 12; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xw + SL_XPAD(j)); w[j] = v.x; w[j + 1] = v.y; }
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); a2[j] = v.x; a2[j + 1] = v.y; }
+#pragma unroll 1
+                for (uint32_t k2 = 0; k2 < (uint32_t)(P / 4); k2 += 16) {
+                    SL_STEPB(0, a2, c2, k2)  SL_STEPB(1, a2, c2, k2 + 4)  SL_STEPB(2, a2, c2, k2 + 8)  SL_STEPB(3, a2, c2, k2 + 12)
+                }
+                double ps2 = 0.0;
+#pragma unroll
+                for (int j = 0; j < FIR_SPL; j += 2) { ps2 += (s + j == 0) ? 0.0 : fabs(a2[j]); ps2 += fabs(a2[j + 1]); }
+                ps2 = wave_sum_f64_lane63(ps2);
+                if (last_lane) p.tsum[((size_t)job * LNN_MAXT + 2) * p.npart + part] = ps2;
+            }
+#undef SL_LOADB
+#undef SL_STEPB
+        } else {
         for (; q < (uint32_t)(P / 2); q += 16) {             /* the one-unit trial alone */
             SL_STEP1(0, q, ha0, ha1, hb0, hb1)      SL_STEP1(1, q + 4, hb0, hb1, ha0, ha1)
             SL_STEP1(2, q + 8, ha0, ha1, hb0, hb1)  SL_STEP1(3, q + 12, hb0, hb1, ha0, ha1)
@@ -141,6 +208,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
                 SL_STEP3(2, q + 8, k1 + 8, k2 + 8, ha0, ha1, hb0, hb1)  SL_STEP3(3, q + 12, k1 + 12, k2 + 12, hb0, hb1, ha0, ha1)
             }
         }
+        }
 #undef SL_LOAD
 #undef SL_RING
 #undef SL_T0
@@ -148,26 +216,28 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_search_long(Plan p, uint32_t
 #undef SL_STEP1
 #undef SL_STEP2
 #undef SL_STEP3
-        double xo[FIR_SPL];
+        if (!TWO) {
+            double xo[FIR_SPL];
 #pragma unroll
-        for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); xo[j] = v.x; xo[j + 1] = v.y; }
-        /* the one-unit trial's forward output (linne_network.c:165-210) straight from the registers, and its search term */
-        double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
-        double ps0 = 0.0, ps1 = 0.0, ps2 = 0.0;
+            for (int j = 0; j < FIR_SPL; j += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc + j); xo[j] = v.x; xo[j + 1] = v.y; }
+            /* the one-unit trial's forward output (linne_network.c:165-210) straight from the registers, and its search term */
+            double *dst = p.sig + ((size_t)job * 2 + (cur ^ 1u)) * p.S + s;
+            double ps0 = 0.0, ps1 = 0.0, ps2 = 0.0;
 #pragma unroll
-        for (int j = 0; j < FIR_SPL; j += 2) {
-            lnn_d2 o; o.x = (s + j == 0) ? xo[j] : (xo[j] + a0[j]); o.y = xo[j + 1] + a0[j + 1];
-            *(lnn_d2 *)(dst + j) = o;
-            ps0 += (s + j == 0) ? 0.0 : fabs(o.x); ps0 += fabs(o.y);
-            ps1 += (s + j == 0) ? 0.0 : fabs(a1[j]); ps1 += fabs(a1[j + 1]);
-            if (NBIG == 3) { ps2 += (s + j == 0) ? 0.0 : fabs(a2[j]); ps2 += fabs(a2[j + 1]); }
-        }
-        ps0 = wave_sum_f64_lane63(ps0); ps1 = wave_sum_f64_lane63(ps1);
-        if (NBIG == 3) ps2 = wave_sum_f64_lane63(ps2);
-        if (last_lane) {
-            p.tsum[((size_t)job * LNN_MAXT + 0) * p.npart + part] = ps0;
-            p.tsum[((size_t)job * LNN_MAXT + 1) * p.npart + part] = ps1;
-            if (NBIG == 3) p.tsum[((size_t)job * LNN_MAXT + 2) * p.npart + part] = ps2;
+            for (int j = 0; j < FIR_SPL; j += 2) {
+                lnn_d2 o; o.x = (s + j == 0) ? xo[j] : (xo[j] + a0[j]); o.y = xo[j + 1] + a0[j + 1];
+                *(lnn_d2 *)(dst + j) = o;
+                ps0 += (s + j == 0) ? 0.0 : fabs(o.x); ps0 += fabs(o.y);
+                ps1 += (s + j == 0) ? 0.0 : fabs(a1[j]); ps1 += fabs(a1[j + 1]);
+                if (NBIG == 3) { ps2 += (s + j == 0) ? 0.0 : fabs(a2[j]); ps2 += fabs(a2[j + 1]); }
+            }
+            ps0 = wave_sum_f64_lane63(ps0); ps1 = wave_sum_f64_lane63(ps1);
+            if (NBIG == 3) ps2 = wave_sum_f64_lane63(ps2);
+            if (last_lane) {
+                p.tsum[((size_t)job * LNN_MAXT + 0) * p.npart + part] = ps0;
+                p.tsum[((size_t)job * LNN_MAXT + 1) * p.npart + part] = ps1;
+                if (NBIG == 3) p.tsum[((size_t)job * LNN_MAXT + 2) * p.npart + part] = ps2;
+            }
         }
     }
 

@@ -189,6 +189,24 @@ def many_tracks(big, ntracks, per_track, tail):
     return frames, ns
 
 
+@pytest.mark.parametrize("two", ["0", "1"])
+def test_long_layer_search_in_one_pass_and_in_one_pass_per_trial(oracle, big, monkeypatch, two):
+    """k_search_long's two forms (LINNE_AMD_SEARCH_TWO): the joining trials on the one-unit trial's window registers (four waves
+    per SIMD), or a pass per big trial (five) -- the same trial sums up to the certificate's slack, the same forward output bit
+    for bit: sampled frames of the 3200-frame batch against the oracle, and the two forms against each other"""
+    monkeypatch.setenv("LINNE_AMD_SEARCH_TWO", two)
+    c = linne_amd.Context(0, scratch_bytes=8 << 30, use_torch_stream=False)
+    try:
+        res, prm, st = run_batch(c, big["frames"], big["ns"], check_decode=False)
+    finally:
+        c.close()
+    idx = sample_indices(NBIG, seed=3)
+    compare_sample(oracle_taps(oracle, big["frames"], big["ns"], idx, big["cache"]), big["ns"], res, prm, st, f"search form {two}")
+    if "one_chunk" in big:
+        a = big["one_chunk"]
+        assert np.array_equal(a[0], res) and np.array_equal(a[1], prm) and np.array_equal(a[2], st, equal_nan=True)
+
+
 def test_many_tracks_in_one_call_keep_the_fast_kernels(oracle, big):
     """64 tracks x (49 full + tail 2000) in ONE EncodeFramesDevice call (tools/linne_codec/linne_codec.c:133-161 per track):
     the host sorts the frames by length class, so the batch has two class runs and the lanes = jobs kernels serve the full
