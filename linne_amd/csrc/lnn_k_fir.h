@@ -317,6 +317,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     for (int i = 0; i < HP + FIR_SPL; i += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc - HP + i); wv[i] = v.x; wv[i + 1] = v.y; }
     const bool live = s < na;
     const bool fast = live && (s >= (uint32_t)P) && (s + FIR_SPL - 1 < na) && ((na % (uint32_t)(FIR_SPL * P)) == 0);
+    const uint32_t fine_unit = fast ? s / (na >> (NT - 1)) : 0u;   /* my samples' unit under the finest split (one division for all trials: the units nest) */
     for (uint32_t rr_ = 0; rr_ < nr; rr_++) {
     const uint32_t job = job0 + rr_;
     if (rr_) __syncthreads();                                       /* the previous job's coefficients are no longer read */
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         double sum = 0.0;
         if ((uint32_t)t < ntr && live) {
             if (fast) {
-                const double *hb = hs[t] + (size_t)(s / n) * np;
+                const double *hb = hs[t] + (size_t)(fine_unit >> (NT - 1 - t)) * np;
                 double h[(P >> 0)];
 #pragma unroll
                 for (int k = 0; k < np; k++) h[k] = hb[k];
