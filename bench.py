@@ -36,7 +36,7 @@ FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains wit
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
                 5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)",
-                25: "k_search_long<P> (search of the long layer in one window pass + fused one-unit forward)",
+                25: "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)",
                 18: "k_fir_small<P,false,*> (search of the last, short layer)", 15: "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)",
                 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false,true> (forward, jobs with several units)",
                 19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_fwd_loss<P> (last layer: forward pass + ordered loss)", 21: "k_autocorr_hist<P,0> (long layer, one-unit trial)", 22: "k_autocorr_hist<P,1> (long layer, two-unit trial)", 23: "k_autocorr_sub<P> (long layer, trials of order <= 32)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",

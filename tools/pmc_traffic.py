@@ -4,7 +4,7 @@ prescribes) of tools/kbench.py --frames F: writes profiles/pmc_latest.json.  Cou
 usage: pmc_traffic.py fetch.csv write.csv frames channels"""
 import csv, json, sys, collections
 fetch_csv, write_csv, frames, channels = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-KIND = [("k_search_long", "k_search_long<P> (search of the long layer in one window pass + fused one-unit forward)"),
+KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)"),
         ("k_fir2<2, false, true>", "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)"),
         ("k_fir_small<16, false", "k_fir_small<P,false,*> (search of the last, short layer)"), ("k_fir_small<8, false", "k_fir_small<P,false,*> (search of the last, short layer)"),
         ("k_fir_small<4, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"), ("k_fir_small<2, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"),
