@@ -189,6 +189,8 @@ int LINNEAmd_SlotFetchResidual(struct LINNEAmdSlot *slot, uint32_t frame, int32_
 uint8_t  *LINNEAmd_SlotStream(struct LINNEAmdSlot *slot);
 uint64_t  LINNEAmd_SlotStreamCapacity(const struct LINNEAmdSlot *slot);
 uint64_t *LINNEAmd_SlotBitPos(struct LINNEAmdSlot *slot);
+/* [max_frames] where every block ends (bit position in the slot's stream buffer): the device's decoder reads a block's codes no further */
+uint64_t *LINNEAmd_SlotBitEnd(struct LINNEAmdSlot *slot);
 const uint64_t *LINNEAmd_SlotEndBits(struct LINNEAmdSlot *slot);
 int LINNEAmd_SlotPcm16Valid(const struct LINNEAmdSlot *slot);
 int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *slot, uint64_t stream_bytes, const uint32_t *num_samples, uint32_t num_frames);

@@ -567,7 +567,7 @@ struct dgroup {
 struct unpack_job {
     const struct LINNEDecoder *dec; const uint8_t *data; struct dgroup *g; int32_t *sdata, *sprm; int32_t **buffer;
     /* stream mode (the device decodes the Rice codes): the group's bytes go to the slot as they are, from seg_first on */
-    uint8_t *sstream; uint64_t *sbitpos; uint64_t seg_first, seg_bytes; const int16_t *s16;
+    uint8_t *sstream; uint64_t *sbitpos, *sbitend; uint64_t seg_first, seg_bytes; const int16_t *s16;
 };
 static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
 {
@@ -584,6 +584,7 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
             g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
                     &g->types[f], &g->ns[f], &g->cons[f], NULL, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS, &rbit);
             j->sbitpos[g->cidx[f]] = (g->offs[f] - j->seg_first) * 8u + rbit;
+            j->sbitend[g->cidx[f]] = (g->offs[f] - j->seg_first + g->cons[f]) * 8u;
             continue;
         }
         if (g->cidx[f] != 0xFFFFFFFFu) {            /* COMPRESS by its header: residual and parameters go to the slot */
@@ -728,13 +729,13 @@ restart:
             }
             sl = gp->slot[produced % ndev][(produced / ndev) % nslots];
             uj.g = g; uj.sdata = sl ? LINNEAmd_SlotData(sl) : NULL; uj.sprm = sl ? LINNEAmd_SlotParams(sl) : NULL;
-            uj.sstream = NULL; uj.sbitpos = NULL; uj.s16 = NULL;
+            uj.sstream = NULL; uj.sbitpos = NULL; uj.sbitend = NULL; uj.s16 = NULL;
             g->seg_first = g->nblk ? g->offs[0] : off; g->seg_bytes = 0;
             t0 = now_s();
             if (stream_mode && sl && ncomp) {
                 g->seg_bytes = off - g->seg_first;                /* the scan above stopped at `off`: the group's bytes are [seg_first, off) */
                 if (g->seg_bytes > LINNEAmd_SlotStreamCapacity(sl)) { stream_mode = 0; g_last_decode_mode |= 2u; for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]); goto restart; }
-                uj.sstream = LINNEAmd_SlotStream(sl); uj.sbitpos = LINNEAmd_SlotBitPos(sl); uj.seg_first = g->seg_first; uj.seg_bytes = g->seg_bytes;
+                uj.sstream = LINNEAmd_SlotStream(sl); uj.sbitpos = LINNEAmd_SlotBitPos(sl); uj.sbitend = LINNEAmd_SlotBitEnd(sl); uj.seg_first = g->seg_first; uj.seg_bytes = g->seg_bytes;
                 lnn_parallel_for((uint32_t)((g->seg_bytes + 1048575u) >> 20), threads, copy_segment, &uj);
             }
             lnn_parallel_for(g->nblk, threads, unpack_blocks, &uj);

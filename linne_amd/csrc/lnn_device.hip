@@ -1248,8 +1248,8 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->in_stream, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_stream, s->stream_cap + 16, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_stream, s->stream_cap + 16);
-        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_bitpos, (sizeof(uint64_t) + sizeof(uint32_t)) * max_frames, hipHostMallocDefault);      /* + the frames' lengths behind the positions */
-        if (e == hipSuccess) e = hipMalloc((void **)&s->d_bitpos, (sizeof(uint64_t) + sizeof(uint32_t)) * max_frames);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_bitpos, (2 * sizeof(uint64_t) + sizeof(uint32_t)) * max_frames, hipHostMallocDefault);      /* positions, the blocks' ends, the frames' lengths */
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_bitpos, (2 * sizeof(uint64_t) + sizeof(uint32_t)) * max_frames);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_endbit, sizeof(uint64_t) * max_frames, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_endbit, sizeof(uint64_t) * max_frames);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_flag, sizeof(uint32_t) * 4, hipHostMallocDefault);
@@ -1271,6 +1271,7 @@ extern "C" int16_t *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *s) { return (s && (s
 extern "C" uint8_t *LINNEAmd_SlotStream(struct LINNEAmdSlot *s) { return s ? s->h_stream : NULL; }
 extern "C" uint64_t LINNEAmd_SlotStreamCapacity(const struct LINNEAmdSlot *s) { return s ? s->stream_cap : 0; }
 extern "C" uint64_t *LINNEAmd_SlotBitPos(struct LINNEAmdSlot *s) { return s ? s->h_bitpos : NULL; }
+extern "C" uint64_t *LINNEAmd_SlotBitEnd(struct LINNEAmdSlot *s) { return (s && s->h_bitpos) ? s->h_bitpos + s->max_frames : NULL; }
 extern "C" const uint64_t *LINNEAmd_SlotEndBits(struct LINNEAmdSlot *s) { return s ? s->h_endbit : NULL; }
 extern "C" int LINNEAmd_SlotPcm16Valid(const struct LINNEAmdSlot *s) { return (s && s->h_out16 && s->h_flag) ? (s->h_flag[0] == 0u) : 0; }
 extern "C" const uint8_t *LINNEAmd_SlotPacked(struct LINNEAmdSlot *s) { return s ? s->h_packed : NULL; }
@@ -1385,7 +1386,7 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
     HIPCHK(ctx, hipMemcpyAsync(s->d_stream, s->h_stream, (stream_bytes + 15u) & ~(uint64_t)7u, hipMemcpyHostToDevice, cin));
     {   /* the frames' lengths travel with the bit positions: the Rice decoder runs on the copy-in stream, beside the synthesis of
          * the group before (k_rice_decode has a wave per 64 frames -- a few dozen waves -- and leaves the chip to it) */
-        uint32_t *h_nsm = (uint32_t *)(s->h_bitpos + s->max_frames);
+        uint32_t *h_nsm = (uint32_t *)(s->h_bitpos + 2 * (size_t)s->max_frames);
         const uint32_t S_ = s->shape.num_samples_per_block;
         for (uint32_t f = 0; f < num_frames; f++) {
             const uint32_t n_ = num_samples ? num_samples[f] : S_;
@@ -1393,11 +1394,11 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
             h_nsm[f] = n_;
         }
     }
-    HIPCHK(ctx, hipMemcpyAsync(s->d_bitpos, s->h_bitpos, sizeof(uint64_t) * s->max_frames + sizeof(uint32_t) * num_frames, hipMemcpyHostToDevice, cin));
+    HIPCHK(ctx, hipMemcpyAsync(s->d_bitpos, s->h_bitpos, 2 * sizeof(uint64_t) * s->max_frames + sizeof(uint32_t) * num_frames, hipMemcpyHostToDevice, cin));
     HIPCHK(ctx, hipMemcpyAsync(s->d_prm, s->h_prm, pb, hipMemcpyHostToDevice, cin));
     {
         RiceDecodeArgs a; memset(&a, 0, sizeof(a));
-        a.words = (const uint32_t *)s->d_stream; a.nbytes = stream_bytes; a.bitpos = s->d_bitpos; a.nsmp = (const uint32_t *)(s->d_bitpos + s->max_frames);
+        a.words = (const uint32_t *)s->d_stream; a.nbytes = stream_bytes; a.bitpos = s->d_bitpos; a.nsmp = (const uint32_t *)(s->d_bitpos + 2 * (size_t)s->max_frames); a.bitend = s->d_bitpos + s->max_frames;
         a.resid = s->d_data; a.endbit = s->d_endbit; a.F = num_frames; a.C = s->shape.num_channels; a.S = s->shape.num_samples_per_block;
         const int sp_ = span_begin(ctx, 28, cin);
         hipLaunchKernelGGL(k_rice_decode, dim3((num_frames + RDEC_THREADS - 1) / RDEC_THREADS), dim3(RDEC_THREADS), 0, cin, a);
@@ -1409,7 +1410,7 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
     if (s->d_out16) {
         HIPCHK(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(uint32_t), ctx->stream));
         hipLaunchKernelGGL(k_narrow16, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, s->d_out16, CS * num_frames, s->d_flag,
-                (const uint32_t *)(s->d_bitpos + s->max_frames), (uint32_t)C, s->shape.num_samples_per_block);
+                (const uint32_t *)(s->d_bitpos + 2 * (size_t)s->max_frames), (uint32_t)C, s->shape.num_samples_per_block);
     }
     HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));

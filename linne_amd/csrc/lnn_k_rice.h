@@ -290,6 +290,7 @@ template <bool LDS> __global__ __launch_bounds__(REMIT_THREADS) void k_rice_emit
 struct RiceDecodeArgs {
     const uint32_t *words; uint64_t nbytes;          /* the stream segment of the group, 4-byte aligned, zero padded to 8 bytes */
     const uint64_t *bitpos;                          /* [F] bit position of the first channel's code (~0: not a COMPRESS block: skip) */
+    const uint64_t *bitend;                          /* [F] bit position behind the block (its codes end before it), or NULL: the segment's end */
     const uint32_t *nsmp;                            /* [F] */
     int32_t *resid;                                  /* [F][C][S] */
     uint64_t *endbit;                                /* [F] */
@@ -345,7 +346,9 @@ __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
     const uint64_t start = have_frame ? a.bitpos[f] : ~0ull;
     const bool live = have_frame && start != ~0ull;
     const uint32_t n = live ? a.nsmp[f] : 0u;
-    const uint64_t nbits_total = a.nbytes * 8u;
+    /* a lane reads no code beyond its own block's end: a run of zeros cannot take it through the rest of the segment */
+    uint64_t nbits_total = a.nbytes * 8u;
+    if (live && a.bitend && a.bitend[f] < nbits_total) nbits_total = a.bitend[f];
     uint32_t nmax = n;                                                      /* the wave walks the longest block's samples */
     for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)nmax, m, 64); nmax = (o > nmax) ? o : nmax; }
     RiceBR r;
