@@ -239,20 +239,21 @@ __global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
 }
 
 /* Synthesis of a LONG layer (order 32..128), four lanes per channel-frame: a wavefront reconstructs the same layer of 16
- * channel-frames; lane g of a channel-frame owns the taps k = g (mod 4) of the zero-extended coefficient vector, in
- * registers as doubles.  The last PL outputs live in LDS as doubles in a ring stored twice (slot i and i + PL), so a
- * lane's taps are a strided run without wrap-around, read with immediate offsets; the row stride and the tap
- * interleaving put the 32 lanes of each LDS access group on 32 different banks.  The int32 dot product is evaluated in
- * FP64 (exact, see k_synth_small), the four partial sums of a channel-frame meet through two DPP quad permutes, and
- * every lane of the quad finishes the step redundantly.  The newest output is forwarded in a register (its tap belongs
- * to lane 3), so the LDS write -> read round trip is off the critical path. */
+ * channel-frames; lane g of a channel-frame owns the taps [TP g, TP g + TP) of the zero-extended coefficient vector and the TP
+ * outputs they multiply, BOTH in registers: its window of the history slides by one sample per step -- the value that leaves
+ * lane g + 1's window enters lane g's (one DPP quad move), the newest output enters lane 3's -- and the time loop is unrolled
+ * over one turn of the TP-slot ring, so every ring index is a compile-time constant (k_synth_small's scheme, four lanes wide).
+ * The int32 dot product is evaluated in FP64 (exact, see k_synth_small), the four partial sums of a channel-frame meet through two
+ * DPP quad permutes, and every lane of the quad finishes the step redundantly.  All taps but the newest are summed one step
+ * ahead (`part`), so only one multiply-add, the quad sum and the integer tail are on the sample-to-sample critical path.
+ * (The first form kept the history in an LDS ring: 32 LDS reads per lane and sample, 8.5 ms per 31 008 channel-frames, bound by
+ * the LDS's bandwidth.) */
 #define SYB_T 64
 template <int PL>
 __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
 {
     constexpr int TP = PL / 4;                                   /* taps per lane */
-    constexpr int RSTR = 2 * PL + 4;                             /* ring row stride in doubles: = 4 (mod 32) */
-    __shared__ __attribute__((aligned(16))) double ring[16 * RSTR];
+    static_assert(SYB_T % TP == 0, "a tile is whole turns of the ring");
     __shared__ int32_t tile[16][SYB_T];
     const uint32_t lane = threadIdx.x, cfl = lane >> 2, g = lane & 3u, S = p.S;
     const uint32_t nrows = p.F * p.C, row0 = blockIdx.x * 16;
@@ -265,14 +266,12 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
     const bool skip = (units == 0 || np == 0 || ns < np);
     const uint32_t half = 1u << ((rs - 1u) & 31u);
     const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
-    double c[TP];
+    double c[TP], h[TP];                                         /* my taps; my window of the outputs: element j (oldest first) at h[(turn position + j) % TP] */
 #pragma unroll
-    for (int j = 0; j < TP; j++) c[j] = 0.0;
-    double *myring = ring + cfl * RSTR;
-    for (uint32_t i = g; i < 2 * PL; i += 4) myring[i] = 0.0;
+    for (int j = 0; j < TP; j++) { c[j] = 0.0; h[j] = 0.0; }
     uint32_t tl = 0, unit = 0;
     bool fresh = true;
-    double ynew = 0.0, part = 0.0;                               /* the previous step's output, forwarded; the partial sum made ahead */
+    double ynew = 0.0, part = 0.0;                               /* the previous step's output; the partial sum made ahead */
     uint32_t nmax = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
@@ -292,53 +291,77 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
         for (int r = 0; r < 16; r++) tile[r][lane] = pre[r];
         if (t + 1 < ntiles) issue(t + 1);
         __syncthreads();
+        /* one step: the oldest element of my window sits at h[TT_].  CALM_: no lane meets a unit's first sample in this turn, the
+         * taps stay as they are and `TL_` is the place inside the unit */
+#define SYB_STEP(TT_, S_, CALM_, TL_) { \
+                const int32_t res = tile[cfl][S_]; \
+                /* window element j multiplies tap j; everything but the newest output (lane 3's last element) was summed during the \
+                 * previous step (`part`): only that one product is on this step's critical path */ \
+                double acc = (g == 3u) ? __builtin_fma(c[TP - 1], ynew, part) : part; \
+                {   /* quad sum: lanes 4q .. 4q+3 */ \
+                    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0xB1, 0xf, 0xf, true);     /* quad_perm: 1,0,3,2 */ \
+                    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0xB1, 0xf, 0xf, true); \
+                    acc += __hiloint2double(hi, lo); \
+                    lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0x4E, 0xf, 0xf, true);         /* quad_perm: 2,3,0,1 */ \
+                    hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0x4E, 0xf, 0xf, true); \
+                    acc += __hiloint2double(hi, lo); \
+                } \
+                /* the window slides: my oldest element leaves for lane g - 1, lane g + 1's oldest enters as my newest (lane 3: the \
+                 * slot is filled with this step's output below).  Then next step's partial sum over the elements 0 .. TP-2 of the \
+                 * NEW window (h[TT_ + 1 ..]) -- lanes 0..2 take their newest element in too: it is known already */ \
+                { \
+                    const double out = h[TT_]; \
+                    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(out), 0xF9, 0xf, 0xf, true);     /* quad_perm: 1,2,3,3: from lane g + 1 */ \
+                    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(out), 0xF9, 0xf, 0xf, true); \
+                    h[TT_] = __hiloint2double(hi, lo);           /* (lane 3: overwritten with ynew once it is known) */ \
+                    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; \
+                    _Pragma("unroll") for (int j = 0; j < TP - 1; j++) { \
+                        const double hv = h[(TT_ + 1 + j) % TP]; \
+                        if ((j & 3) == 0) a0 = __builtin_fma(c[j], hv, a0); \
+                        else if ((j & 3) == 1) a1 = __builtin_fma(c[j], hv, a1); \
+                        else if ((j & 3) == 2) a2 = __builtin_fma(c[j], hv, a2); \
+                        else a3 = __builtin_fma(c[j], hv, a3); \
+                    } \
+                    const double hl = (g == 3u) ? 0.0 : h[TT_]; \
+                    a3 = __builtin_fma(c[TP - 1], hl, a3); \
+                    part = (a0 + a1) + (a2 + a3); \
+                } \
+                const uint32_t sum32 = (uint32_t)__double2loint(acc + 6755399441055744.0);      /* acc mod 2^32 (see k_synth_small) */ \
+                const uint32_t pred = half + sum32; \
+                int32_t y = res; \
+                if (!skip && (TL_) >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u))); \
+                ynew = (double)y; \
+                if (g == 3u) h[TT_] = ynew;                      /* the newest element of lane 3's window */ \
+                if (g == 0) tile[cfl][S_] = y; }
 #pragma unroll 1
-        for (uint32_t s = 0; s < SYB_T; s++) {
-            const uint32_t sidx = t * SYB_T + s, tm = sidx & (PL - 1);
-            if (fresh && !skip && unit < units) {                /* first sample of a unit: my taps of its zero-extended coefficients */
+        for (uint32_t sb = 0; sb < SYB_T; sb += TP) {
+            /* One turn of the ring = TP steps.  If no lane of the wave meets a unit boundary inside the turn (the common case),
+             * the turn runs as straight-line code; otherwise it takes the careful path (k_synth_small's scheme). */
+            const bool calm = !__any((!skip && unit < units) && (fresh || tl + (uint32_t)TP > ns));
+            if (calm) {
 #pragma unroll
-                for (int j = 0; j < TP; j++) {
-                    const uint32_t k = 4u * (uint32_t)j + g;
-                    c[j] = (k >= PL - np) ? (double)crec[unit * np + (k - (PL - np))] : 0.0;
-                }
+                for (int tt = 0; tt < TP; tt++) SYB_STEP(tt, sb + (uint32_t)tt, true, tl + (uint32_t)tt)
+                tl += TP;                                        /* tl + TP <= ns for predicting lanes; == ns closes the unit */
+                if (!skip && unit < units && tl == ns) { tl = 0; unit++; fresh = true; }
+                continue;
             }
-            fresh = false;
-            const int32_t res = tile[cfl][s];
-            /* tap k = 4j + g multiplies y[sidx - PL + k] (ring position tm + k).  Everything but the newest tap (k = PL - 1,
-             * lane 3) was summed during the previous step (`part`); only that one product is on this step's critical path */
-            double acc = (g == 3u) ? __builtin_fma(c[TP - 1], ynew, part) : part;
-            {   /* quad sum: lanes 4q .. 4q+3 */
-                int lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0xB1, 0xf, 0xf, true);     /* quad_perm: 1,0,3,2 */
-                int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0xB1, 0xf, 0xf, true);
-                acc += __hiloint2double(hi, lo);
-                lo = __builtin_amdgcn_update_dpp(0, __double2loint(acc), 0x4E, 0xf, 0xf, true);         /* quad_perm: 2,3,0,1 */
-                hi = __builtin_amdgcn_update_dpp(0, __double2hiint(acc), 0x4E, 0xf, 0xf, true);
-                acc += __hiloint2double(hi, lo);
-            }
-            {   /* next step's partial sum: positions tm + 1 + k, k <= PL - 2 -- none of them is written by this step */
-                const double *hp = myring + ((tm + 1u) & (PL - 1)) + g;
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
-                for (int j = 0; j < TP - 1; j++) {
-                    const double hv = hp[4 * j];
-                    if ((j & 3) == 0) a0 = __builtin_fma(c[j], hv, a0);
-                    else if ((j & 3) == 1) a1 = __builtin_fma(c[j], hv, a1);
-                    else if ((j & 3) == 2) a2 = __builtin_fma(c[j], hv, a2);
-                    else a3 = __builtin_fma(c[j], hv, a3);
+            for (int tt = 0; tt < TP; tt++) {
+                if (fresh && !skip && unit < units) {            /* first sample of a unit: my taps of its zero-extended coefficients */
+#pragma unroll
+                    for (int j = 0; j < TP; j++) {
+                        const uint32_t k = (uint32_t)TP * g + (uint32_t)j;
+                        c[j] = (k >= PL - np) ? (double)crec[unit * np + (k - (PL - np))] : 0.0;
+                    }
+                    /* (`part`, made ahead with the unit before's taps, is not used: a unit's first np samples are copied) */
                 }
-                const double hl = (g == 3u) ? 0.0 : hp[4 * (TP - 1)];
-                a3 = __builtin_fma(c[TP - 1], hl, a3);
-                part = (a0 + a1) + (a2 + a3);
+                fresh = false;
+                SYB_STEP(tt, sb + (uint32_t)tt, false, tl)
+                tl++;
+                if (tl == ns) { tl = 0; unit++; fresh = true; }
             }
-            const uint32_t sum32 = (uint32_t)__double2loint(acc + 6755399441055744.0);      /* acc mod 2^32 (see k_synth_small) */
-            const uint32_t pred = half + sum32;
-            int32_t y = res;
-            if (!skip && tl >= np && unit < units) y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)pred >> (rs & 31u)));
-            ynew = (double)y;
-            if (g == 0) { myring[tm] = ynew; myring[tm + PL] = ynew; tile[cfl][s] = y; }
-            tl++;
-            if (tl == ns) { tl = 0; unit++; fresh = true; }
         }
+#undef SYB_STEP
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; r++) {
