@@ -825,13 +825,21 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
                 const double (*src)[CHUNK + P] = sv[(k - 1u) & 1u];
                 const uint32_t (*rem)[CHUNK + P] = srem[(k - 1u) & 1u];
                 double (*dst)[CHUNK] = sprod[(k - 1u) & 1u];
+                /* all reads first, then all writes: the compiler cannot know that `src` and `dst` never overlap and would wait out
+                 * every element's LDS trip before starting the next */
+                double av[NPM], bv[NPM]; uint32_t rv[NPM];
+#pragma unroll
+                for (int m = 0; m < NPM; m++) {
+                    const uint32_t e = (pe[m] != 0xFFFFFFFFu) ? pe[m] : 0u;
+                    const uint32_t i = e & 0xFFFu, lag = (e >> 20) & 0xFFu, t = e >> 28;
+                    av[m] = src[t][i]; bv[m] = src[t][i + lag]; rv[m] = rem[t][i];
+                }
 #pragma unroll
                 for (int m = 0; m < NPM; m++) {
                     const uint32_t e = pe[m];
                     if (e != 0xFFFFFFFFu) {
-                        const uint32_t i = e & 0xFFFu, ch = (e >> 12) & 0xFFu, lag = (e >> 20) & 0xFFu, t = e >> 28;
-                        const double a = src[t][i], b = src[t][i + lag];
-                        dst[ch][i] = (lag <= rem[t][i]) ? a * b : 0.0;
+                        const uint32_t i = e & 0xFFFu, ch = (e >> 12) & 0xFFu, lag = (e >> 20) & 0xFFu;
+                        dst[ch][i] = (lag <= rv[m]) ? av[m] * bv[m] : 0.0;
                     }
                 }
             }
