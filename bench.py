@@ -382,7 +382,9 @@ def main():
     if world > 1:
         import datetime
         import torch.distributed as dist
-        tmo = datetime.timedelta(seconds=300)            # a transport leg that hangs becomes an error, not a dead job
+        tmo = datetime.timedelta(seconds=300)            # a transport leg that hangs becomes an error, not a dead job:
+        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")           # wait() raises at the timeout instead of the watchdog
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")    # tearing the process down (the legs are in try / except)
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)
         else:
