@@ -8,9 +8,20 @@ resident in HBM.  At N=1 the batch is BASELINE.json configs[1]: 60 min of 44.1 k
 shard with no data-path collective): "scaling": "weak".  The decode hot path (configs[2]) is timed right after on
 the encode's own output and reported as decode_frames_per_s; it must reproduce the PCM bit for bit.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel against HBM as BASELINE.json asks (the path
-is FP64-VALU / dependent-chain bound; `valu_f64` gives that view), `cpu_baseline` times the
-reference CPU encoder (oracle/_ref, or the oracle port if absent) on a bounded sample of the same workload.
+Starting it.  `python bench.py --gpus N` alone starts the N ranks itself (N child processes, one per GPU, from a parent
+that never touches the GPU; rank 0's line is the output; any child's failure is the exit code).  Under a launcher
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`) WORLD_SIZE is set and must equal --gpus.
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant encode kernel against HBM as BASELINE.json asks (the path is
+FP64-VALU / dependent-chain bound, see DESIGN.md; `valu_f64` gives that view), `roofline_decode` the dominant decode kernel;
+`cpu_baseline` / `cpu_baseline_decode` time the reference CPU encoder / decoder (oracle/_ref, or the oracle port if absent) on a
+bounded sample of the same workload; `block_at_a_time` is the per-call latency of the unchanged 13-symbol API.
+
+Everything behind the timed regions is an optional LEG with a deadline of its own (sample parity, CPU baselines, block-at-a-time
+calls, the end-to-end API, the transports).  A leg that raises becomes {"error": ...}; a leg that HANGS is cut off by a watchdog
+thread, which prints the line with what there is and ends the process: the headline is never lost to a sick link.  Control
+traffic at N > 1 (barriers, the MAX of the times, agreement flags) runs on a gloo group; RCCL carries only what north_star gives
+it, the scatter of frame batches and the gather of residuals (transports.rccl_scatter_gather), on a group of its own.
 """
 import argparse
 import json
@@ -23,29 +34,41 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import numpy as np
-import torch
 
-import linne_amd
+torch = None            # set by _load(): the launcher parent (--gpus N without WORLD_SIZE) must not import what may touch the GPU
+linne_amd = None
+
+
+def _load():
+    global torch, linne_amd
+    if torch is None:
+        import torch as _torch
+        import linne_amd as _linne_amd
+        torch, linne_amd = _torch, _linne_amd
+
 
 ALGO_BYTES_PER_CF = 82552           # 40960 in + 40960 out + 632 params per channel-frame
 MAC_PER_CF_REFERENCE = 46.2e6       # as written in the reference (-m 7, N = 10240)
-MAC_PER_CF_EXECUTED = 25.2e6        # multiply-adds (separate or fused) per channel-frame in the schedule this build runs
+MAC_PER_CF_EXECUTED = 25.2e6        # multiply-adds (separate or fused) per channel-frame in the schedule this build runs; -m 7 only
 HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
 FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25)
+DECODE_KINDS = (11, 12, 28, 29)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
                 5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)",
                 25: "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)",
                 18: "k_fir_small<P,false,*> (search of the last, short layer)", 15: "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)",
                 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false,true> (forward, jobs with several units)",
                 19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_fwd_loss<P> (last layer: forward pass + ordered loss)", 21: "k_autocorr_hist<P,0> (long layer, one-unit trial)", 22: "k_autocorr_hist<P,1> (long layer, two-unit trial)", 23: "k_autocorr_sub<P> (long layer, trials of order <= 32)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
-                9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synth_small+k_synth_big (all layers, de-emphasis)", 12: "k_ms_to_lr"}
+                9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synthesize (one wave per channel-frame, all layers)", 12: "k_ms_to_lr",
+                28: "k_synth_big<P> (synthesis of the long layer)", 29: "k_synth_small<P> (synthesis of the short layers, de-emphasis)"}
 
 
 def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):
     """compressible synthetic 'music' (SURVEY 8d recipe, generated on the GPU): per channel 6 harmonics of
     110*(ch+1) Hz with amplitudes 0.3/(k+1) and random phases, plus AR(2)-coloured noise; mix, clip, round."""
+    _load()
     g = torch.Generator(device=device)
     g.manual_seed(0x4C494E4E ^ seed)
     out = torch.empty((nch, num_samples), dtype=torch.int32, device=device)
@@ -73,6 +96,7 @@ def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 2
 
 def frames_from_track(track, block):
     """[C][num_samples] -> ([F][C][block] zero padded, num_samples per frame)"""
+    _load()
     nch, ns = track.shape
     F = (ns + block - 1) // block
     pad = F * block - ns
@@ -108,21 +132,26 @@ def _checkers():
     return Oracle, REF_SO, EncodeParameter, reference_available
 
 
-def sample_parity(frames, nsm, res, prm, st, shape, bits, block, preset, ms, nsample_mid=128):
-    """Outside the timed region: a sample of the timed batch's output -- the first 64 frames, the last 64 (with the ragged
-    tail) and `nsample_mid` random ones in between -- serialised with the host stage (LINNEAmd_PackFrames) and compared byte
-    for byte with the CPU reference's EncodeBlock of the same frames (oracle/_ref when built, else the oracle port; a fresh
+def _ptrs(C, x, nch):
+    return (C.POINTER(C.c_int32) * nch)(*[x[ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
+
+
+def sample_parity(frames, nsm, res, prm, st, shape, bits, block, preset, ms, nedge=64, nsample_mid=128, threads=None, seed=12345):
+    """Outside the timed region: a sample of the timed batch's output -- the first `nedge` frames, the last `nedge` (with the
+    ragged tail) and `nsample_mid` random ones in between -- serialised with the host stage (LINNEAmd_PackFrames) and compared
+    byte for byte with the CPU reference's EncodeBlock of the same frames (oracle/_ref when built, else the oracle port; a fresh
     handle per frame on both sides).  Equal blocks mean equal pre-emphasis, unit counts, shifts, coefficients and residuals
-    (libs/linne_encoder/src/linne_encoder.c:594-752).  decode(encode(x)) == x cannot show that: it holds for any coefficients."""
+    (libs/linne_encoder/src/linne_encoder.c:594-752).  decode(encode(x)) == x cannot show that: it holds for any coefficients.
+    At N > 1 every rank checks a (smaller) sample of ITS OWN shard and the verdicts are AND-reduced."""
     import ctypes as C
     from concurrent.futures import ThreadPoolExecutor
     from linne_amd.api import LinneApi
     Oracle, REF_SO, EncodeParameter, reference_available = _checkers()
     F, nch, _ = frames.shape
-    rng = np.random.default_rng(12345)
-    idx = set(range(min(64, F))) | set(range(max(0, F - 64), F))
-    if F > 128:
-        idx |= set(int(i) for i in rng.choice(np.arange(64, F - 64), size=min(nsample_mid, F - 128), replace=False))
+    rng = np.random.default_rng(seed)
+    idx = set(range(min(nedge, F))) | set(range(max(0, F - nedge), F))
+    if F > 2 * nedge and nsample_mid:
+        idx |= set(int(i) for i in rng.choice(np.arange(nedge, F - nedge), size=min(nsample_mid, F - 2 * nedge), replace=False))
     idx = sorted(idx)
     sel = torch.as_tensor(idx, device=frames.device)
     h_pcm, h_res, h_prm, h_st = (t.index_select(0, sel).cpu().numpy() for t in (frames, res, prm, st))
@@ -137,8 +166,7 @@ def sample_parity(frames, nsm, res, prm, st, shape, bits, block, preset, ms, nsa
             enc = api.new_encoder(nch, bits, 44100, block, preset, ms)
             out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
             osz = C.c_uint32(0)
-            ptrs = (C.POINTER(C.c_int32) * nch)(*[x[ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
-            r = api.L.LINNEEncoder_EncodeBlock(enc, ptrs, n, out.ctypes.data, out.size, C.byref(osz))
+            r = api.L.LINNEEncoder_EncodeBlock(enc, _ptrs(C, x, nch), n, out.ctypes.data, out.size, C.byref(osz))
             api.L.LINNEEncoder_Destroy(enc)
             assert r == 0
             return out[:osz.value].tobytes()
@@ -148,7 +176,7 @@ def sample_parity(frames, nsm, res, prm, st, shape, bits, block, preset, ms, nsa
         return b
 
     t0 = time.perf_counter()
-    with ThreadPoolExecutor(max_workers=host_cores()) as ex:
+    with ThreadPoolExecutor(max_workers=threads or host_cores()) as ex:
         wanted = list(ex.map(want, range(len(idx))))
     bad = []
     for k, f in enumerate(idx):
@@ -161,59 +189,148 @@ def sample_parity(frames, nsm, res, prm, st, shape, bits, block, preset, ms, nsa
             "seconds": time.perf_counter() - t0}
 
 
-def cpu_baseline(frames_host, bits, block, preset, ms, budget_frames_per_thread):
-    """reference CPU encoder (EncodeBlock incl. its entropy stage) on the first frames of the workload, one handle
-    per thread over disjoint frames"""
+def _run_threads(work, n):
+    ths = [threading.Thread(target=work, args=(t,)) for t in range(n)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(frames_host, bits, rate, block, preset, ms, budget_frames_per_thread):
+    """reference CPU encoder (EncodeBlock incl. its entropy stage, libs/linne_encoder/src/linne_encoder.c:594-752) on the first
+    frames of the workload, one handle per thread over disjoint frames; then the reference CPU DECODER (DecodeBlock,
+    libs/linne_decoder/src/linne_decoder.c:564-668) over the blocks the encoder just wrote, again one handle per thread.
+    Returns (encode record, decode record or None, the blocks thread 0 wrote in order -- used by the block-at-a-time leg)."""
     import ctypes as C
-    from linne_amd.api import LinneApi
+    from linne_amd.api import LinneApi, _RefDecoderConfig, _RefHeader
     Oracle, REF_SO, EncodeParameter, reference_available = _checkers()
     cores = host_cores()
     F, nch, _ = frames_host.shape
     per = min(budget_frames_per_thread, max(1, F // cores))
     total = per * cores
-    if reference_available():
-        api = LinneApi(REF_SO)
-        kind = "reference"
-
-        def work(t):
-            enc = api.new_encoder(nch, bits, 44100, block, preset, ms)
-            out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
-            osz = C.c_uint32(0)
-            for f in range(t * per, (t + 1) * per):
-                ptrs = (C.POINTER(C.c_int32) * nch)(*[frames_host[f, ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
-                r = api.L.LINNEEncoder_EncodeBlock(enc, ptrs, block, out.ctypes.data, out.size, C.byref(osz))
-                assert r == 0
-            api.L.LINNEEncoder_Destroy(enc)
-
-        ths = [threading.Thread(target=work, args=(t,)) for t in range(cores)]
-        t0 = time.perf_counter()
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-        dt = time.perf_counter() - t0
-    else:
+    if not reference_available():
         o = Oracle()
-        kind = "port"
-        p = EncodeParameter(nch, bits, 44100, block, preset, int(ms))
+        p = EncodeParameter(nch, bits, rate, block, preset, int(ms))
         sub = np.ascontiguousarray(frames_host[:total])
         nbytes = C.c_uint64(0)
         dt = o.L.oracle_bench_encode(C.byref(p), sub.ctypes.data, total, cores, C.byref(nbytes))
-    single = None
-    if kind == "reference":                          # one core, a few frames: the per-core rate the speed-up is usually quoted against
-        n1 = min(per, 24)
-        enc = api.new_encoder(nch, bits, 44100, block, preset, ms)
+        return ({"value": total / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                 "sample": f"{total} full {nch}-channel frames of the same track ({per} per thread, {dt:.1f} s wall), EncodeBlock incl. entropy stage",
+                 "single_core_frames_per_s": None}, None, None)
+    api = LinneApi(REF_SO)
+    L = api.L
+    blocks = [None] * total
+
+    def enc_work(t):
+        enc = api.new_encoder(nch, bits, rate, block, preset, ms)
         out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
         osz = C.c_uint32(0)
-        t1 = time.perf_counter()
-        for f in range(n1):
-            ptrs = (C.POINTER(C.c_int32) * nch)(*[frames_host[f, ch].ctypes.data_as(C.POINTER(C.c_int32)) for ch in range(nch)])
-            assert api.L.LINNEEncoder_EncodeBlock(enc, ptrs, block, out.ctypes.data, out.size, C.byref(osz)) == 0
-        single = n1 / (time.perf_counter() - t1)
-        api.L.LINNEEncoder_Destroy(enc)
-    return {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": kind,
-            "sample": f"{total} full {nch}-channel frames of the same track ({per} per thread, {dt:.1f} s wall), EncodeBlock incl. entropy stage",
-            "single_core_frames_per_s": single}
+        for f in range(t * per, (t + 1) * per):
+            r = L.LINNEEncoder_EncodeBlock(enc, _ptrs(C, frames_host[f], nch), block, out.ctypes.data, out.size, C.byref(osz))
+            assert r == 0
+            blocks[f] = out[:osz.value].copy()
+        L.LINNEEncoder_Destroy(enc)
+
+    dt = _run_threads(enc_work, cores)
+    # one core, a few frames: the per-core rate the speed-up is usually quoted against
+    n1 = min(per, 24)
+    enc = api.new_encoder(nch, bits, rate, block, preset, ms)
+    out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
+    osz = C.c_uint32(0)
+    t1 = time.perf_counter()
+    for f in range(n1):
+        assert L.LINNEEncoder_EncodeBlock(enc, _ptrs(C, frames_host[f], nch), block, out.ctypes.data, out.size, C.byref(osz)) == 0
+    single = n1 / (time.perf_counter() - t1)
+    L.LINNEEncoder_Destroy(enc)
+    enc_rec = {"value": total / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
+               "sample": f"{total} full {nch}-channel frames of the same track ({per} per thread, {dt:.1f} s wall), EncodeBlock incl. entropy stage",
+               "single_core_frames_per_s": single}
+
+    # ---- the decoder, on what the encoder wrote
+    hdr = _RefHeader(1, 2, nch, total * block, rate, bits, block, preset, int(ms))
+    reps = 6
+    ok = [True] * cores
+
+    def dec_work(t, first=None, count=None, nrep=reps):
+        cfg = _RefDecoderConfig(nch, 5, 128, 1)
+        dec = L.LINNEDecoder_Create(C.byref(cfg), None, 0)
+        assert dec and L.LINNEDecoder_SetHeader(dec, C.byref(hdr)) == 0
+        back = np.zeros((nch, block), dtype=np.int32)
+        bp = _ptrs(C, back, nch)
+        dsz, dn = C.c_uint32(0), C.c_uint32(0)
+        f0 = t * per if first is None else first
+        cnt = per if count is None else count
+        for rep in range(nrep):
+            for f in range(f0, f0 + cnt):
+                b = blocks[f]
+                if L.LINNEDecoder_DecodeBlock(dec, b.ctypes.data, b.size, bp, nch, block, C.byref(dsz), C.byref(dn)) != 0 or dn.value != block:
+                    ok[t] = False
+                elif rep == 0 and not np.array_equal(back, frames_host[f]):
+                    ok[t] = False
+        L.LINNEDecoder_Destroy(dec)
+
+    ddt = _run_threads(dec_work, cores)
+    n1d = min(per, 128)
+    t1 = time.perf_counter()
+    dec_work(0, 0, n1d, 2)
+    dsingle = 2 * n1d / (time.perf_counter() - t1)
+    dec_rec = {"value": total * reps / ddt, "unit": "frames/s", "cores": cores, "kind": "reference",
+               "sample": f"the {total} blocks the reference encoder wrote for cpu_baseline, {reps} passes ({per} blocks per thread, {ddt:.1f} s wall), "
+                         "DecodeBlock incl. CRC check and entropy stage", "single_core_frames_per_s": dsingle, "bit_exact": all(ok)}
+    return enc_rec, dec_rec, blocks[:per]
+
+
+def block_at_a_time(frames_host, bits, rate, block, preset, ms, ref_blocks, nblocks=96, warm=8):
+    """per-call latency of the reference's own consumers' path: LINNEEncoder_EncodeBlock (tools/linne_codec/linne_codec.c:133-161)
+    and LINNEDecoder_DecodeBlock (tools/linne_player/linne_player.c:66-118 calls it from an audio callback) of liblinne_amd.so, one
+    block per call, host planes in, bytes out and back -- synchronous, PCIe and the host entropy stage included"""
+    import ctypes as C
+    from linne_amd.api import LinneApi, _RefDecoderConfig, _RefHeader
+    api = LinneApi(linne_amd.LIB_PATH)
+    L = api.L
+    F, nch, _ = frames_host.shape
+    nblocks = min(nblocks, F)
+    enc = api.new_encoder(nch, bits, rate, block, preset, ms)
+    out = np.zeros(nch * block * 8 + 65536, dtype=np.uint8)
+    osz = C.c_uint32(0)
+    mine = []
+    for f in range(min(warm, nblocks)):     # the first calls create the GPU context and size its buffers
+        assert L.LINNEEncoder_EncodeBlock(enc, _ptrs(C, frames_host[f], nch), block, out.ctypes.data, out.size, C.byref(osz)) == 0
+    L.LINNEEncoder_Destroy(enc)
+    enc = api.new_encoder(nch, bits, rate, block, preset, ms)          # (a fresh handle: the stream's blocks from its first on)
+    t0 = time.perf_counter()
+    for f in range(nblocks):
+        assert L.LINNEEncoder_EncodeBlock(enc, _ptrs(C, frames_host[f], nch), block, out.ctypes.data, out.size, C.byref(osz)) == 0
+        mine.append(out[:osz.value].copy())
+    enc_ms = (time.perf_counter() - t0) / nblocks * 1e3
+    L.LINNEEncoder_Destroy(enc)
+    same = None
+    if ref_blocks:
+        k = min(len(ref_blocks), nblocks)
+        same = all(np.array_equal(mine[f], ref_blocks[f]) for f in range(k))
+    hdr = _RefHeader(1, 2, nch, nblocks * block, rate, bits, block, preset, int(ms))
+    cfg = _RefDecoderConfig(nch, 5, 128, 1)
+    dec = L.LINNEDecoder_Create(C.byref(cfg), None, 0)
+    assert dec and L.LINNEDecoder_SetHeader(dec, C.byref(hdr)) == 0
+    back = np.zeros((nch, block), dtype=np.int32)
+    bp = _ptrs(C, back, nch)
+    dsz, dn = C.c_uint32(0), C.c_uint32(0)
+    ok = True
+    for f in range(min(warm, nblocks)):
+        assert L.LINNEDecoder_DecodeBlock(dec, mine[f].ctypes.data, mine[f].size, bp, nch, block, C.byref(dsz), C.byref(dn)) == 0
+    t0 = time.perf_counter()
+    for f in range(nblocks):
+        r = L.LINNEDecoder_DecodeBlock(dec, mine[f].ctypes.data, mine[f].size, bp, nch, block, C.byref(dsz), C.byref(dn))
+        ok = ok and r == 0 and np.array_equal(back, frames_host[f])
+    dec_ms = (time.perf_counter() - t0) / nblocks * 1e3
+    L.LINNEDecoder_Destroy(dec)
+    return {"encode_ms": enc_ms, "decode_ms": dec_ms, "reference_encode_ms": None, "reference_decode_ms": None, "blocks": nblocks,
+            "decode_bit_exact": bool(ok), "bytes_equal_reference_encodeblock": same,
+            "what": f"LINNEEncoder_EncodeBlock / LINNEDecoder_DecodeBlock of liblinne_amd.so, one {nch}-channel block of {block} samples per call "
+                    "(host planes -> block bytes -> host planes; decode_ms includes the comparison with the input); reference_* = the reference on one host core"}
 
 
 def end_to_end(x_host, bits, rate, block, preset, ms):
@@ -247,7 +364,6 @@ def end_to_end(x_host, bits, rate, block, preset, ms):
                "host_threads": host_cores(), "note": "host planes -> .lnn -> host planes through the 13-symbol API; includes PCIe and the host entropy stage"}
     L.LINNEEncoder_Destroy(enc); L.LINNEDecoder_Destroy(dec)
     return res
-
 
 
 def leg_direct_h2d(ctx, shape, frames, nsm, res_ref, steps, chunk_frames, barrier, world, red):
@@ -306,20 +422,28 @@ def leg_direct_h2d(ctx, shape, frames, nsm, res_ref, steps, chunk_frames, barrie
             "what": "pinned host PCM -> H2D -> encode hot path -> D2H residual+params+stats, per GPU on its own PCIe link, double-buffered"}
 
 
-def leg_rccl(dist, ctx, shape, frames, nsm, res_ref, prm_ref, steps, chunk_frames, barrier, world, rank, red):
-    """Transport "rccl": north_star's N > 1 data path.  Rank 0 holds the whole batch (world x this rank's track) in its HBM;
-    chunks of frames go round-robin to the ranks by RCCL point-to-point send / recv (batched: ncclGroupStart ... ncclGroupEnd),
-    every rank analyses its chunks, residual + params + stats come back the same way (linne_amd.sharding.ChunkExchange,
-    software-pipelined: the links work while the kernels run).  Whole-job frames/s incl. scatter and gather."""
+def leg_exchange(dist, group, ctx, shape, frames, nsm, res_ref, prm_ref, steps, chunk_frames, barrier, world, rank, red):
+    """Transport "scatter / gather": north_star's N > 1 data path.  Rank 0 holds the whole batch (world x this rank's track) in its
+    HBM; chunks of frames go round-robin to the ranks by point-to-point send / recv on `group` (RCCL: batched, ncclGroupStart ...
+    ncclGroupEnd; a gloo group only in one-GPU rehearsals, where every transfer is staged through host copies), every rank analyses
+    its chunks, residual + params + stats come back the same way (linne_amd.sharding.ChunkExchange, software-pipelined: the links
+    work while the kernels run; waits are stream waits, the host never blocks on a transfer).  Whole-job frames/s incl. scatter and
+    gather.  The record says which backend really moved the bytes."""
     from linne_amd.sharding import ChunkExchange
     F, nch, S = frames.shape
     dev = frames.device
     Ftot = F * world
     nsm_all = np.tile(nsm, world)
-    ex = ChunkExchange(dist if world > 1 else None, Ftot, chunk_frames, [((nch, S), torch.int32)],
-                       [((nch, S), torch.int32), ((nch, linne_amd.PARAM_WORDS), torch.int32), ((nch, linne_amd.STAT_WORDS), torch.float64)], dev, root=0)
+    backend = dist.get_backend(group)
+    if backend == "nccl":           # the whole-group communicator comes up here, inside this leg's deadline
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize()
+        assert int(t.item()) == world
+    ex = ChunkExchange(dist, Ftot, chunk_frames, [((nch, S), torch.int32)],
+                       [((nch, S), torch.int32), ((nch, linne_amd.PARAM_WORDS), torch.int32), ((nch, linne_amd.STAT_WORDS), torch.float64)], dev, root=0, group=group)
     if rank == 0:
-        all_pcm = frames.repeat(world, 1, 1) if world > 1 else frames
+        all_pcm = frames.repeat(world, 1, 1)
         outs = [torch.empty((Ftot, nch, S), dtype=torch.int32, device=dev), torch.zeros((Ftot, nch, linne_amd.PARAM_WORDS), dtype=torch.int32, device=dev),
                 torch.zeros((Ftot, nch, linne_amd.STAT_WORDS), dtype=torch.float64, device=dev)]
         ins = [all_pcm]
@@ -340,12 +464,100 @@ def leg_rccl(dist, ctx, shape, frames, nsm, res_ref, prm_ref, steps, chunk_frame
     barrier()
     dt = red(time.perf_counter() - t0)
     moved = (ex.bytes_per_frame_out + ex.bytes_per_frame_back) * Ftot * (world - 1) / max(1, world)
-    return {"frames_per_s": Ftot * steps / dt, "ms_per_step": dt / steps * 1e3, "rccl_ranks": world, "chunk_frames": chunk_frames,
-            "chunks_per_step": len(ex.chunks), "root_link_gb_per_s": moved * steps / dt / 1e9, "results_equal_resident_path": same,
-            "what": "rank 0's HBM -> ncclSend/ncclRecv scatter of int32 [chunk][C][S] -> encode hot path on every rank -> gather of residual+params+stats to rank 0; pipelined"}
+    via = "RCCL ncclSend / ncclRecv over xGMI, device memory to device memory" if backend == "nccl" else f"{backend} with every transfer staged through host copies (a REHEARSAL of the schedule, not an RCCL measurement)"
+    return {"frames_per_s": Ftot * steps / dt, "ms_per_step": dt / steps * 1e3, "ranks": world, "backend": backend, "staged_through_host": bool(ex.stage_through_host),
+            "chunk_frames": chunk_frames, "chunks_per_step": len(ex.chunks), "root_link_gb_per_s": moved * steps / dt / 1e9, "results_equal_resident_path": same,
+            "what": f"rank 0's HBM -> scatter of int32 [chunk][C][S] -> encode hot path on every rank -> gather of residual+params+stats to rank 0; pipelined; {via}"}
 
 
-def main():
+class Guard:
+    """The one JSON line and the deadlines of the optional legs.  run(name, seconds, fn) returns fn()'s record, {"error": ...} if
+    it raised; if it has not returned after `seconds`, a watchdog thread records the timeout, prints the line (rank 0) and ends
+    the process -- the legs behind a hung one are not run, the headline in front of it is never lost."""
+
+    def __init__(self, rank):
+        self.rank, self.line, self.lock, self.printed, self.exit_code = rank, None, threading.Lock(), False, 0
+
+    def emit(self):
+        with self.lock:
+            if self.printed:
+                return
+            self.printed = True
+            if self.rank == 0 and self.line is not None:
+                print(json.dumps(self.line), flush=True)
+
+    def run(self, name, seconds, fn, on_timeout=None):
+        done = threading.Event()
+
+        def watch():
+            if done.wait(seconds):
+                return
+            rec = {"error": f"timed out after {seconds} s (cut off by the watchdog; the legs behind it were not run)"}
+            if self.line is not None:
+                if on_timeout is not None:
+                    on_timeout(rec)
+                else:
+                    self.line[name] = rec
+                self.line.setdefault("legs_timed_out", []).append(name)
+            self.emit()
+            sys.stderr.write(f"bench.py rank {self.rank}: leg {name} hung; exiting\n")
+            sys.stderr.flush()
+            os._exit(self.exit_code)
+
+        threading.Thread(target=watch, daemon=True).start()
+        try:
+            out = fn()
+        except Exception as exc:
+            out = {"error": repr(exc)}
+        done.set()
+        return out
+
+
+def launch(n, argv, script=None):
+    """`python bench.py --gpus N` with no launcher around it: N child processes, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR=127.0.0.1 / MASTER_PORT in their environment), started by this parent, which makes no GPU call and never
+    replaces itself.  Rank 0's JSON line goes straight to our stdout.  Exit code: the first failing child's; when one fails the
+    others get 30 s to finish and are then killed by PID."""
+    import signal
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=env))
+
+    def stop(signum, _frame):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, stop)
+    signal.signal(signal.SIGINT, stop)
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            c = p.poll()
+            if c not in (None, 0) and rc == 0:
+                rc, deadline = c, time.time() + 30
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            deadline = None
+        time.sleep(0.2)
+    for p in procs:
+        if p.returncode and rc == 0:
+            rc = p.returncode
+    return rc
+
+
+def parse_args(argv):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -361,14 +573,33 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the EncodeWhole/DecodeWhole leg on host buffers (it launches smaller "
                     "batches: skip it when collecting the per-kernel rocprof summary of the timed region)")
     ap.add_argument("--no-sample-parity", action="store_true", help="skip the sampled comparison of the timed batch's output with the CPU reference")
+    ap.add_argument("--no-block-at-a-time", action="store_true", help="skip the EncodeBlock / DecodeBlock per-call latency leg")
     ap.add_argument("--tracks-total", type=int, default=0, help="STRONG scaling: this many tracks in the whole job, split evenly over the GPUs "
                     "(BASELINE configs[3]: --tracks-total 1024 --minutes 3); overrides --tracks")
     ap.add_argument("--no-transports", action="store_true", help="skip the transport legs (direct per-GPU H2D/D2H; RCCL scatter/gather from rank 0)")
     ap.add_argument("--chunk-frames", type=int, default=0, help="frames per pipeline chunk of the transport legs (default: a quarter of the shard)")
     ap.add_argument("--tracks", type=int, default=1, help="tracks per GPU in ONE batch, each --minutes long with its own ragged tail "
                     "(BASELINE configs[3]: --tracks 1024 --minutes 3 on 8 GPUs = 128 per GPU)")
-    args = ap.parse_args()
+    ap.add_argument("--leg-seconds", type=float, default=60.0, help="deadline of an optional leg (the CPU baselines and the end-to-end leg get twice as long)")
+    return ap.parse_args(argv)
 
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            sys.exit(launch(args.gpus, argv))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={os.environ['WORLD_SIZE']}: start it as `python bench.py --gpus N` "
+                 "(it starts the ranks itself) or under torch.distributed.run with --nproc-per-node equal to --gpus")
+    worker(args)
+
+
+def worker(args):
+    _load()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -377,24 +608,29 @@ def main():
     local = local % ndev                    # (rehearsals on a one-GPU box put several ranks on the same device)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    backend = os.environ.get("BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm; "gloo" only for one-GPU rehearsals
-    dist = None
+    backend = os.environ.get("BENCH_BACKEND", "nccl")       # the transfers' backend: "nccl" is RCCL on ROCm; "gloo" only for one-GPU rehearsals
+    guard = Guard(rank)
+    dist, xgroup, xgroup_err = None, None, None
     if world > 1:
         import datetime
         import torch.distributed as dist
-        tmo = datetime.timedelta(seconds=300)            # a transport leg that hangs becomes an error, not a dead job:
-        os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "1")           # wait() raises at the timeout instead of the watchdog
-        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")    # tearing the process down (the legs are in try / except)
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the container's hostname may not resolve
+        # control plane (barriers, MAX of the times, agreement flags): gloo over 127.0.0.1 -- nothing the headline needs rides on RCCL
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=240))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev, timeout=tmo)
+            try:            # the communicator itself comes up lazily, inside the exchange leg's deadline
+                xgroup = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+            except Exception as exc:
+                xgroup_err = repr(exc)
         else:
-            dist.init_process_group(backend=backend, timeout=tmo)
+            xgroup = dist.group.WORLD
     scaling = "weak"
     if args.tracks_total:
         assert args.tracks_total % world == 0, "--tracks-total must be a multiple of the GPU count"
         args.tracks = args.tracks_total // world
         scaling = "strong"
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    L = args.leg_seconds
 
     nch, bits, block, rate, ms = args.channels, args.bits, 10240, args.rate, args.channels >= 2
     ns_total = int(round(args.minutes * 60 * rate))
@@ -416,9 +652,24 @@ def main():
     work = torch.empty_like(frames)
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def red_max(v):
+        if world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
+
+    def all_ok(flag):
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0])
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     def encode_step():
         ctx.encode_frames(shape, frames, nsm, out=(res, prm, st))
@@ -443,7 +694,7 @@ def main():
                 kern_ms[k] += m
                 kern_launches[k] += ctx.last_launches(k)
     barrier()
-    enc_s = time.perf_counter() - t0
+    enc_s = red_max(time.perf_counter() - t0)
     ctx.enable_timing(False)
 
     # decode: warm-up, then K timed steps
@@ -455,105 +706,77 @@ def main():
     for _ in range(args.steps):
         decode_step()
         torch.cuda.synchronize()
-        for k in (11, 12):
+        for k in DECODE_KINDS:
             m = ctx.last_ms(k)
             if m > 0:
                 kern_ms[k] += m
                 kern_launches[k] += ctx.last_launches(k)
     barrier()
-    dec_s = time.perf_counter() - t0
+    dec_s = red_max(time.perf_counter() - t0)
     ctx.enable_timing(False)
+    ok = all_ok(ok)
+    if not ok:
+        guard.exit_code = 2
 
-    if world > 1:
-        tt = torch.tensor([enc_s, dec_s], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        enc_s, dec_s = float(tt[0]), float(tt[1])
-        okt = torch.tensor([1 if ok else 0], device=red_dev)
-        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-        ok = bool(okt.item())
-
-    def red_max(v):
-        if world == 1:
-            return v
-        t = torch.tensor([v], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t[0])
-
-    transports = None
-    if not args.no_transports:
-        transports = {}
-        chunk = args.chunk_frames or (F + 3) // 4
-        tsteps = max(1, min(args.steps, 3))
-        try:
-            transports["direct_h2d"] = leg_direct_h2d(ctx, shape, frames, nsm, res, tsteps, chunk, barrier, world, red_max)
-        except Exception as exc:
-            transports["direct_h2d"] = {"error": repr(exc)}
-        if world > 1:
-            try:
-                transports["rccl_scatter_gather"] = leg_rccl(dist, ctx, shape, frames, nsm, res, prm, tsteps, chunk, barrier, world, rank, red_max)
-            except Exception as exc:
-                transports["rccl_scatter_gather"] = {"error": repr(exc)}
-        torch.cuda.empty_cache()
-
+    # ---- the line: everything the timed regions gave; the legs below fill in the rest
     if rank == 0:
         total_frames = F * world * args.steps
         enc_fps = total_frames / enc_s
         dec_fps = total_frames / dec_s
-        # dominant encode kernel: roofline against HBM with ALGORITHMIC bytes (DESIGN.md "Measurement")
-        dom = max([k for k in ENCODE_KINDS if k != 13], key=lambda k: kern_ms[k])      # k_stats (13) runs beside the analysis
-        launches = max(1, kern_launches[dom])
-        avg_ms = kern_ms[dom] / launches
-        # one launch of a per-layer kernel serves one chunk of frames for one layer; price it on the channel-frames
-        # of its chunk: all steps together processed F*nch*steps channel-frames in launches/(layers) chunk-launches
-        nlayers = len(linne_amd.PRESET_LAYERS[args.preset])
         layers = linne_amd.PRESET_LAYERS[args.preset]
+        nlayers = len(layers)
         n_big = sum(1 for P in layers if P >= 32)
-        # timed spans of one kind per frame group: per-layer kernels have one span per layer they serve
-        launches_per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2), 16: 1, 21: n_big, 22: n_big, 23: n_big}.get(dom, 1)
-        chunk_launches = launches / launches_per_chunk
-        cf_per_launch = F * nch * args.steps / chunk_launches
-        # a per-layer kernel of one layer carries that layer's share; report the whole-kernel view: bytes of the
-        # channel-frames one launch processes / its duration
-        achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
+        pmc, pmc_src = {}, None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
             try:
-                per_cf = json.load(open(pmc)).get(KERNEL_KINDS[dom], {}).get("hbm_bytes_per_channel_frame_per_launch")
-                traffic = per_cf * cf_per_launch if per_cf else None
+                pmc = json.load(open(pmc_path))
+                pmc_src = "profiles/pmc_latest.json (committed file, NOT measured in this run): " + str(pmc.get("_source", ""))
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": KERNEL_KINDS[dom], "avg_launch_ms": avg_ms, "launches": launches,
-                    "channel_frames_per_launch": cf_per_launch,
-                    "note": "algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64"}
+                pmc = {}
+
+        def roof(kinds, exclude=()):
+            """dominant kernel of `kinds` by summed HIP-event time: algorithmic bytes of the channel-frames one launch processes /
+            its average duration, against the HBM peak (DESIGN.md "Measurement")"""
+            cand = [k for k in kinds if k not in exclude and kern_ms[k] > 0]
+            if not cand:
+                return None
+            dom = max(cand, key=lambda k: kern_ms[k])
+            launches = max(1, kern_launches[dom])
+            avg_ms = kern_ms[dom] / launches
+            # timed spans of one kind per chunk of frames: per-layer kernels have one span per layer they serve
+            per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2),
+                         16: 1, 21: n_big, 22: n_big, 23: n_big, 28: n_big, 29: nlayers - n_big}.get(dom, 1)
+            cf_per_launch = F * nch * args.steps / (launches / per_chunk)
+            achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
+            per_cf = (pmc.get(KERNEL_KINDS[dom]) or {}).get("hbm_bytes_per_channel_frame_per_launch")
+            return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": per_cf * cf_per_launch if per_cf else None, "traffic_source": pmc_src if per_cf else None,
+                    "kernel": KERNEL_KINDS[dom], "avg_launch_ms": avg_ms, "launches": launches, "channel_frames_per_launch": cf_per_launch}
+
+        roofline = roof(ENCODE_KINDS, exclude=(13,))            # k_stats (13) runs beside the analysis
+        if roofline:
+            roofline["note"] = "algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64"
+        whole = (pmc.get("_whole_step") or {})
+        if roofline and whole.get("encode_hbm_bytes_per_channel_frame"):
+            roofline["whole_step_traffic_per_channel_frame"] = whole["encode_hbm_bytes_per_channel_frame"]
+            roofline["whole_step_traffic_over_algorithmic"] = whole["encode_hbm_bytes_per_channel_frame"] / ALGO_BYTES_PER_CF
+        roofline_decode = roof(DECODE_KINDS)
+        if roofline_decode:
+            roofline_decode["note"] = ("algorithmic bytes = 82552 B per channel-frame (residual in, PCM out, parameters); the synthesis is one dependent "
+                                       "recurrence per channel-frame: latency bound")
+            if whole.get("decode_hbm_bytes_per_channel_frame"):
+                roofline_decode["whole_step_traffic_per_channel_frame"] = whole["decode_hbm_bytes_per_channel_frame"]
         cf_per_s = enc_fps * nch / world        # per GPU
         valu = {"executed_tflops": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12, "reference_equiv_tflops": 2 * MAC_PER_CF_REFERENCE * cf_per_s / 1e12,
                 "peak_fma_tflops": FP64_PEAK_TFLOPS, "frac_of_unfused_peak": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / (FP64_PEAK_TFLOPS / 2),
                 "measured_unfused_mul_add_tflops": FP64_UNFUSED_MEASURED_TFLOPS,
                 "frac_of_measured_unfused": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / FP64_UNFUSED_MEASURED_TFLOPS,
                 "note": "values that reach the stream may not fuse multiply and add (the certified search may); tools/ubench/dp_rate.hip "
-                        "sustains 32.4 TFLOP/s of unfused FP64 mul+add on this GPU (profiles/r01_dp_rate.txt), 63 with FMA"}
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))
-            cpu = cpu_baseline(frames[:nf].cpu().numpy(), bits, block, args.preset, ms, args.cpu_frames_per_thread)
-        e2e = None
-        parity = None
-        if not args.no_sample_parity and world == 1:
-            try:
-                parity = sample_parity(frames, nsm, res, prm, st, shape, bits, block, args.preset, ms)
-            except Exception as exc:
-                parity = {"ok": False, "error": repr(exc)}
-        if not args.no_end_to_end and world == 1 and args.tracks == 1:
-            try:
-                x_host = np.ascontiguousarray(frames.permute(1, 0, 2).reshape(nch, -1)[:, :ns_total].cpu().numpy())
-                e2e = end_to_end(x_host, bits, rate, block, args.preset, ms)
-                del x_host
-            except Exception as exc:                 # the hot-path numbers above do not depend on it
-                e2e = {"error": repr(exc)}
+                        "sustains 32.4 TFLOP/s of unfused FP64 mul+add on this GPU (profiles/r01_dp_rate.txt), 63 with FMA; the multiply-add "
+                        "count per channel-frame is DESIGN.md's figure for -m 7 (a constant, not a counter)"} if args.preset == 7 else None
         breakdown = {KERNEL_KINDS[k]: round(kern_ms[k] / args.steps, 3) for k in KERNEL_KINDS if kern_ms[k] > 0}
-        line = {
+        guard.line = {
             "metric": "frames/sec encode (-m 7) + decode, 44.1 kHz stereo, bit-exact; 1/2/4/8 GPU",
             "value": enc_fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": enc_s / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
@@ -561,28 +784,116 @@ def main():
             "config": {"workload": f"encode -m {args.preset}: {args.tracks} x {args.minutes:g} min {rate / 1000:g} kHz int{bits} {nch}-channel per GPU = {F} frames of {block} samples "
                                    f"(tail {int(nsm[-1])}), MS {'on' if ms else 'off'}, PCM resident in HBM; decode = inverse hot path on the encode output",
                        "frames_per_gpu": F, "channels": nch, "preset": args.preset, "tracks_per_gpu": args.tracks, "sharding": f"{world * args.tracks} independent track(s), {args.tracks} per GPU"},
+            "ranks": world, "control_backend": "gloo" if world > 1 else None, "transfer_backend": (backend if world > 1 else None),
             "decode_frames_per_s": dec_fps, "decode_ms_per_step": dec_s / args.steps * 1e3, "decode_bit_exact": ok,
-            "encode_sample_parity": (parity or {}).get("ok"), "encode_sample_parity_detail": parity,
+            "encode_sample_parity": None, "encode_sample_parity_detail": None,
             "encode_channel_frames_per_s": enc_fps * nch,
             "kernel_ms_per_step": breakdown,
-            "roofline": roofline, "valu_f64": valu, "cpu_baseline": cpu, "end_to_end_api": e2e,
-            "transports": transports,
+            "roofline": roofline, "roofline_decode": roofline_decode, "valu_f64": valu, "cpu_baseline": None, "cpu_baseline_decode": None,
+            "block_at_a_time": None, "end_to_end_api": None, "transports": None,
             "transports_note": "value = the hot path with every rank's shard resident in its own HBM (contract: inputs resident when the timed "
                                "region starts); transports = the same work with the data starting elsewhere: in pinned host memory of each rank "
                                "(direct_h2d) or in rank 0's HBM (rccl_scatter_gather, N > 1), transfers inside the timed region",
         }
-        if cpu:
+    line = guard.line
+
+    # ---- leg: sampled parity against the CPU reference, on EVERY rank's own shard
+    if not args.no_sample_parity:
+        small = world > 1
+        par = guard.run("encode_sample_parity_detail", L, lambda: sample_parity(
+            frames, nsm, res, prm, st, shape, bits, block, args.preset, ms, nedge=8 if small else 64, nsample_mid=16 if small else 128,
+            threads=max(1, host_cores() // world) if small else None, seed=12345 + rank))
+        mine_ok = bool(par.get("ok"))
+        everyone = guard.run("encode_sample_parity_agreement", L, lambda: {"ok": all_ok(mine_ok)})
+        if rank == 0:
+            line["encode_sample_parity"] = bool(everyone.get("ok"))
+            if world > 1:
+                par["ranks_checked"] = world
+                par["what"] = par.get("what", "") + f"; every rank checked {par.get('frames_compared')} frames of its own shard, verdicts AND-reduced"
+            line["encode_sample_parity_detail"] = par
+        if not everyone.get("ok"):
+            guard.exit_code = 2
+
+    # ---- legs on rank 0 at N = 1: the CPU baselines, the block-at-a-time API, the end-to-end API
+    if rank == 0 and world == 1:
+        ref_blocks = None
+        host_frames = None
+        if not args.no_cpu_baseline or not args.no_block_at_a_time:
+            nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))
+            host_frames = frames[:nf].cpu().numpy()
+        if not args.no_cpu_baseline:
+            out = guard.run("cpu_baseline", 2 * L, lambda: cpu_baseline(host_frames, bits, rate, block, args.preset, ms, args.cpu_frames_per_thread))
+            if isinstance(out, dict):
+                line["cpu_baseline"] = out
+            else:
+                line["cpu_baseline"], line["cpu_baseline_decode"], ref_blocks = out
+        if not args.no_block_at_a_time:
+            bat = guard.run("block_at_a_time", L, lambda: block_at_a_time(host_frames, bits, rate, block, args.preset, ms, ref_blocks))
+            cpu, cpud = line.get("cpu_baseline") or {}, line.get("cpu_baseline_decode") or {}
+            if "error" not in bat:
+                if cpu.get("single_core_frames_per_s"):
+                    bat["reference_encode_ms"] = 1e3 / cpu["single_core_frames_per_s"]
+                if cpud.get("single_core_frames_per_s"):
+                    bat["reference_decode_ms"] = 1e3 / cpud["single_core_frames_per_s"]
+            line["block_at_a_time"] = bat
+        del host_frames
+        if not args.no_end_to_end and args.tracks == 1:
+            def e2e():
+                x_host = np.ascontiguousarray(frames.permute(1, 0, 2).reshape(nch, -1)[:, :ns_total].cpu().numpy())
+                return end_to_end(x_host, bits, rate, block, args.preset, ms)
+            line["end_to_end_api"] = guard.run("end_to_end_api", 2 * L, e2e)
+
+    # ---- legs: the transports
+    if not args.no_transports:
+        transports = {}
+        if rank == 0:
+            line["transports"] = transports
+        chunk = args.chunk_frames or (F + 3) // 4
+        tsteps = max(1, min(args.steps, 3))
+
+        def put(name):
+            return lambda rec: transports.__setitem__(name, rec)
+
+        transports["direct_h2d"] = guard.run("transports.direct_h2d", L, lambda: leg_direct_h2d(ctx, shape, frames, nsm, res, tsteps, chunk, barrier, world, red_max),
+                                             on_timeout=put("direct_h2d"))
+        if world > 1:
+            # the exchange comes LAST: should RCCL hang, everything else is already in the line.  Every rank agrees on the outcome
+            # over the gloo group before anyone believes the record; after a failure nothing touches the RCCL group again.
+            name = "rccl_scatter_gather" if backend == "nccl" else f"{backend}_scatter_gather_rehearsal"
+            if xgroup is None:
+                rec = {"error": f"no {backend} group: {xgroup_err}"}
+            else:
+                rec = guard.run("transports." + name, 1.5 * L, lambda: leg_exchange(dist, xgroup, ctx, shape, frames, nsm, res, prm, tsteps, chunk, barrier, world, rank, red_max),
+                                on_timeout=put(name))
+            agreed = guard.run("transports." + name + ".agreement", L, lambda: {"ok": all_ok("error" not in rec)}, on_timeout=put(name))
+            if not agreed.get("ok") and "error" not in rec:
+                rec = {"error": "another rank failed or timed out in this leg", "this_rank": rec}
+            transports[name] = rec
+        torch.cuda.empty_cache()
+
+    if rank == 0:
+        cpu, e2e = line.get("cpu_baseline"), line.get("end_to_end_api")
+        if cpu and cpu.get("value"):
             # like for like: the reference's EncodeBlock starts from host memory and includes its entropy coder, so the honest
             # ratio is the drop-in API's EncodeWhole (host planes -> .lnn bytes); the HBM-resident hot path alone is given beside it
             if e2e and e2e.get("encode_whole_frames_per_s"):
                 line["speedup_end_to_end_vs_cpu_baseline"] = e2e["encode_whole_frames_per_s"] / cpu["value"]
-            line["hot_path_resident_over_cpu_encodeblock"] = enc_fps / cpu["value"]
-        print(json.dumps(line), flush=True)
+            line["hot_path_resident_over_cpu_encodeblock"] = line["value"] / cpu["value"]
+        cpud = line.get("cpu_baseline_decode")
+        if cpud and cpud.get("value"):
+            if e2e and e2e.get("decode_whole_frames_per_s"):
+                line["speedup_decode_end_to_end_vs_cpu_baseline"] = e2e["decode_whole_frames_per_s"] / cpud["value"]
+            line["decode_hot_path_resident_over_cpu_decodeblock"] = line["decode_frames_per_s"] / cpud["value"]
+    guard.emit()
     ctx.close()
     if world > 1:
-        dist.destroy_process_group()
-    if not ok or (rank == 0 and world == 1 and not args.no_sample_parity and parity is not None and not parity.get("ok")):
-        sys.exit(2)
+        # leave together; the process groups are not torn down collectively (a communicator that has seen a failed leg may hang in
+        # its destructor) -- the line is out, the processes just end
+        guard.run("final_barrier", 30, lambda: dist.barrier() or {})
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(guard.exit_code)
+    if guard.exit_code:
+        sys.exit(guard.exit_code)
 
 
 if __name__ == "__main__":

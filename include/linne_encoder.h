@@ -21,8 +21,8 @@ struct LINNEEncodeParameter {
     uint16_t num_samples_per_block;
     uint8_t preset;                                 /* 0 .. LINNE_NUM_PARAMETER_PRESETS-1 */
     LINNEChannelProcessMethod ch_process_method;
-    uint8_t enable_learning;                        /* -l : SGD refinement (not offered by this build: INVALID_FORMAT) */
-    uint8_t num_afmethod_iterations;                /* -a N: auxiliary-function refinement (N > 0 not offered: INVALID_FORMAT) */
+    uint8_t enable_learning;                        /* -l : SGD refinement of the analysed parameters (linne_network.c:805-873; on the device: lnn_k_train.h) */
+    uint8_t num_afmethod_iterations;                /* -a N: N auxiliary-function iterations in the final pass (lpc.c:578-633; on the device: lnn_k_af.h) */
 };
 
 struct LINNEEncoderConfig {

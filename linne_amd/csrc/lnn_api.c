@@ -659,8 +659,8 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     /* stream mode (the default; LINNE_AMD_DECODE_STREAM=0 turns it off): the device decodes the Rice codes
      * (LINNEAmd_SlotDecodeStreamSubmit), the host threads only scan the block headers, check the CRCs and decode the parameters.
      * Only for streams whose CRCs are checked: a block that passes is what an encoder wrote.  Should the device still meet
-     * something no encoder writes, or PCM beyond the 16-bit range, the whole call starts over with the host's Rice decoder
-     * (stream_mode = 0), which restates the reference's.  60-minute stream, one GPU, 16 host threads: 62 ms against 94 with the
+     * something no encoder writes, the whole call starts over with the host's Rice decoder (stream_mode = 0, and the host path's
+     * group size and slots), which restates the reference's; PCM beyond the 16-bit range only makes that group come back as int32.  60-minute stream, one GPU, 16 host threads: 62 ms against 94 with the
      * host's Rice decoder (profiles/r02_decode_stream.txt). */
     int stream_mode;
     { const char *e_ = getenv("LINNE_AMD_DECODE_STREAM"); stream_mode = (e_ ? atoi(e_) != 0 : 1); }
@@ -670,15 +670,19 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     hd = &decoder->header;
     if (buffer_num_channels < hd->num_channels || buffer_num_samples < hd->num_samples) return LINNE_APIRESULT_INSUFFICIENT_BUFFER;
     for (i = 0; i < hd->num_channels; i++) if (buffer[i] == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
+    if (!decoder->check_crc) stream_mode = 0;
+    g_last_decode_mode = 0;
+setup:      /* (again after the device's Rice decoder refused something: the host path gets the host path's group size and slots) */
+    for (i = 0; i < ngalloc; i++) dgroup_free(&grp[i]);
+    ngalloc = 0;
     {
         const uint32_t S = decoder->shape.num_samples_per_block;
         const uint32_t F = (uint32_t)(((uint64_t)hd->num_samples + S - 1) / S);
         /* group g of blocks goes to device g mod ndev, slot (g / ndev) mod LNN_SLOTS of that device */
         if (gp->ndev == 0) { gp->ndev = lnn_parse_device_list(getenv("LINNE_AMD_DEVICES"), gp->device, LNN_MAX_DEVICES); if (gp->ndev == 0) { const char *e = getenv("LINNE_AMD_DEVICE"); gp->device[0] = e ? atoi(e) : 0; gp->ndev = 1; } }
-        ndev = gp->ndev; window = ndev * LNN_SLOTS;
+        ndev = gp->ndev; window = ndev * LNN_SLOTS; nslots = LNN_SLOTS;
         group = default_group((F + ndev - 1) / ndev, &decoder->shape, &decoder->layers, 0); if (group > F) group = F ? F : 1;
     }
-    if (!decoder->check_crc) stream_mode = 0;
     if (stream_mode) {
         /* The device's Rice decoder and the synthesis are serial per block / per channel: a launch takes as long for 3 000 blocks as
          * for 30 000 (9 + 11 ms), so the stream goes in FEW groups -- two per device, the second one's host parsing and Rice
@@ -695,9 +699,7 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
         if (nslots > LNN_SLOTS) nslots = LNN_SLOTS;
         window = ndev * nslots;
     }
-    g_last_decode_mode = 0;
     for (ngalloc = 0; ngalloc < window; ngalloc++) if (dgroup_alloc(&grp[ngalloc], group) != 0) { ngalloc++; ret = LNN_NG; goto done; }
-restart:
     memset(&uj, 0, sizeof(uj));
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;
     off = LINNE_HEADER_SIZE; produced = 0; consumed_groups = 0; progress = 0; scanning = 1; ret = LNN_OK;
@@ -734,7 +736,7 @@ restart:
             t0 = now_s();
             if (stream_mode && sl && ncomp) {
                 g->seg_bytes = off - g->seg_first;                /* the scan above stopped at `off`: the group's bytes are [seg_first, off) */
-                if (g->seg_bytes > LINNEAmd_SlotStreamCapacity(sl)) { stream_mode = 0; g_last_decode_mode |= 2u; for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]); goto restart; }
+                if (g->seg_bytes > LINNEAmd_SlotStreamCapacity(sl)) { stream_mode = 0; g_last_decode_mode |= 2u; for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]); goto setup; }
                 uj.sstream = LINNEAmd_SlotStream(sl); uj.sbitpos = LINNEAmd_SlotBitPos(sl); uj.sbitend = LINNEAmd_SlotBitEnd(sl); uj.seg_first = g->seg_first; uj.seg_bytes = g->seg_bytes;
                 lnn_parallel_for((uint32_t)((g->seg_bytes + 1048575u) >> 20), threads, copy_segment, &uj);
             }
@@ -795,7 +797,7 @@ restart:
                     if (anomaly) {      /* not what an encoder writes: the host's decoder defines the result */
                         stream_mode = 0; g_last_decode_mode |= 2u;
                         for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]);
-                        goto restart;
+                        goto setup;
                     }
                 }
                 t0 = now_s();

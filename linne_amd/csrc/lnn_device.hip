@@ -81,6 +81,9 @@ struct LINNEAmdContext {
     int pcm16_next;                     /* the next EncodeFramesDevice call reads int16 samples (set by the staging slots, cleared by the call) */
     int force_exact;                    /* LINNE_AMD_EXACT=1: every unit-count search runs the exact ordered chains (diff against the certified search) */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
+    /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
+     * inside the chunk loop; production never sets them and gets the batch-size rules) */
+    struct { int sort, l0_products, wide, search_long, rows16, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -258,6 +261,18 @@ extern "C" int LINNEAmd_SetAfIterations(struct LINNEAmdContext *ctx, uint32_t it
     return LNN_OK;
 }
 extern "C" int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable) { if (!ctx) return LNN_INVALID_ARGUMENT; ctx->timing = enable; return LNN_OK; }
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static void read_call_knobs(LINNEAmdContext *ctx)
+{
+    ctx->knob.sort = env_int("LINNE_AMD_SORT", 1);
+    ctx->knob.l0_products = env_int("LINNE_AMD_L0_PRODUCTS", 1);
+    ctx->knob.wide = env_int("LINNE_AMD_WIDE", 1);
+    ctx->knob.search_long = env_int("LINNE_AMD_SEARCH_LONG", 1);
+    ctx->knob.rows16 = env_int("LINNE_AMD_ROWS16", 1);
+    { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
+    { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : 2); }
+    ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
+}
 /* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
 static int span_begin(LINNEAmdContext *ctx, int kind, hipStream_t st)
 {
@@ -490,8 +505,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
     ctx->na_max = 0;
     for (uint32_t k = 0; k < nlen; k++) if (ctx->sig_cls[slot_of[k]].na > ctx->na_max) ctx->na_max = ctx->sig_cls[slot_of[k]].na;
     {
-        const char *e_ = getenv("LINNE_AMD_SORT");
-        if (e_ && atoi(e_) == 0) { for (uint32_t f = 0; f < F; f++) { idx[f] = slot_of[raw[f]]; map[f] = f; } }
+        if (ctx->knob.sort == 0) { for (uint32_t f = 0; f < F; f++) { idx[f] = slot_of[raw[f]]; map[f] = f; } }
         else {
             for (uint32_t f = 0; f < F; f++) count[raw[f] + 1]++;
             for (uint32_t k = 0; k < nlen; k++) count[k + 1] += count[k];
@@ -499,19 +513,17 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
         }
     }
     {       /* short layers by products (k_autocorr_prod): all trials present and every unit length even, in every class of this call */
-        const char *e_ = getenv("LINNE_AMD_L0_PRODUCTS");
         ctx->prod_ok = 0;
         for (uint32_t l = 0; l < hs->L; l++) {
-            if (hs->P[l] > 16u || !(e_ ? atoi(e_) : 1)) continue;
+            if (hs->P[l] > 16u || !ctx->knob.l0_products) continue;
             uint32_t nt = 0; for (uint32_t u = 1; u <= hs->P[l]; u <<= 1) nt++;
             int ok = 1;
             for (uint32_t k = 0; k < nlen; k++) { const DevClass &c = ctx->sig_cls[slot_of[k]]; if (c.ntrials[l] != nt || (c.na % (1u << nt)) != 0) ok = 0; }
             if (ok) ctx->prod_ok |= 1 << l;
         }
         /* long layers by lanes = lags (k_autocorr_wide): a small batch, and every unit length of every trial a class has even */
-        const char *w_ = getenv("LINNE_AMD_WIDE");
         for (uint32_t l = 0; l < hs->L; l++) {
-            if (hs->P[l] < 32u || hs->P[l] > 128u || !(w_ ? atoi(w_) : 1) || (uint64_t)F * shape->num_channels * (l == 0 ? 1u : hs->R) > 64u) continue;
+            if (hs->P[l] < 32u || hs->P[l] > 128u || !ctx->knob.wide || (uint64_t)F * shape->num_channels * (l == 0 ? 1u : hs->R) > 64u) continue;
             int ok = 1;
             for (uint32_t k = 0; k < nlen; k++) { const DevClass &c = ctx->sig_cls[slot_of[k]]; if (c.ntrials[l] == 0 || (c.na % (1u << c.ntrials[l])) != 0) ok = 0; }
             if (ok) ctx->prod_ok |= 1 << l;
@@ -610,6 +622,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    read_call_knobs(ctx);
     if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames)) != LNN_OK) return ret;
 
     const uint32_t C = shape->num_channels, S = shape->num_samples_per_block;
@@ -678,10 +691,10 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         bool fuse_all = fuse_cfg;
         for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
         p.fused_last = fuse_cfg ? 1u : 0u;
-        { const char *e_ = getenv("LINNE_AMD_SEARCH_LONG"); p.search_long = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
-        { const char *e_ = getenv("LINNE_AMD_ROWS16"); p.rows16 = (e_ ? atoi(e_) : 1) ? 1u : 0u; }
+        p.search_long = ctx->knob.search_long ? 1u : 0u;
+        p.rows16 = ctx->knob.rows16 ? 1u : 0u;
         build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
-        { const char *e_ = getenv("LINNE_AMD_HIST"); p.hist = (e_ ? (atoi(e_) != 0) : (J >= 12288u)) ? 1u : 0u; }
+        p.hist = (ctx->knob.hist >= 0 ? (ctx->knob.hist != 0) : (J >= 12288u)) ? 1u : 0u;
         if (p.runs[1].mixed) p.hist = 0;                        /* more class runs than RowRuns holds: blocks may mix classes, which only the general kernels serve */
         bool hist_all[LNN_MAXL];                                /* per layer: every frame of the chunk is k_autocorr_hist's (host copy of hist_takes) */
         for (uint32_t l = 0; l < hs.L; l++) {
@@ -692,7 +705,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 if (!(c.ntrials[l] == nt && (c.na % (16u << (nt - 1))) == 0 && (c.na >> (nt - 1)) >= 32u)) hist_all[l] = false;
             }
         }
-        p.cls_of_frame = ctx->d_clsidx + f0; p.frame_map = ctx->d_map + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount; p.min_margin = (unsigned long long *)(ctx->d_ucount + 2); p.force_exact = ctx->force_exact ? 1u : 0u; { const char *e_ = getenv("LINNE_AMD_DBG_MAXTR"); p.dbg_maxtr = e_ ? (uint32_t)atoi(e_) : 0u; }
+        p.cls_of_frame = ctx->d_clsidx + f0; p.frame_map = ctx->d_map + f0; p.cls = ctx->d_cls; p.sintab = ctx->d_sin; p.wtab = ctx->d_wt; p.ucount = ctx->d_ucount; p.min_margin = (unsigned long long *)(ctx->d_ucount + 2); p.force_exact = ctx->force_exact ? 1u : 0u; p.dbg_maxtr = ctx->knob.dbg_maxtr;
         uint8_t *const abase = (uint8_t *)ctx->arena + (size_t)slot * part_bytes;
         uint8_t *a = abase;
 #define TAKE(ptr, type, count) do { ptr = (type *)a; a += align_up(sizeof(type) * (uint64_t)(count)); } while (0)
@@ -919,6 +932,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    read_call_knobs(ctx);
     if ((ret = upload_lengths(ctx, shape, h_num_samples, num_frames)) != LNN_OK) return ret;
     DecPlan p; memset(&p, 0, sizeof(p));
     p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
@@ -928,17 +942,17 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     {   /* layers in reverse order (linne_decoder.c:503-509): long layers one wave per channel-frame, short ones (order <= 16)
          * with lanes = channel-frames; the de-emphasis rides on layer 0's pass */
-        const int sp_ = span_begin(ctx, 11, ctx->stream);
         const uint32_t CF = num_frames * p.C, gsmall = (CF + 63) / 64;
         if (hs.P[0] > 16) { snprintf(ctx->err, sizeof(ctx->err), "internal: layer 0 of order %u", hs.P[0]); return LNN_NG; }
         /* The lanes = channel-frames kernels have few, long-running waves: a pass over a short layer takes the time of one
          * wave's 10240-step recurrence however small the batch.  Below a few thousand channel-frames the one-wave-per-
          * channel-frame kernel (all layers and the de-emphasis in one launch) finishes sooner. */
-        const char *force = getenv("LINNE_AMD_DECODE_KERNEL");          /* "wave" / "lanes": for tests and measurements */
-        const bool use_wave = force ? (strcmp(force, "wave") == 0) : (CF < 6144u);
-        if (use_wave) hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u);
+        const bool use_wave = ctx->knob.decode_kernel ? (ctx->knob.decode_kernel == 1) : (CF < 6144u);      /* LINNE_AMD_DECODE_KERNEL = "wave" / "lanes": for tests and measurements */
+        /* timing kinds: 11 = k_synthesize (all layers in one launch), 28 = k_synth_big, 29 = k_synth_small */
+        if (use_wave) { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u); span_end(ctx, sp_, ctx->stream); }
         else for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
             const bool de = (l == 0);
+            const int sp_ = span_begin(ctx, hs.P[l] <= 16u ? 29 : (hs.P[l] <= 128u && (hs.P[l] & (hs.P[l] - 1u)) == 0 ? 28 : 11), ctx->stream);
             switch (hs.P[l]) {
             case 2:  if (de) hipLaunchKernelGGL((k_synth_small<2, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<2, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
             case 4:  if (de) hipLaunchKernelGGL((k_synth_small<4, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<4, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
@@ -949,8 +963,8 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
             case 128: hipLaunchKernelGGL((k_synth_big<128>), dim3((CF + 15) / 16), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
             default: hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, (uint32_t)l, 0u); break;      /* not a preset size */
             }
+            span_end(ctx, sp_, ctx->stream);
         }
-        span_end(ctx, sp_, ctx->stream);
     }
     if (p.ms)
         { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3(num_frames, (p.S + 255) / 256), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }

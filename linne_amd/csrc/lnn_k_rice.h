@@ -356,7 +356,9 @@ __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
     /* the lane's stream is staged RDEC_CHUNK words at a time: the loads of a chunk are issued at a tile boundary and land in the
      * ring at the next one, 16 samples of work later -- every lane's loads touch lines of their own, so a load waited for on the
      * spot costs the wave a full trip to memory */
-    const uint32_t readable = (uint32_t)((((a.nbytes + 15u) & ~(uint64_t)7u)) >> 2);        /* words the caller made readable behind the data */
+    /* the contract of LINNEAmd_RiceDecodeDevice (include/linne_amd.h): the stream is readable up to the next multiple of 8 bytes.
+     * Words from r.nwords on are never loaded and read as zeros, on this path as on load()'s */
+    const uint32_t readable = r.nwords;
     uint4 inf[RDEC_CHUNK / 4];
     bool inflight = false;
     auto issue = [&]() {
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
             const uint32_t w = r.hi + 4u * k;
             uint4 v = make_uint4(0u, 0u, 0u, 0u);
             if (w + 4u <= readable) v = *(const uint4 *)(a.words + w);
-            else { if (w < readable) v.x = a.words[w]; if (w + 1u < readable) v.y = a.words[w + 1u]; if (w + 2u < readable) v.z = a.words[w + 2u]; }
+            else { if (w < readable) v.x = a.words[w]; if (w + 1u < readable) v.y = a.words[w + 1u]; if (w + 2u < readable) v.z = a.words[w + 2u]; }      /* (w + 3 >= readable here) */
             inf[k] = v;
         }
         inflight = true;

@@ -101,6 +101,7 @@ struct multi_job {
     const int32_t *pcm; int32_t *data; int32_t *params; double *stats; uint8_t *plan;
     const uint32_t *num_samples; uint32_t num_frames, group, ngroups; int for_encode;
     int ret;
+    char err[256];                       /* this device's message; multi_run copies the first failing device's into m->err after the joins */
 };
 
 static void *multi_worker(void *arg)
@@ -115,7 +116,7 @@ static void *multi_worker(void *arg)
     for (g = d; g < j->ngroups; g += G) mine++;
     if (!j->num_samples) {                                   /* every frame full */
         uint32_t f;
-        if (!(full = malloc(sizeof(uint32_t) * j->group))) { j->ret = LNN_NG; return NULL; }
+        if (!(full = malloc(sizeof(uint32_t) * j->group))) { j->ret = LNN_NG; snprintf(j->err, sizeof(j->err), "device %d: out of host memory", m->device[d]); return NULL; }
         for (f = 0; f < j->group; f++) full[f] = S;
     }
     j->ret = LNN_OK;
@@ -132,14 +133,14 @@ static void *multi_worker(void *arg)
                 memcpy(LINNEAmd_SlotParams(sl), j->params + (uint64_t)base * C * LINNE_AMD_PARAM_WORDS, pb * cnt);
                 j->ret = LINNEAmd_SlotDecodeSubmit(sl, ns, cnt);
             }
-            if (j->ret != LNN_OK) snprintf(m->err, sizeof(m->err), "device %d: %s", m->device[d], LINNEAmd_GetLastError(m->ctx[d]));
+            if (j->ret != LNN_OK) snprintf(j->err, sizeof(j->err), "device %d: %s", m->device[d], LINNEAmd_GetLastError(m->ctx[d]));
             submitted++;
         }
         if (j->ret != LNN_OK) break;
         {
             struct LINNEAmdSlot *sl = m->slot[d][done % MULTI_SLOTS];
             const uint32_t base = (d + done * G) * j->group, cnt = (j->num_frames - base < j->group) ? (j->num_frames - base) : j->group;
-            if ((j->ret = LINNEAmd_SlotWait(sl)) != LNN_OK) { snprintf(m->err, sizeof(m->err), "device %d: %s", m->device[d], LINNEAmd_GetLastError(m->ctx[d])); break; }
+            if ((j->ret = LINNEAmd_SlotWait(sl)) != LNN_OK) { snprintf(j->err, sizeof(j->err), "device %d: %s", m->device[d], LINNEAmd_GetLastError(m->ctx[d])); break; }
             memcpy(j->data + (uint64_t)base * C * S, LINNEAmd_SlotData(sl), fb * cnt);
             if (j->for_encode) {
                 memcpy(j->params + (uint64_t)base * C * LINNE_AMD_PARAM_WORDS, LINNEAmd_SlotParams(sl), pb * cnt);
@@ -185,6 +186,7 @@ static int multi_run(struct LINNEAmdMulti *m, const struct LINNEAmdShape *shape,
         for (i = 0; i < MULTI_SLOTS && i < mine; i++)
             if (!m->slot[d][i] && !(m->slot[d][i] = LINNEAmd_SlotCreate(m->ctx[d], shape, m->slot_frames, for_encode))) {
                 snprintf(m->err, sizeof(m->err), "device %d: SlotCreate: %s", m->device[d], LINNEAmd_GetLastError(m->ctx[d]));
+                multi_drop_slots(m);                        /* no half-created set stays behind: the next call starts from nothing */
                 return LNN_NG;
             }
     }
@@ -194,12 +196,12 @@ static int multi_run(struct LINNEAmdMulti *m, const struct LINNEAmdShape *shape,
         j->m = m; j->dev = d; j->shape = shape; j->pcm = pcm; j->data = data; j->params = params; j->stats = stats; j->plan = plan;
         j->num_samples = num_samples; j->num_frames = num_frames; j->group = group; j->ngroups = ngroups; j->for_encode = for_encode;
         if (d + 1 == m->ndev) break;                        /* the calling thread serves the last device */
-        if (pthread_create(&th[d], NULL, multi_worker, j) != 0) { j->ret = LNN_NG; ret = LNN_NG; break; }
+        if (pthread_create(&th[d], NULL, multi_worker, j) != 0) { j->ret = LNN_NG; ret = LNN_NG; snprintf(m->err, sizeof(m->err), "device %d: pthread_create failed", m->device[d]); break; }
         started++;
     }
     if (ret == LNN_OK) multi_worker(&job[m->ndev - 1]);
     for (d = 0; d < started; d++) pthread_join(th[d], NULL);
-    for (d = 0; d < m->ndev && ret == LNN_OK; d++) if (job[d].ret != LNN_OK) ret = job[d].ret;
+    for (d = 0; d < m->ndev && ret == LNN_OK; d++) if (job[d].ret != LNN_OK) { ret = job[d].ret; snprintf(m->err, sizeof(m->err), "%s", job[d].err); }
     return ret;
 }
 

@@ -42,15 +42,19 @@ class ChunkExchange:
     encode: in = [((C, S), int32)], out = [((C, S), int32), ((C, 160), int32), ((C, 8), float64)].
     """
 
-    def __init__(self, dist, num_frames, chunk_frames, in_specs, out_specs, device, root=0):
+    def __init__(self, dist, num_frames, chunk_frames, in_specs, out_specs, device, root=0, group=None):
+        """group: the process group the transfers run on (default: the default group); it must span every rank, so that a
+        rank's number in it is its global rank.  bench.py keeps control traffic (barriers, reductions of times and flags) on a
+        gloo group and hands the RCCL group in here: a sick RCCL link then costs this leg, not the job."""
         import torch
-        self.dist, self.torch = dist, torch
-        self.world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
-        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.dist, self.torch, self.group = dist, torch, group
+        self.world = dist.get_world_size(group) if dist is not None and dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if self.world > 1 else 0
+        self.backend = dist.get_backend(group) if self.world > 1 else None
         self.root, self.device = root, device
         # device tensors on a backend that only moves host memory ("gloo": rehearsals of the N > 1 path on a one-GPU box): every
         # transfer is staged through a host copy.  Never the case on "nccl" (RCCL moves device memory over xGMI directly).
-        self.stage_through_host = bool(self.world > 1 and torch.device(device).type != "cpu" and dist.get_backend() != "nccl")
+        self.stage_through_host = bool(self.world > 1 and torch.device(device).type != "cpu" and self.backend != "nccl")
         self.num_frames, self.chunk_frames = int(num_frames), int(chunk_frames)
         self.chunks = chunk_ranges(self.num_frames, self.chunk_frames)
         self.in_specs, self.out_specs = list(in_specs), list(out_specs)
@@ -75,13 +79,14 @@ class ChunkExchange:
         if not ops:
             return []
         if self.stage_through_host:
-            return [_StagedOp(self.dist, op) for op in ops]
+            return [_StagedOp(self.dist, op, self.group) for op in ops]
         return self.dist.batch_isend_irecv(ops)
 
     def run(self, process, num_samples, root_inputs=None, root_outputs=None):
         """process(inputs_chunk, num_samples_chunk, outputs_chunk) fills the output views from the input views.
         On the root, root_inputs / root_outputs are the whole-batch tensors [F, ...]; elsewhere they are ignored."""
-        dist, P2POp = self.dist, (self.dist.P2POp if self.dist is not None else None)
+        dist = self.dist
+        P2POp = (lambda op, tensor, peer: dist.P2POp(op, tensor, peer, group=self.group)) if dist is not None else None
         R, G = self.rounds, self.world
         if self.rank == self.root:
             pending = []
@@ -153,10 +158,10 @@ class ChunkExchange:
 class _StagedOp:
     """one point-to-point transfer of a device tensor through host memory (see ChunkExchange.stage_through_host)"""
 
-    def __init__(self, dist, op):
+    def __init__(self, dist, op, group=None):
         self.tensor, self.is_recv = op.tensor, op.op is dist.irecv
         self.host = op.tensor.cpu() if not self.is_recv else op.tensor.new_empty(op.tensor.shape, device="cpu")
-        self.work = (dist.irecv if self.is_recv else dist.isend)(self.host, op.peer)
+        self.work = (dist.irecv if self.is_recv else dist.isend)(self.host, op.peer, group=group)
 
     def wait(self):
         self.work.wait()

@@ -1,7 +1,7 @@
 """HBM traffic per kernel from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md
 prescribes) of tools/kbench.py --frames F: writes profiles/pmc_latest.json.  Counters are KiB; FETCH_SIZE is doubled
 (gfx950 reports half of the bytes of wide coalesced reads); WRITE_SIZE is used as is.
-usage: pmc_traffic.py fetch.csv write.csv frames channels"""
+usage: pmc_traffic.py fetch.csv write.csv frames channels [note, e.g. the commit the library was built from]"""
 import csv, json, sys, collections
 fetch_csv, write_csv, frames, channels = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)"),
@@ -11,7 +11,8 @@ KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the s
         ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_fwd_loss", "k_fwd_loss<P> (last layer: forward pass + ordered loss)"),
         ("k_fir2<1, true", "k_fir2<1,true,*> (forward of layer 0, jobs with several units)"),
         ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"),
-        ("k_synth", "k_synth_small+k_synth_big (all layers, de-emphasis)"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan"), ("k_rice_emit", "k_rice_emit")]
+        ("k_synth_big", "k_synth_big<P> (synthesis of the long layer)"), ("k_synth_small", "k_synth_small<P> (synthesis of the short layers, de-emphasis)"),
+        ("k_synthesize", "k_synthesize (one wave per channel-frame, all layers)"), ("k_ms_to_lr", "k_ms_to_lr"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan"), ("k_rice_emit", "k_rice_emit")]
 def load(path, counter):
     per = collections.defaultdict(dict)
     for r in csv.DictReader(open(path)):
@@ -36,6 +37,22 @@ for kind in fa:
     bytes_total = (2.0 * sum(fk) + sum(wk)) * 1024.0
     out[kind] = {"launches_sampled": n, "fetch_kib_raw": [int(v) for v in fk], "write_kib": [int(v) for v in wk],
                  "hbm_bytes_per_channel_frame_per_launch": int(bytes_total / n / (frames * channels))}
+# the whole step: every kernel of the encode call (decode call) summed, per channel-frame -- against the algorithmic 82 552 B
+DECODE = ("k_synth", "k_ms_to_lr")
+tot = {"encode": 0.0, "decode": 0.0}
+for kind, v in out.items():
+    if kind.startswith("_") or kind.startswith("k_rice"): continue
+    side = "decode" if kind.startswith(DECODE) else "encode"
+    tot[side] += (2.0 * sum(v["fetch_kib_raw"]) + sum(v["write_kib"])) * 1024.0
+out["_whole_step"] = {"encode_hbm_bytes_per_channel_frame": int(tot["encode"] / (frames * channels)), "decode_hbm_bytes_per_channel_frame": int(tot["decode"] / (frames * channels)),
+                      "algorithmic_bytes_per_channel_frame": 82552, "encode_over_algorithmic": round(tot["encode"] / (frames * channels) / 82552.0, 2),
+                      "decode_over_algorithmic": round(tot["decode"] / (frames * channels) / 82552.0, 2)}
+try:
+    import subprocess
+    out["_source"] += "; tree " + subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+except Exception:
+    pass
+if len(sys.argv) > 5: out["_source"] += "; " + sys.argv[5]
 json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
 for k, v in out.items():
     if not k.startswith("_"): print(k, v["launches_sampled"], v["hbm_bytes_per_channel_frame_per_launch"])
