@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
 FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25)
-DECODE_KINDS = (11, 12, 28, 29)
+DECODE_KINDS = (11, 12, 30, 31, 32)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
                 5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)",
                 25: "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)",
@@ -62,7 +62,8 @@ KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocor
                 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false,true> (forward, jobs with several units)",
                 19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_fwd_loss<P> (last layer: forward pass + ordered loss)", 21: "k_autocorr_hist<P,0> (long layer, one-unit trial)", 22: "k_autocorr_hist<P,1> (long layer, two-unit trial)", 23: "k_autocorr_sub<P> (long layer, trials of order <= 32)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
                 9: "k_chain_sum<1>", 10: "k_finalize", 11: "k_synthesize (one wave per channel-frame, all layers)", 12: "k_ms_to_lr",
-                28: "k_synth_big<P> (synthesis of the long layer)", 29: "k_synth_small<P> (synthesis of the short layers, de-emphasis)"}
+                30: "k_synth_big<P> (synthesis of the long layer)", 31: "k_synth_small<P> (synthesis of the short layers, de-emphasis)",
+                32: "k_synth_pipe (a wave per stage of the cascade, 16-sample blocks: the latency form)"}
 
 
 def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):
@@ -746,7 +747,7 @@ def worker(args):
             avg_ms = kern_ms[dom] / launches
             # timed spans of one kind per chunk of frames: per-layer kernels have one span per layer they serve
             per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2),
-                         16: 1, 21: n_big, 22: n_big, 23: n_big, 28: n_big, 29: nlayers - n_big}.get(dom, 1)
+                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big}.get(dom, 1)
             cf_per_launch = F * nch * args.steps / (launches / per_chunk)
             achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
             per_cf = (pmc.get(KERNEL_KINDS[dom]) or {}).get("hbm_bytes_per_channel_frame_per_launch")

@@ -257,7 +257,9 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * forward pass fused with its loss (k_fwd_loss; replaces 19 + 9 for the frames it takes), 21 / 22 / 23 the long layer's
  * autocorrelation with lanes = jobs (k_autocorr_hist for the trials of order P and P/2, k_autocorr_sub for the shorter ones;
  * replace 3 for the frames they take), 24 Rice scan + emission, 25 the long layer's search in one window pass (k_search_long;
- * replaces 5 for the frames it takes). */
+ * replaces 5 for the frames it takes), 26 the real final pass of -a N, 27 the -l trainer, 28 Rice decoding, 30 / 31 the synthesis of
+ * the long layer (k_synth_big) / of the short layers and the de-emphasis (k_synth_small); 11 is then the one-launch form
+ * (k_synthesize: small batches). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_EnableTiming(struct LINNEAmdContext *ctx, int enable);

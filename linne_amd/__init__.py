@@ -22,6 +22,7 @@ LIB_PATH = os.path.join(_HERE, "liblinne_amd.so")
 PARAM_WORDS = 160
 STAT_WORDS = 8
 RICE_PLAN_BYTES = 1040         # include/linne_amd.h: [0] order, [1] host-search flag, [16..] parameters
+RICE_PLAN_NBITS = 4            # uint32 at this byte offset of a plan: the channel's whole Rice code in bits
 PRM_PREV, PRM_PCOEF, PRM_UNITS, PRM_RSHIFT, PRM_COEF = 0, 2, 4, 7, 10
 ST_R0, ST_K1, ST_ZERO, ST_TAIL, ST_BEST, ST_LOSS = 0, 1, 4, 5, 6, 7
 PRESET_LAYERS = {0: (2, 32), 1: (2, 32), 2: (4, 64, 8), 3: (4, 64, 8), 4: (4, 64, 8),

@@ -83,7 +83,7 @@ struct LINNEAmdContext {
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -166,6 +166,7 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     { const char *fl = getenv("LINNE_AMD_FWD_LOSS"); ctx->fwd_loss = fl ? atoi(fl) : -1; }
     { const char *sp = getenv("LINNE_AMD_FIR_SMALL"); ctx->fir_small = sp ? atoi(sp) : 1; }
     (void)hipFuncSetAttribute((const void *)k_levinson_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEV_LDS_BUDGET);
+    (void)hipFuncSetAttribute((const void *)k_synth_pipe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEV_LDS_BUDGET);
     if ((e = hipEventCreate(&ctx->ev[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev[1])) != hipSuccess) { CC_FAIL("hipEventCreate"); }
 #undef CC_FAIL
     return ctx;
@@ -270,7 +271,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.search_long = env_int("LINNE_AMD_SEARCH_LONG", 1);
     ctx->knob.rows16 = env_int("LINNE_AMD_ROWS16", 1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
-    { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : 2); }
+    { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : 2)); }
     ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
 }
 /* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
@@ -947,12 +948,18 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
         /* The lanes = channel-frames kernels have few, long-running waves: a pass over a short layer takes the time of one
          * wave's 10240-step recurrence however small the batch.  Below a few thousand channel-frames the one-wave-per-
          * channel-frame kernel (all layers and the de-emphasis in one launch) finishes sooner. */
-        const bool use_wave = ctx->knob.decode_kernel ? (ctx->knob.decode_kernel == 1) : (CF < 6144u);      /* LINNE_AMD_DECODE_KERNEL = "wave" / "lanes": for tests and measurements */
-        /* timing kinds: 11 = k_synthesize (all layers in one launch), 28 = k_synth_big, 29 = k_synth_small */
-        if (use_wave) { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u); span_end(ctx, sp_, ctx->stream); }
+        /* LINNE_AMD_DECODE_KERNEL = "wave" / "lanes" / "pipe": for tests and measurements.  Small batches -- block-at-a-time calls
+         * above all -- take the pipelined latency form (k_synth_pipe: a wave per stage of the cascade, 16-sample blocks) when the
+         * frame fits its LDS image; k_synthesize is its fallback for longer frames */
+        const bool pipe_fits = SP_LDS_BYTES(p.S) <= LEV_LDS_BUDGET;
+        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < 6144u ? 3 : 2);
+        const bool use_pipe = (form == 3) && pipe_fits, use_wave = (form == 1) || (form == 3 && !pipe_fits);
+        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe */
+        if (use_pipe) { const int sp_ = span_begin(ctx, 32, ctx->stream); hipLaunchKernelGGL(k_synth_pipe, dim3(CF), dim3(64 * (hs.L + 1)), SP_LDS_BYTES(p.S), ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
+        else if (use_wave) { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u); span_end(ctx, sp_, ctx->stream); }
         else for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
             const bool de = (l == 0);
-            const int sp_ = span_begin(ctx, hs.P[l] <= 16u ? 29 : (hs.P[l] <= 128u && (hs.P[l] & (hs.P[l] - 1u)) == 0 ? 28 : 11), ctx->stream);
+            const int sp_ = span_begin(ctx, hs.P[l] <= 16u ? 31 : (hs.P[l] <= 128u && (hs.P[l] & (hs.P[l] - 1u)) == 0 ? 30 : 11), ctx->stream);
             switch (hs.P[l]) {
             case 2:  if (de) hipLaunchKernelGGL((k_synth_small<2, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<2, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
             case 4:  if (de) hipLaunchKernelGGL((k_synth_small<4, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<4, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;

@@ -749,7 +749,9 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
     static_assert(NCH <= 64, "one wave adds up all chains");
     __shared__ double sv[2][NT][CHUNK + P];
     __shared__ uint32_t srem[2][NT][CHUNK + P];
-    __shared__ double sprod[2][NCH][CHUNK];
+    /* rows padded by one double: adder lane c walks row c, and a lane stride of CHUNK doubles (512 B .. 2 KB) would put every lane
+     * on the same LDS bank -- an NCH-way conflict on every read of the dependent chain */
+    __shared__ double sprod[2][NCH][CHUNK + 1];
     const uint32_t row = blockIdx.x, tid = threadIdx.x, job = L0 ? row * p.R : row;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
@@ -824,7 +826,7 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
             if (k >= 1u && k - 1u < nchunks) {                      /* the pairs of chunk k - 1: both samples inside the same unit, else +0.0 (no effect on the bits) */
                 const double (*src)[CHUNK + P] = sv[(k - 1u) & 1u];
                 const uint32_t (*rem)[CHUNK + P] = srem[(k - 1u) & 1u];
-                double (*dst)[CHUNK] = sprod[(k - 1u) & 1u];
+                double (*dst)[CHUNK + 1] = sprod[(k - 1u) & 1u];
                 /* all reads first, then all writes: the compiler cannot know that `src` and `dst` never overlap and would wait out
                  * every element's LDS trip before starting the next */
                 double av[NPM], bv[NPM]; uint32_t rv[NPM];

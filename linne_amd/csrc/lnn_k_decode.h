@@ -372,6 +372,185 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * k_synth_pipe: the LATENCY form of the synthesis -- what LINNEDecoder_DecodeBlock waits for (tools/linne_player decodes a block
+ * per audio callback, linne_player.c:66-118; linne_decoder.c:503-522).  One block per channel-frame, one WAVE PER STAGE of the
+ * cascade: the layers in decode order (L-1 .. 0), then the two de-emphasis stages; the stages work IN PLACE on the channel-frame's
+ * samples in LDS and follow each other at a distance of 16 samples (a progress counter per stage), so the call takes the time of
+ * the slowest stage, not the sum.
+ *
+ * A layer stage walks its units in blocks of 16 outputs.  y[t] = r[t] - ((half + sum_d c_d y[t - d]) >> rshift) is split by the
+ * distance d of a tap (linne_lpc_synthesize.c:27-33 written with d = np - ord):
+ *   d <= i            (i = place in the block) the block's own outputs: the serial part.  Lane i holds output i's sum; when y_j is
+ *                     final it is read with v_readlane and every later lane adds its tap times y_j -- one dependent multiply-add
+ *                     per sample instead of a wave-wide reduction (k_synthesize: ~290 cycles per sample, this: ~50);
+ *   i < d <= i + 16   the previous block's outputs: added in the same steps into the NEXT block's sums (second coefficient set);
+ *   d > i + 16        older samples (only layers of more than 16 taps): a Toeplitz product on the matrix unit,
+ *                     v_mfma_i32_16x16x64_i8 -- A = the last 64 KS outputs as four planes of signed base-256 digits (rows), B = the
+ *                     unit's 8-bit coefficients laid out as a Toeplitz matrix (constant per unit), issued a block ahead and summed
+ *                     modulo 2^32 (the reference's wrap-around int32 arithmetic is associative, the planes recombine by shifts).
+ * Coefficients are 8-bit by format (the stream codes them with a 256-symbol Huffman code; k_synth_small / k_synth_big rely on the
+ * same range).  Frames too long for the LDS image stay with k_synthesize. */
+typedef int lnn_v4i __attribute__((ext_vector_type(4)));
+#define SP_RING 256u
+struct SpShared { uint32_t prog[LNN_MAXL + 1]; uint32_t pad[4]; int8_t ring[LNN_MAXL][4][SP_RING]; };
+
+__device__ __forceinline__ uint32_t sp_load_prog(const uint32_t *q) { return __hip_atomic_load(q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sp_publish(uint32_t *q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void sp_wait(const uint32_t *q, uint32_t need) { if (q) while (sp_load_prog(q) < need) __builtin_amdgcn_s_sleep(1); }
+
+/* c * s modulo 2^32 for an 8-bit c and any 32-bit s, on the full-rate 24-bit multiplier: s = sl + 2^16 sh */
+__device__ __forceinline__ uint32_t sp_mul8(int32_t c, int32_t sl, int32_t sh) { return (uint32_t)__mul24(c, sl) + ((uint32_t)__mul24(c, sh) << 16); }
+
+template <int KS>       /* 64-sample steps of history summed on the matrix unit: 0 for layers of <= 16 taps, 1 up to 80, 2 up to 144 */
+__device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout, int8_t (*ring)[SP_RING], const int32_t *coef,
+        uint32_t P, uint32_t units, uint32_t rs, uint32_t n, uint32_t lane)
+{
+    const uint32_t np = units ? P / units : 0u, ns = units ? n / units : 0u;
+    if (units == 0 || np == 0 || ns < np) { sp_wait(pin, n); sp_publish(pout, n); return; }        /* (what k_synthesize skips) */
+    const uint32_t i = lane & 15u, g = lane >> 4;
+    const uint32_t half = 1u << ((rs - 1u) & 31u), sh_ = rs & 31u;
+    for (uint32_t unit = 0; unit < units; unit++) {
+        const uint32_t base = unit * ns;
+        const int32_t *cu = coef + (size_t)unit * np;
+        /* tap of distance d: cu[np - d] (linne_lpc_synthesize.c:30: coef[ord] meets data[smpl + ord], the output is data[smpl + np]) */
+        int32_t ccA[16], ccB[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int32_t da = (int32_t)i - j, db = 16 + (int32_t)i - j;
+            ccA[j] = (da >= 1 && (uint32_t)da <= np) ? cu[np - (uint32_t)da] : 0;
+            ccB[j] = ((uint32_t)db <= np) ? cu[np - (uint32_t)db] : 0;
+        }
+        lnn_v4i bfrag[KS ? KS : 1];
+        if (KS) {
+#pragma unroll
+            for (int s = 0; s < KS; s++) {
+                uint32_t w[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const uint32_t k = 64u * s + 16u * g + e, d = 64u * KS + 16u - k + i;      /* window element k lies d samples before output i */
+                    const int32_t c = (d <= np) ? cu[np - d] : 0;
+                    w[e >> 2] |= ((uint32_t)c & 0xFFu) << (8 * (e & 3));
+                }
+                bfrag[s][0] = (int)w[0]; bfrag[s][1] = (int)w[1]; bfrag[s][2] = (int)w[2]; bfrag[s][3] = (int)w[3];
+            }
+        }
+        /* the unit's first np samples pass through (linne_lpc_synthesize.c:26): they are this stage's outputs as they are */
+        sp_wait(pin, base + np);
+        if (KS) {       /* their digits: sample t of the unit sits at ring index (t - np + 128) mod 256 */
+            for (uint32_t t = lane; t < np; t += 64u) {
+                int32_t v = buf[base + t];
+                const uint32_t ix = (t - np + 128u) & (SP_RING - 1u);
+#pragma unroll
+                for (int b = 0; b < 4; b++) { const int32_t dg = (int32_t)(int8_t)v; ring[b][ix] = (int8_t)dg; v = (v - dg) >> 8; }
+            }
+        }
+        sp_publish(pout, base + np);
+        /* what the 16 samples in front of the first block add to its sums (distances i + 1 .. i + 16) */
+        uint32_t nxt = 0;
+        {
+            const int32_t tprev = (int32_t)np - 16 + (int32_t)i;
+            const int32_t yp = (lane < 16u && tprev >= 0) ? buf[base + (uint32_t)tprev] : 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int32_t sv = __builtin_amdgcn_readlane(yp, j);
+                nxt += sp_mul8(ccB[j], sv & 0xFFFF, sv >> 16);
+            }
+        }
+        auto window = [&](uint32_t m) -> uint32_t {             /* matrix-unit part of block m's sums: the 64 KS samples that end 16 before it */
+            lnn_v4i acc4 = { 0, 0, 0, 0 };
+            if (KS) {
+                const uint32_t w0 = 128u + 16u * m - 16u - 64u * KS;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    lnn_v4i a = { 0, 0, 0, 0 };
+                    if (i < 4u) a = *(const lnn_v4i *)&ring[i][(w0 + 64u * s + 16u * g) & (SP_RING - 1u)];
+                    acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[s], acc4, 0, 0, 0);
+                }
+            }
+            return (uint32_t)acc4[0] + ((uint32_t)acc4[1] << 8) + ((uint32_t)acc4[2] << 16) + ((uint32_t)acc4[3] << 24);     /* lanes 0 .. 15: planes 0 .. 3 of column i */
+        };
+        const uint32_t nblk = (ns - np + 15u) / 16u;
+        uint32_t mcur = window(0);
+        for (uint32_t m = 0; m < nblk; m++) {
+            const uint32_t t0 = np + 16u * m, cnt = (ns - t0 < 16u) ? (ns - t0) : 16u;
+            sp_wait(pin, base + t0 + cnt);
+            const int32_t res = (lane < cnt) ? buf[base + t0 + i] : 0;
+            const uint32_t mnext = (m + 1u < nblk) ? window(m + 1u) : 0u;      /* issued now, needed a block later */
+            uint32_t acc = half + mcur + nxt;
+            nxt = 0;
+            int32_t yout = 0;
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+                const int32_t sv = __builtin_amdgcn_readlane(y, j);
+                const int32_t sl = sv & 0xFFFF, sh = sv >> 16;
+                acc += sp_mul8(ccA[j], sl, sh);
+                nxt += sp_mul8(ccB[j], sl, sh);
+                yout = (i == (uint32_t)j) ? y : yout;
+            }
+            if (lane < cnt) buf[base + t0 + i] = yout;
+            sp_publish(pout, base + t0 + cnt);
+            if (KS && lane < 16u) {
+                int32_t v = yout;
+                const uint32_t ix = (128u + 16u * m + i) & (SP_RING - 1u);
+#pragma unroll
+                for (int b = 0; b < 4; b++) { const int32_t dg = (int32_t)(int8_t)v; ring[b][ix] = (int8_t)dg; v = (v - dg) >> 8; }
+            }
+            mcur = mnext;
+        }
+    }
+    sp_wait(pin, n);            /* what lies behind the last unit passes through */
+    sp_publish(pout, n);
+}
+
+__global__ __launch_bounds__(64 * (LNN_MAXL + 1)) void k_synth_pipe(DecPlan p)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t sp_dyn[];
+    SpShared *sh = (SpShared *)sp_dyn;
+    int32_t *buf = (int32_t *)(sp_dyn + sizeof(SpShared));
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t n = p.nsmp[cf / p.C], S = p.S, L = p.L;
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    int32_t *g = p.data + (size_t)cf * S;
+    if (tid <= LNN_MAXL) sh->prog[tid] = 0u;
+    for (uint32_t t = tid; t < n; t += blockDim.x) buf[t] = g[t];
+    __syncthreads();
+    if (wave < L) {
+        const uint32_t l = L - 1u - wave, P = p.P[l];
+        const uint32_t *pin = wave ? &sh->prog[wave - 1u] : (const uint32_t *)0;
+        const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
+        const int32_t *coef = rec + LINNE_AMD_PRM_COEF + p.coef_off[l];
+        if (P <= 16u) sp_layer_stage<0>(buf, pin, &sh->prog[wave], sh->ring[wave], coef, P, units, rs, n, lane);
+        else if (P <= 64u) sp_layer_stage<1>(buf, pin, &sh->prog[wave], sh->ring[wave], coef, P, units, rs, n, lane);
+        else sp_layer_stage<2>(buf, pin, &sh->prog[wave], sh->ring[wave], coef, P, units, rs, n, lane);
+    } else if (wave == L) {
+        /* two-stage de-emphasis (linne_utility.c:215-241) behind the last layer stage, 64 samples at a time; the recurrences are
+         * wave-uniform (scalar) */
+        const uint32_t *pin = &sh->prog[L - 1u];
+        const int32_t c0e = rec[LINNE_AMD_PRM_PCOEF + 0], c1e = rec[LINNE_AMD_PRM_PCOEF + 1];
+        int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
+        for (uint32_t c0 = 0; c0 < n; c0 += 64u) {
+            const uint32_t cnt = (n - c0 < 64u) ? (n - c0) : 64u;
+            sp_wait(pin, c0 + cnt);
+            const int32_t cur = (lane < cnt) ? buf[c0 + lane] : 0;
+            int32_t outv = cur;
+            for (uint32_t k = 0; k < cnt; k++) {
+                const int32_t b = __builtin_amdgcn_readlane(cur, (int)k);
+                const int32_t z = (int32_t)((uint32_t)b + (uint32_t)mulshr5(zp, c1e));
+                const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                zp = z; yp = y;
+                if (lane == k) outv = y;
+            }
+            if (lane < cnt) buf[c0 + lane] = outv;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = tid; t < n; t += blockDim.x) g[t] = buf[t];
+}
+#define SP_LDS_BYTES(n_) (sizeof(SpShared) + sizeof(int32_t) * (size_t)(n_))
+
 /* MS -> LR (linne_utility.c:135-147) */
 __global__ void k_ms_to_lr(DecPlan p)
 {

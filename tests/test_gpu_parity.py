@@ -289,7 +289,7 @@ def test_own_cli_matches_the_reference_cli(tmp_path):
         assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe"])
 @pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
 def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
     """DecodeFramesDevice picks its kernels by batch size (one wave per channel-frame for small batches; lanes =
@@ -349,7 +349,7 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     assert ret == 0 and np.array_equal(dec, x)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe"])
 def test_corrupt_streams_do_not_hang_or_fault(product, oracle, monkeypatch, kernel):
     """with the CRC check off a damaged payload reaches the parser and the GPU with arbitrary parameters (unit counts,
     shifts, coefficients, residuals): decoding must come back with a result code (and the device must stay usable)"""
@@ -751,3 +751,109 @@ def test_block_at_a_time_forms_agree(product, oracle, monkeypatch, wide, lev_wav
         pos += n
     product.L.LINNEEncoder_Destroy(enc)
     assert bytes(got) == want
+
+
+@pytest.mark.gpu
+def test_the_references_full_round_trip_matrix(product):
+    """every cell of the reference's own round-trip matrix (test/linne_encode_decode/main.cpp:335-536: 9 waveforms x {1,2,8}
+    channels x {8,16,24} bits x presets {0,7}, 8192 samples in blocks of 1024): the bytes hash to what oracle/_ref wrote
+    (tests/golden/matrix_hashes.json, committed: no _ref needed here) and DecodeWhole restores the input, as the reference's test
+    asks"""
+    import hashlib
+    from test_oracle_cpu import matrix_cells
+    n = 0
+    for name, x, bits, preset, ms, e in matrix_cells():
+        got = product.encode_whole(x, bits, 8000, 1024, preset, ms)
+        assert len(got) == e["bytes"] and hashlib.sha256(got).hexdigest() == e["sha256"], name
+        ret, dec = product.decode_whole(got)
+        assert ret == 0 and np.array_equal(dec, x), name
+        n += 1
+    assert n == 162
+
+
+@pytest.mark.gpu
+def test_option_goldens_without_the_reference_library(product):
+    """-a 1/2/3 and -l (lpc.c:578-633, linne_network.c:805-873) pinned by committed hashes of oracle/_ref's streams: these stay
+    tests (not skips) on a box where oracle/_ref was not shipped"""
+    import hashlib
+    from test_oracle_cpu import option_cases
+    n = 0
+    for name, x, e in option_cases():
+        bits = e["music_args"][2]
+        got = product.encode_whole(x, bits, 44100, e["block"], e["preset"], x.shape[0] >= 2, af_iters=e["af_iters"], learning=e["learning"])
+        assert len(got) == e["bytes"] and hashlib.sha256(got).hexdigest() == e["sha256"], name
+        ret, dec = product.decode_whole(got)
+        assert ret == 0 and np.array_equal(dec, x), name
+        n += 1
+    assert n == 9
+
+
+@pytest.mark.gpu
+def test_two_handles_on_two_threads_at_once(product, oracle):
+    """the boundary's threading contract (a handle is used by one thread at a time, different handles are independent):
+    two encoder handles and two decoder handles driven from two threads at the same moment, whole streams and block-at-a-time
+    calls mixed, several rounds -- every result equals the single-threaded one"""
+    import threading
+    cases = [(music(2, 9 * 4096 + 1234, 16, seed=401), 16, 4096, 7, True), (music(1, 7 * 2048 + 99, 24, seed=402), 24, 2048, 4, False)]
+    want = [oracle.encode_whole(x, bits, 44100, block, preset, ms) for x, bits, block, preset, ms in cases]
+    errors = []
+    gate = threading.Barrier(2)
+
+    def work(k):
+        x, bits, block, preset, ms = cases[k]
+        try:
+            for rnd in range(4):
+                gate.wait(timeout=120)
+                got = product.encode_whole(x, bits, 44100, block, preset, ms) if rnd % 2 == 0 else product.encode_blocks(x, bits, 44100, block, preset, ms)
+                assert got == want[k], f"thread {k} round {rnd}: encode differs"
+                ret, dec = product.decode_whole(got)
+                assert ret == 0 and np.array_equal(dec, x), f"thread {k} round {rnd}: decode differs"
+        except Exception as exc:          # (a failed assert on one side must not leave the other at the barrier)
+            errors.append(repr(exc))
+            gate.abort()
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(300)
+    assert not errors, errors
+
+
+@pytest.mark.gpu
+def test_rice_decode_device_reads_no_further_than_its_contract(ctx):
+    """LINNEAmd_RiceDecodeDevice promises to read d_stream only up to the next multiple of 8 bytes behind stream_bytes
+    (include/linne_amd.h): a mono batch's emitted codes in a buffer that ends exactly there -- with non-zero bytes between
+    stream_bytes and that bound -- decode to the residual, and every frame's end position is the next frame's start"""
+    import ctypes as C
+    import torch
+    nch, bits, block, preset, F = 1, 16, 4096, 4, 5
+    frames = music_frames(F, nch, block, bits, seed=77)
+    frames[2] = waveform("white_noise", nch, block, bits, seed=3)
+    ns = np.full(F, block, dtype=np.uint32); ns[-1] = 3000
+    frames[-1, :, 3000:] = 0
+    shape = ctx.shape(nch, bits, block, preset, False)
+    res, prm, st = ctx.encode_frames(shape, torch.from_numpy(frames).cuda(), ns)
+    plan = ctx.rice_plan(shape, res, ns)
+    packed, offsets = ctx.rice_emit(shape, res, plan)
+    ctx.synchronize()
+    off = offsets.cpu().numpy().view(np.uint32)
+    assert (off != 0xFFFFFFFF).all()
+    nbits = plan.cpu().numpy()[:, 0, linne_amd.RICE_PLAN_NBITS:linne_amd.RICE_PLAN_NBITS + 4].copy().view(np.uint32)[:, 0]
+    for k in (F, F - 1, F - 2, F - 3):                       # prefixes of the batch: stream_bytes on and off the 4- and 8-byte grids
+        total = int(off[k])
+        bound = (total + 7) & ~7
+        buf = torch.full((bound,), 0xA5, dtype=torch.uint8, device="cuda")
+        buf[:total] = packed[:total]
+        bitpos = torch.from_numpy((off[:k].astype(np.uint64) * 8).view(np.int64)).cuda()
+        out = torch.full((k, nch, block), 123456, dtype=torch.int32, device="cuda")
+        endbit = torch.zeros(k, dtype=torch.int64, device="cuda")
+        nsk = np.ascontiguousarray(ns[:k])
+        ret = linne_amd.lib.LINNEAmd_RiceDecodeDevice(C.c_void_p(ctx.h), C.byref(shape), C.c_void_p(buf.data_ptr()), C.c_uint64(total), C.c_void_p(bitpos.data_ptr()),
+                                                      nsk.ctypes.data_as(C.c_void_p), C.c_uint32(k), C.c_void_p(out.data_ptr()), C.c_void_p(endbit.data_ptr()))
+        assert ret == 0
+        ctx.synchronize()
+        got, want, eb = out.cpu().numpy(), res.cpu().numpy(), endbit.cpu().numpy().view(np.uint64)
+        for f in range(k):
+            assert np.array_equal(got[f, 0, :ns[f]], want[f, 0, :ns[f]]), f"{k} frames, frame {f}"
+            assert int(eb[f]) == int(off[f]) * 8 + int(nbits[f]), f"{k} frames, frame {f}: end position"

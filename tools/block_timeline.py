@@ -1,7 +1,7 @@
 """kernel timeline of the LAST EncodeBlock and the LAST DecodeBlock of a rocprofv3 --kernel-trace run of tools/blockrate.py:
 start, duration, gap, grid"""
 import csv, glob, sys
-f = sorted(glob.glob(sys.argv[1] + '/*/*kernel_trace.csv'))[-1]
+f = sorted(glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True))[-1]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 DEC = ('k_synth', 'k_ms_to_lr', 'k_rice_decode', 'k_narrow')
