@@ -113,7 +113,8 @@ int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEA
 /* DECODE hot path, device resident, in place: d_data holds the entropy-decoded residual on entry and PCM on
  * return.  Replaces linne_decoder.c:503-522: per channel the int32 synthesis cascade in reverse layer order
  * (linne_lpc_synthesize.c:8-83), two-stage de-emphasis (linne_utility.c:215-241), then MS->LR
- * (linne_utility.c:135-147). */
+ * (linne_utility.c:135-147).  d_params' coefficients must lie in [-128, 127], the range the stream's 8-bit coefficient code can
+ * express (lnn_parse_block delivers nothing else): the synthesis kernels multiply them on 8-bit / exact-FP64 paths. */
 int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         int32_t *d_data, const uint32_t *h_num_samples, uint32_t num_frames, const int32_t *d_params);
 

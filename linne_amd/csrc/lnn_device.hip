@@ -81,6 +81,7 @@ struct LINNEAmdContext {
     int pcm16_next;                     /* the next EncodeFramesDevice call reads int16 samples (set by the staging slots, cleared by the call) */
     int force_exact;                    /* LINNE_AMD_EXACT=1: every unit-count search runs the exact ordered chains (diff against the certified search) */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
+    void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
     struct { int sort, l0_products, wide, search_long, rows16, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe */; uint32_t dbg_maxtr; } knob;
@@ -188,6 +189,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->d_clsidx) hipFree(ctx->d_clsidx);
     if (ctx->d_nsmp) hipFree(ctx->d_nsmp);
     if (ctx->d_plan_nsmp) hipFree(ctx->d_plan_nsmp);
+    if (ctx->hstage) hipFree(ctx->hstage);
     if (ctx->af_h) hipHostFree(ctx->af_h);
     for (int i = 0; i < LNN_META; i++) { if (ctx->meta_h[i]) hipHostFree(ctx->meta_h[i]); if (ctx->meta_ev[i]) hipEventDestroy(ctx->meta_ev[i]); }
     if (ctx->has_copy) { hipStreamSynchronize(ctx->copy_in); hipStreamSynchronize(ctx->copy_out); hipStreamDestroy(ctx->copy_in); hipStreamDestroy(ctx->copy_out); }
@@ -980,8 +982,29 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     return LNN_OK;
 }
 
-/* host-buffer forms: staging buffers are allocated per call (the block-at-a-time API is latency-, not
- * throughput-oriented; batch callers use the device entry points) */
+/* device staging of the host-buffer forms: one allocation kept between calls (a block-at-a-time caller pays no hipMalloc /
+ * hipFree -- and with it no device-wide synchronisation -- per block); batches beyond HSTAGE_KEEP get a transient one */
+#define HSTAGE_KEEP ((uint64_t)64 << 20)
+static int hstage_get(LINNEAmdContext *ctx, uint64_t bytes, void **out, int *transient)
+{
+    *transient = 0;
+    if (bytes > HSTAGE_KEEP) {
+        if (hipMalloc(out, bytes) != hipSuccess) { (void)hipGetLastError(); snprintf(ctx->err, sizeof(ctx->err), "hipMalloc of staging buffers failed"); return LNN_NG; }
+        *transient = 1;
+        return LNN_OK;
+    }
+    if (ctx->hstage_cap < bytes) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->hstage) { HIPCHK(ctx, hipFree(ctx->hstage)); ctx->hstage = NULL; ctx->hstage_cap = 0; }
+        uint64_t cap = bytes < ((uint64_t)1 << 20) ? ((uint64_t)1 << 20) : bytes;
+        if (hipMalloc(&ctx->hstage, cap) != hipSuccess) { (void)hipGetLastError(); ctx->hstage = NULL; snprintf(ctx->err, sizeof(ctx->err), "hipMalloc of staging buffers failed"); return LNN_NG; }
+        ctx->hstage_cap = cap;
+    }
+    *out = ctx->hstage;
+    return LNN_OK;
+}
+
+/* host-buffer forms (what the block-at-a-time API calls; batch callers use the device entry points or the staging slots) */
 extern "C" int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         const int32_t *pcm, const uint32_t *num_samples, uint32_t num_frames,
         int32_t *residual, int32_t *params, double *stats)
@@ -994,12 +1017,12 @@ extern "C" int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const stru
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * num_frames,
                    sb = sizeof(double) * LINNE_AMD_STAT_WORDS * (uint64_t)shape->num_channels * num_frames;
     int32_t *d_pcm = NULL, *d_res = NULL, *d_prm = NULL; double *d_st = NULL;
-    int ret = LNN_NG;
-    if (hipMalloc((void **)&d_pcm, nb) != hipSuccess || hipMalloc((void **)&d_res, nb) != hipSuccess
-            || hipMalloc((void **)&d_prm, pb) != hipSuccess || hipMalloc((void **)&d_st, sb) != hipSuccess) {
-        snprintf(ctx->err, sizeof(ctx->err), "hipMalloc of staging buffers failed");
-        goto done;
-    }
+    void *stage = NULL; int transient = 0;
+    const uint64_t nb_a = align_up(nb), pb_a = align_up(pb);
+    int ret = hstage_get(ctx, 2 * nb_a + pb_a + align_up(sb), &stage, &transient);
+    if (ret != LNN_OK) return ret;
+    d_pcm = (int32_t *)stage; d_res = (int32_t *)((uint8_t *)stage + nb_a); d_prm = (int32_t *)((uint8_t *)stage + 2 * nb_a); d_st = (double *)((uint8_t *)stage + 2 * nb_a + pb_a);
+    ret = LNN_NG;
     if (hipMemcpyAsync(d_pcm, pcm, nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "H2D failed"); goto done; }
     if (hipMemsetAsync(d_prm, 0, pb, ctx->stream) != hipSuccess || hipMemsetAsync(d_st, 0, sb, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "memset failed"); goto done; }
     ret = LINNEAmd_EncodeFramesDevice(ctx, shape, d_pcm, num_samples, num_frames, d_res, d_prm, d_st);
@@ -1014,11 +1037,8 @@ extern "C" int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const stru
     }
     ret = LNN_OK;
 done:
-    hipStreamSynchronize(ctx->stream);
-    if (d_pcm) hipFree(d_pcm);
-    if (d_res) hipFree(d_res);
-    if (d_prm) hipFree(d_prm);
-    if (d_st) hipFree(d_st);
+    if (ret != LNN_OK || transient) hipStreamSynchronize(ctx->stream);
+    if (transient) hipFree(stage);
     return ret;
 }
 
@@ -1032,8 +1052,11 @@ extern "C" int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const stru
     const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * num_frames;
     int32_t *d_data = NULL, *d_prm = NULL;
-    int ret = LNN_NG;
-    if (hipMalloc((void **)&d_data, nb) != hipSuccess || hipMalloc((void **)&d_prm, pb) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hipMalloc of staging buffers failed"); goto done; }
+    void *stage = NULL; int transient = 0;
+    int ret = hstage_get(ctx, align_up(nb) + pb, &stage, &transient);
+    if (ret != LNN_OK) return ret;
+    d_data = (int32_t *)stage; d_prm = (int32_t *)((uint8_t *)stage + align_up(nb));
+    ret = LNN_NG;
     if (hipMemcpyAsync(d_data, data, nb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess
             || hipMemcpyAsync(d_prm, params, pb, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "H2D failed"); goto done; }
     ret = LINNEAmd_DecodeFramesDevice(ctx, shape, d_data, num_samples, num_frames, d_prm);
@@ -1046,9 +1069,8 @@ extern "C" int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const stru
     }
     ret = LNN_OK;
 done:
-    hipStreamSynchronize(ctx->stream);
-    if (d_data) hipFree(d_data);
-    if (d_prm) hipFree(d_prm);
+    if (ret != LNN_OK || transient) hipStreamSynchronize(ctx->stream);
+    if (transient) hipFree(stage);
     return ret;
 }
 

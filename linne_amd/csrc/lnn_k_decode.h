@@ -402,6 +402,10 @@ __device__ __forceinline__ void sp_wait(const uint32_t *q, uint32_t need) { if (
 /* c * s modulo 2^32 for an 8-bit c and any 32-bit s, on the full-rate 24-bit multiplier: s = sl + 2^16 sh */
 __device__ __forceinline__ uint32_t sp_mul8(int32_t c, int32_t sl, int32_t sh) { return (uint32_t)__mul24(c, sl) + ((uint32_t)__mul24(c, sh) << 16); }
 
+/* the four signed base-256 digits d_b in [-128, 127] of v (v = sum d_b 256^b modulo 2^32), byte b of the result: adding 128 to each
+ * of the three low digits makes them the unsigned bytes of v + 0x00808080 (the carries run as they must), and x - 128 = x ^ 0x80 */
+__device__ __forceinline__ uint32_t sp_digits(int32_t v) { return ((uint32_t)v + 0x00808080u) ^ 0x00808080u; }
+
 template <int KS>       /* 64-sample steps of history summed on the matrix unit: 0 for layers of <= 16 taps, 1 up to 80, 2 up to 144 */
 __device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout, int8_t (*ring)[SP_RING], const int32_t *coef,
         uint32_t P, uint32_t units, uint32_t rs, uint32_t n, uint32_t lane)
@@ -439,10 +443,9 @@ __device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout
         sp_wait(pin, base + np);
         if (KS) {       /* their digits: sample t of the unit sits at ring index (t - np + 128) mod 256 */
             for (uint32_t t = lane; t < np; t += 64u) {
-                int32_t v = buf[base + t];
+                const uint32_t dg = sp_digits(buf[base + t]);
                 const uint32_t ix = (t - np + 128u) & (SP_RING - 1u);
-#pragma unroll
-                for (int b = 0; b < 4; b++) { const int32_t dg = (int32_t)(int8_t)v; ring[b][ix] = (int8_t)dg; v = (v - dg) >> 8; }
+                ring[0][ix] = (int8_t)dg; ring[1][ix] = (int8_t)(dg >> 8); ring[2][ix] = (int8_t)(dg >> 16); ring[3][ix] = (int8_t)(dg >> 24);
             }
         }
         sp_publish(pout, base + np);
@@ -477,25 +480,43 @@ __device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout
             sp_wait(pin, base + t0 + cnt);
             const int32_t res = (lane < cnt) ? buf[base + t0 + i] : 0;
             const uint32_t mnext = (m + 1u < nblk) ? window(m + 1u) : 0u;      /* issued now, needed a block later */
-            uint32_t acc = half + mcur + nxt;
+            const uint32_t acc0 = half + mcur + nxt;
+            uint32_t acc = acc0;
             nxt = 0;
-            int32_t yout = 0;
+            /* Speculation: every output of the block fits 24 bits (any audio of <= 23 bits does) -- then c * y is ONE full-rate
+             * 24-bit multiply-add per sum, and a step of the dependent chain is shift, subtract, v_readlane, multiply-add.  An
+             * output outside that range (loud 24-bit material, a damaged stream) is seen after the block, and the block is done
+             * again with the multiplication split in halves (exact modulo 2^32 for any value). */
+            /* (a lone wave issues an instruction every ~9 cycles whatever its dependences, so a step costs what it counts in
+             * instructions: shift, subtract, v_readlane, two multiply-adds and the three wait states the scalar result needs) */
 #pragma unroll
             for (int j = 0; j < 16; j++) {
                 const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
                 const int32_t sv = __builtin_amdgcn_readlane(y, j);
-                const int32_t sl = sv & 0xFFFF, sh = sv >> 16;
-                acc += sp_mul8(ccA[j], sl, sh);
-                nxt += sp_mul8(ccB[j], sl, sh);
-                yout = (i == (uint32_t)j) ? y : yout;
+                acc += (uint32_t)__mul24(ccA[j], sv);
+                nxt += (uint32_t)__mul24(ccB[j], sv);
+            }
+            /* lane i's sum has not changed since step i (ccA[j] = 0 for j >= i): its output, whatever the step */
+            int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+            const bool fits = (lane >= 16u) || (((int32_t)((uint32_t)yout << 8) >> 8) == yout);
+            if (!__all(fits)) {
+                acc = acc0; nxt = 0;
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+                    const int32_t sv = __builtin_amdgcn_readlane(y, j);
+                    const int32_t sl = sv & 0xFFFF, sh = sv >> 16;
+                    acc += sp_mul8(ccA[j], sl, sh);
+                    nxt += sp_mul8(ccB[j], sl, sh);
+                }
+                yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
             }
             if (lane < cnt) buf[base + t0 + i] = yout;
             sp_publish(pout, base + t0 + cnt);
             if (KS && lane < 16u) {
-                int32_t v = yout;
+                const uint32_t dg = sp_digits(yout);
                 const uint32_t ix = (128u + 16u * m + i) & (SP_RING - 1u);
-#pragma unroll
-                for (int b = 0; b < 4; b++) { const int32_t dg = (int32_t)(int8_t)v; ring[b][ix] = (int8_t)dg; v = (v - dg) >> 8; }
+                ring[0][ix] = (int8_t)dg; ring[1][ix] = (int8_t)(dg >> 8); ring[2][ix] = (int8_t)(dg >> 16); ring[3][ix] = (int8_t)(dg >> 24);
             }
             mcur = mnext;
         }
@@ -536,7 +557,16 @@ __global__ __launch_bounds__(64 * (LNN_MAXL + 1)) void k_synth_pipe(DecPlan p)
             sp_wait(pin, c0 + cnt);
             const int32_t cur = (lane < cnt) ? buf[c0 + lane] : 0;
             int32_t outv = cur;
-            for (uint32_t k = 0; k < cnt; k++) {
+            if (cnt == 64u) {                 /* whole chunk: lane indices are constants, the results go back with v_writelane */
+#pragma unroll
+                for (int k = 0; k < 64; k++) {
+                    const int32_t b = __builtin_amdgcn_readlane(cur, k);
+                    const int32_t z = (int32_t)((uint32_t)b + (uint32_t)mulshr5(zp, c1e));
+                    const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                    zp = z; yp = y;
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(outv) : "s"(y), "n"(k));
+                }
+            } else for (uint32_t k = 0; k < cnt; k++) {
                 const int32_t b = __builtin_amdgcn_readlane(cur, (int)k);
                 const int32_t z = (int32_t)((uint32_t)b + (uint32_t)mulshr5(zp, c1e));
                 const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
