@@ -84,7 +84,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -272,6 +272,8 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.wide = env_int("LINNE_AMD_WIDE", 1);
     ctx->knob.search_long = env_int("LINNE_AMD_SEARCH_LONG", 1);
     ctx->knob.rows16 = env_int("LINNE_AMD_ROWS16", 1);
+    ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
+    ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
     { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : 2)); }
     ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
@@ -668,7 +670,17 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         ps.pcm = d_pcm; ps.pcm16 = pcm16; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.frame_map = ctx->d_map; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
         hipStream_t ss = ctx->stream;
         if (ctx->has_side) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
-        const int sp_ = span_begin(ctx, 13, ss); hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps); span_end(ctx, sp_, ss);
+        if (!env_int("LINNE_AMD_DBG_NOSTATS", 0)) {      /* TIMING EXPERIMENTS ONLY: without the statistics the block types are wrong */
+        const int sp_ = span_begin(ctx, 13, ss);
+        /* batches: lanes = channel-frames (k_stats_rows); a few channel-frames: a block each (k_stats finishes one block sooner).  LINNE_AMD_STATS_ROWS forces either */
+        const bool rows_form = ctx->knob.stats_rows >= 0 ? (ctx->knob.stats_rows != 0) : ((uint64_t)num_frames * C >= 1024u);
+        if (rows_form && (S & 3u) == 0 && (hs.P[0] == 2u || hs.P[0] == 4u)) {
+            const dim3 g((num_frames * C + 63u) / 64u);
+            if (hs.P[0] == 4u) { if (pcm16) hipLaunchKernelGGL((k_stats_rows<5, true>), g, dim3(320), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<5, false>), g, dim3(320), 0, ss, ps); }
+            else               { if (pcm16) hipLaunchKernelGGL((k_stats_rows<3, true>), g, dim3(192), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<3, false>), g, dim3(192), 0, ss, ps); }
+        }
+        else hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps);
+        span_end(ctx, sp_, ss); }
         if (ss != ctx->stream) HIPCHK(ctx, hipEventRecord(ctx->side_done, ss));
     }
     uint32_t chunk_index = 0;
@@ -696,6 +708,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.fused_last = fuse_cfg ? 1u : 0u;
         p.search_long = ctx->knob.search_long ? 1u : 0u;
         p.rows16 = ctx->knob.rows16 ? 1u : 0u;
+        p.prep_general = ctx->knob.prep_general ? 1u : 0u;
         build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         p.hist = (ctx->knob.hist >= 0 ? (ctx->knob.hist != 0) : (J >= 12288u)) ? 1u : 0u;
         if (p.runs[1].mixed) p.hist = 0;                        /* more class runs than RowRuns holds: blocks may mix classes, which only the general kernels serve */

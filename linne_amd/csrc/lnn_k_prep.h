@@ -36,11 +36,10 @@ __device__ __forceinline__ int64_t block_max_i64(int64_t v, int64_t *sh)
     return r;
 }
 
-__global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
+/* the general form: every phase streams the channel through global memory (xint <-> xtmp); any block length, and the ordered
+ * double chains for material whose pre-emphasis correlations leave the exact-integer range */
+__device__ void prep_general(const Plan &p, int64_t *sh, int32_t &sh_coef, double (*sh_prod)[PREP_CHUNK])
 {
-    __shared__ int64_t sh[PREP_THREADS / 64];
-    __shared__ int32_t sh_coef;
-    __shared__ double sh_prod[2][PREP_CHUNK];
     const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;     /* one block per (frame, channel) */
     const DevClass &c = p.cls[p.cls_of_frame[f]];
     const uint32_t n = c.n, S = p.S, C = p.C;
@@ -137,6 +136,181 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
     /* two stages: xint -> xtmp -> xint, the pre-emphasised channel is back in xint */
 }
 
+/* one round's tile of the fast form: samples t0 .. t0 + 2562 of the channel after copy / zero padding / LR -> MS (0 outside
+ * [0, n)), coalesced, ALL of a thread's loads issued before the first is used (a load waited for on the spot costs the block a trip
+ * to memory per element: 11 trips per round) */
+template <bool P16, bool MS>
+__device__ __forceinline__ void prep2_fill_t(const Plan &p, int32_t *tile, int64_t t0, uint32_t n, size_t inbase, uint32_t ch, uint32_t tid)
+{
+    constexpr uint32_t NQ = (PREP_THREADS * 10u + 3u + PREP_THREADS - 1u) / PREP_THREADS;      /* 11 */
+    const int16_t *p16 = (const int16_t *)p.pcm;
+    const size_t b0 = MS ? inbase : inbase + (size_t)ch * p.S, b1 = inbase + (size_t)p.S;
+    int32_t a[NQ], b[NQ];
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++) {
+        const int64_t s = t0 + (int64_t)(tid + PREP_THREADS * q);
+        const size_t idx = (s >= 0 && s < (int64_t)n) ? (size_t)s : 0u;                       /* (n >= 1: index 0 is always readable) */
+        a[q] = P16 ? (int32_t)p16[b0 + idx] : p.pcm[b0 + idx];
+        b[q] = MS ? (P16 ? (int32_t)p16[b1 + idx] : p.pcm[b1 + idx]) : 0;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < NQ; q++) {
+        const uint32_t i = tid + PREP_THREADS * q;
+        const int64_t s = t0 + (int64_t)i;
+        int32_t v = a[q];
+        if (MS) { const int32_t side = (int32_t)((uint32_t)b[q] - (uint32_t)a[q]); v = (ch == 1) ? side : (int32_t)((uint32_t)a[q] + (uint32_t)(side >> 1)); }
+        if (s < 0 || s >= (int64_t)n) v = 0;
+        if (i < PREP_THREADS * 10u + 3u) tile[i] = v;
+    }
+}
+__device__ __forceinline__ void prep2_fill(const Plan &p, int32_t *tile, int64_t t0, uint32_t n, size_t inbase, uint32_t ch, bool ms, uint32_t tid)
+{
+    if (p.pcm16) { if (ms) prep2_fill_t<true, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<true, false>(p, tile, t0, n, inbase, ch, tid); }
+    else         { if (ms) prep2_fill_t<false, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<false, false>(p, tile, t0, n, inbase, ch, tid); }
+}
+
+/* k_prep: copy / zero padding, MS, the two pre-emphasis stages (linne_encoder.c:613-641, linne_utility.c:120-212), one block per
+ * (frame, channel).
+ *
+ * Fast form (blocks of up to 10 240 samples whose correlations stay exact integers -- all 16-bit material): the channel lives in
+ * REGISTERS.  A thread owns four runs of 10 consecutive samples (one per 2560-sample round) with a halo of two samples in front and
+ * one behind, so that everything a stage needs of its neighbours -- x[s + 1] for the cross products, the previous stage's
+ * output at s - 1 for the next stage's filter -- is recomputed locally: the block talks only in its reductions (max |x|, sum x^2,
+ * the two correlation sums: ONE combined reduction per stage) and through the LDS tile that makes the global loads and stores
+ * coalesced.  Global traffic: the PCM in, the pre-emphasised channel out -- 80 KB per channel-frame where the general form
+ * (five passes over xint / xtmp) moved 369 KB (profiles/pmc_latest.json before round 3).  Every value is the general form's:
+ * same integer arithmetic, and the correlation sums are exact integers whatever the order (the `exact` test is the same).
+ * A block whose sums are not exact starts over in the general form. */
+#define PREP2_RUN 10u
+#define PREP2_ROUND (PREP_THREADS * PREP2_RUN)          /* 2560 samples */
+#define PREP2_MAXROUNDS 4u
+__global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
+{
+    __shared__ int64_t sh[4][PREP_THREADS / 64];
+    __shared__ int32_t sh_coef;
+    __shared__ int32_t sh_exact;
+    /* the tile of the fast form and the product buffers of the general form are never live together */
+    __shared__ __attribute__((aligned(16))) double sh_prod[2][PREP_CHUNK];
+    int32_t *tile = (int32_t *)&sh_prod[0][0];                 /* PREP2_ROUND + 3 words */
+    static_assert(sizeof(double) * 2 * PREP_CHUNK >= sizeof(int32_t) * (PREP2_ROUND + 3), "tile fits the product buffers");
+    const uint32_t f = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+    const DevClass &c = p.cls[p.cls_of_frame[f]];
+    const uint32_t n = c.n, S = p.S, C = p.C;
+    if (S > PREP2_ROUND * PREP2_MAXROUNDS || p.prep_general) { prep_general(p, sh[0], sh_coef, sh_prod); return; }
+    const uint32_t fo = p.frame_map[f];
+    const size_t inbase = (size_t)fo * C * S;
+    int32_t *out = p.xint + ((size_t)f * C + ch) * S;
+    int32_t *rec = p.prm + ((size_t)fo * C + ch) * LINNE_AMD_PARAM_WORDS;
+    const uint32_t rounds = (S + PREP2_ROUND - 1u) / PREP2_ROUND;
+    const bool ms = p.ms && ch < 2;
+    auto input_at = [&](int64_t s) -> int32_t {                 /* the channel after copy / zero padding / LR -> MS; 0 outside [0, n) */
+        if (s < 0 || s >= (int64_t)n) return 0;
+        if (!ms) return pcm_at(p, inbase + (size_t)ch * S + (size_t)s);
+        const uint32_t l = (uint32_t)pcm_at(p, inbase + (size_t)s), r = (uint32_t)pcm_at(p, inbase + (size_t)S + (size_t)s);
+        const int32_t side = (int32_t)(r - l);
+        return (ch == 1) ? side : (int32_t)(l + (uint32_t)(side >> 1));
+    };
+    /* x[r][j] = sample r * 2560 + 10 tid + j, j = -2 .. 10 (index j + 2) */
+    int32_t x[PREP2_MAXROUNDS][PREP2_RUN + 3];
+#pragma unroll
+    for (uint32_t r = 0; r < PREP2_MAXROUNDS; r++) {
+        if (r < rounds) {
+            const int64_t t0 = (int64_t)r * PREP2_ROUND - 2;
+            __syncthreads();
+            prep2_fill(p, tile, t0, n, inbase, ch, ms, tid);
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < PREP2_RUN + 3u; j++) x[r][j] = tile[PREP2_RUN * tid + j];
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < PREP2_RUN + 3u; j++) x[r][j] = 0;
+        }
+    }
+    int32_t coefs[2], firsts[2];
+    /* the reduction of one stage: max |v|, sum v^2 (s < n), sum v[s]^2 and sum v[s] v[s+1] (s < n - 1) */
+    auto stage_coef = [&](auto value_at, uint32_t stage) -> bool {     /* value_at(r, j): the stage's input at sample r * 2560 + 10 tid + j, j = 0 .. 10 */
+        int64_t mx = 0; uint64_t s0 = 0, s1 = 0, sq = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < PREP2_MAXROUNDS; r++) {
+            if (r >= rounds) continue;
+#pragma unroll
+            for (uint32_t j = 0; j < PREP2_RUN; j++) {
+                const uint32_t s = r * PREP2_ROUND + PREP2_RUN * tid + j;
+                if (s < n) {
+                    const int64_t a = value_at(r, j); const int64_t av = a < 0 ? -a : a;
+                    mx = av > mx ? av : mx;
+                    sq += (uint64_t)(a * a);
+                    if (s + 1 < n) { const int64_t b = value_at(r, j + 1); s0 += (uint64_t)(a * a); s1 += (uint64_t)(a * b); }
+                }
+            }
+        }
+        /* one combined reduction: wave shuffles, then one LDS hop */
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int64_t m2 = __shfl_xor(mx, o); mx = m2 > mx ? m2 : mx;
+            sq += (uint64_t)__shfl_xor((int64_t)sq, o); s0 += (uint64_t)__shfl_xor((int64_t)s0, o); s1 += (uint64_t)__shfl_xor((int64_t)s1, o);
+        }
+        __syncthreads();
+        if ((tid & 63u) == 0) { sh[0][tid >> 6] = mx; sh[1][tid >> 6] = (int64_t)sq; sh[2][tid >> 6] = (int64_t)s0; sh[3][tid >> 6] = (int64_t)s1; }
+        __syncthreads();
+        if (tid == 0) {
+            int64_t m = sh[0][0]; uint64_t q = 0, a0 = 0, a1 = 0;
+            for (uint32_t w = 0; w < PREP_THREADS / 64; w++) { m = sh[0][w] > m ? sh[0][w] : m; q += (uint64_t)sh[1][w]; a0 += (uint64_t)sh[2][w]; a1 += (uint64_t)sh[3][w]; }
+            /* the same test as the general form: mx^2 n < 2^62 (the 64-bit sums cannot wrap) and sum x^2 < 2^53 (every partial sum of
+             * the reference's double chains is an exactly representable integer, so any order gives its bits) */
+            const bool exact = (((double)m * (double)m * (double)n) < 4.0e18) && (q < (1ull << 53));
+            int32_t coef = 0;
+            if (exact) {
+                const double c0 = (double)(int64_t)a0;
+                double c1 = (double)(int64_t)a1;
+                c1 /= c0;
+                if ((c0 < 1e-6) || (c1 < 0.0)) coef = 0;
+                else { coef = (int32_t)round_away(c1 * 32.0); if (coef >= 16) coef = 15; }
+            }
+            sh_coef = coef; sh_exact = exact ? 1 : 0;
+        }
+        __syncthreads();
+        coefs[stage] = sh_coef;
+        return sh_exact != 0;
+    };
+    /* stage 0 works on x, stage 1 on y[s] = x[s] - mulshr5(x[s ? s - 1 : 0], coef0) for s < n (0 beyond), recomputed where needed */
+    const int32_t x_first = input_at(0);
+    auto xv = [&](uint32_t r, uint32_t j) -> int32_t { return x[r][j + 2]; };
+    if (!stage_coef(xv, 0u)) { __syncthreads(); prep_general(p, sh[0], sh_coef, sh_prod); return; }
+    const int32_t cf0 = coefs[0];
+    auto yat = [&](uint32_t r, int32_t j) -> int32_t {          /* j = -1 .. 10 */
+        const int64_t s = (int64_t)r * PREP2_ROUND + (int64_t)PREP2_RUN * tid + j;
+        if (s < 0 || s >= (int64_t)n) return 0;
+        const int32_t prev = (s == 0) ? x[r][j + 2] : x[r][j + 1];
+        return (int32_t)((uint32_t)x[r][j + 2] - (uint32_t)mulshr5(prev, cf0));
+    };
+    auto yv = [&](uint32_t r, uint32_t j) -> int32_t { return yat(r, (int32_t)j); };
+    firsts[0] = x_first;
+    const int32_t y_first = (n > 0) ? (int32_t)((uint32_t)x_first - (uint32_t)mulshr5(x_first, cf0)) : 0;
+    if (!stage_coef(yv, 1u)) { __syncthreads(); prep_general(p, sh[0], sh_coef, sh_prod); return; }
+    const int32_t cf1 = coefs[1];
+    firsts[1] = y_first;
+    if (tid == 0) {
+        rec[LINNE_AMD_PRM_PREV + 0] = firsts[0]; rec[LINNE_AMD_PRM_PCOEF + 0] = cf0;
+        rec[LINNE_AMD_PRM_PREV + 1] = firsts[1]; rec[LINNE_AMD_PRM_PCOEF + 1] = cf1;
+    }
+    /* z[s] = y[s] - mulshr5(y[s ? s - 1 : 0], coef1), through the tile to coalesced stores */
+#pragma unroll
+    for (uint32_t r = 0; r < PREP2_MAXROUNDS; r++) {
+        if (r >= rounds) continue;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < PREP2_RUN; j++) {
+            const uint32_t s = r * PREP2_ROUND + PREP2_RUN * tid + j;
+            int32_t z = 0;
+            if (s < n) { const int32_t yc = yat(r, (int32_t)j), yp = (s == 0) ? yc : yat(r, (int32_t)j - 1); z = (int32_t)((uint32_t)yc - (uint32_t)mulshr5(yp, cf1)); }
+            tile[PREP2_RUN * tid + j] = z;
+        }
+        __syncthreads();
+        for (uint32_t i = tid; i < PREP2_ROUND; i += PREP_THREADS) { const uint32_t s = r * PREP2_ROUND + i; if (s < S) out[s] = tile[i]; }
+    }
+}
+
 /* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW channel at
  * order P0 = layer-0 size, then Levinson-Durbin.  One block per (frame, channel): all threads window a chunk of samples
  * and form the lag products into LDS, then lane `lag` adds its products in sample order -- one chain per lag, as in the
@@ -192,6 +366,135 @@ __global__ __launch_bounds__(STAT_THREADS) void k_stats(Plan p)
         for (uint32_t i = 0; i < 8; i++) pc[i] = 0.0;
         if (!zero) levinson(rl, r0, P0, a, pc);
         st[LINNE_AMD_ST_R0] = rl[0];
+        st[LINNE_AMD_ST_K1 + 0] = pc[1]; st[LINNE_AMD_ST_K1 + 1] = pc[2]; st[LINNE_AMD_ST_K1 + 2] = pc[3];
+        st[LINNE_AMD_ST_ZERO] = zero ? 1.0 : 0.0;
+    }
+}
+
+/* k_stats_rows: the same statistics with lanes = channel-frames, for batches (k_stats keeps the small ones: it finishes a single
+ * block sooner).  A block takes 64 channel-frames and P0 + 1 waves; all waves load: 16 samples of 64 rows per tile, coalesced
+ * 16-byte (int16: 8-byte) loads, converted, scaled and SIN-windowed once, transposed into LDS (row stride 65).  Wave `lag` then
+ * walks the positions: lane = channel-frame adds v[m - lag] * v[m] to its chain in sample order -- the reference's products in the
+ * reference's order (lpc.c:215-249 after :188-195); the last `lag` values ride in registers (the position loop is unrolled over
+ * the ring's turn).  Zeros stand in front of sample 0 and behind a frame's end: adding +-0.0 leaves a chain's bits unchanged.
+ * 485 blocks serve the 60-minute stereo track where k_stats launches 31 008, each of which has five lanes adding while 251 wait:
+ * 3.1 ms beside k_prep (and 2.6 ms of the step lost to the crowding) became a fraction of a millisecond. */
+#define STATR_T 16                      /* positions per tile (64 was measured: slower -- 69 KB of LDS leave two blocks per CU and the kernel lives beside k_prep) */
+template <int LAG, typename IssueNext, typename CommitNext>
+__device__ __forceinline__ double stats_rows_chain(const double (*xt)[STATR_T][65], uint32_t lane, uint32_t ntiles, IssueNext &&issue_next, CommitNext &&commit_next)
+{
+    double r = 0.0, ring[LAG ? LAG : 1];
+#pragma unroll
+    for (int k = 0; k < (LAG ? LAG : 1); k++) ring[k] = 0.0;
+    constexpr int TURN = LAG ? LAG : 1;                     /* the tile length (16) is a multiple of 1, 2 and 4: the ring index is a constant; 3 needs the modulo below */
+#pragma unroll 1
+    for (uint32_t ti = 0; ti < ntiles; ti++) {
+        const uint32_t buf = ti & 1u;
+        issue_next(ti);                                     /* the next tile's loads are requested now and land in LDS behind this tile's work */
+        if (LAG == 3) {
+#pragma unroll 1
+            for (uint32_t m = 0; m < (uint32_t)STATR_T; m++) {
+                const double v = xt[buf][m][lane];
+                r += ring[0] * v;
+                ring[0] = ring[1]; ring[1] = ring[2]; ring[2] = v;
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t m0 = 0; m0 < (uint32_t)STATR_T; m0 += 16u) {
+#pragma unroll
+                for (int m = 0; m < 16; m++) {              /* 16 is a multiple of the ring's turn: its index is a constant */
+                    const double v = xt[buf][m0 + m][lane];
+                    if (LAG == 0) r += v * v;
+                    else { r += ring[m % TURN] * v; ring[m % TURN] = v; }
+                }
+            }
+        }
+        commit_next(ti);
+        __syncthreads();
+    }
+    return r;
+}
+
+template <int NW, bool P16>          /* NW = P0 + 1 waves (3 or 5); P16: the PCM is staged as int16.  The host launches it only for S % 4 == 0 */
+__global__ __launch_bounds__(64 * NW, 2) void k_stats_rows(Plan p)
+{
+    constexpr uint32_t NPIECE = 64u * (STATR_T / 4u), NTH = 64u * NW, NP = (NPIECE + NTH - 1u) / NTH;     /* loader pieces (a row's 4 consecutive samples) per thread and tile */
+    __shared__ __attribute__((aligned(16))) double xt[2][STATR_T][65];
+    __shared__ double rl[5][64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const uint32_t P0 = p.P[0], C = p.C, S = p.S, nrows = p.F * C, row0 = blockIdx.x * 64u;
+    /* my row as a chain owner (lane) */
+    uint32_t row = row0 + lane; const bool mine = row < nrows; if (!mine) row = nrows - 1u;
+    const DevClass &c = p.cls[p.cls_of_frame[row / C]];
+    const uint32_t my_n = mine ? c.n : 0u;
+    uint32_t n_blk = my_n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)n_blk, o); n_blk = v > n_blk ? v : n_blk; }
+    n_blk = (uint32_t)__builtin_amdgcn_readfirstlane((int)n_blk);
+    const uint32_t ntiles = (n_blk + STATR_T - 1u) / STATR_T;
+    /* my loader pieces: piece pc = row pc / 16, samples 4 (pc % 16) .. + 3 of the tile; everything that does not depend on the tile
+     * is set up once.  A tile's loads are ALL issued before any is used (no branches between them: addresses are clamped, the
+     * values masked afterwards) */
+    size_t pbase[NP]; uint32_t pn[NP], plsm[NP], plrow[NP]; const double *psw[NP];
+#pragma unroll
+    for (uint32_t q = 0; q < NP; q++) {
+        const uint32_t pc = tid + q * NTH, pcc = pc < NPIECE ? pc : 0u;
+        plrow[q] = pcc / (STATR_T / 4u); plsm[q] = 4u * (pcc % (STATR_T / 4u));
+        uint32_t r = row0 + plrow[q]; const bool have = (pc < NPIECE) && r < nrows; if (r >= nrows) r = nrows - 1u;
+        const uint32_t fr = r / C, ch = r % C;
+        const DevClass &lc = p.cls[p.cls_of_frame[fr]];
+        pn[q] = have ? lc.n : 0u;
+        pbase[q] = ((size_t)p.frame_map[fr] * C + ch) * S;
+        psw[q] = p.sintab + lc.sin_off;
+    }
+    int4 raw[NP]; double sv[NP][4];
+    auto issue = [&](uint32_t ti) {
+#pragma unroll
+        for (uint32_t q = 0; q < NP; q++) {
+            const uint32_t s = ti * STATR_T + plsm[q], sc = (s + 3u < S) ? s : 0u;          /* (S % 4 == 0: a piece is inside the row or behind its end) */
+            if (P16) { const short4 v = *(const short4 *)((const int16_t *)p.pcm + pbase[q] + sc); raw[q] = make_int4(v.x, v.y, v.z, v.w); }
+            else raw[q] = *(const int4 *)(p.pcm + pbase[q] + sc);
+            const uint32_t last = pn[q] ? pn[q] - 1u : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4u; j++) sv[q][j] = psw[q][(s + j < pn[q]) ? (s + j) : last];
+        }
+    };
+    auto commit = [&](uint32_t ti, uint32_t buf) {
+#pragma unroll
+        for (uint32_t q = 0; q < NP; q++) {
+            if (tid + q * NTH < NPIECE) {
+                const uint32_t s = ti * STATR_T + plsm[q];
+                const int32_t v[4] = { raw[q].x, raw[q].y, raw[q].z, raw[q].w };
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; j++) xt[buf][plsm[q] + j][plrow[q]] = (s + j < pn[q]) ? ((double)v[j] * p.scale) * sv[q][j] : 0.0;   /* lpc.c:192: the window on the scaled sample */
+            }
+        }
+    };
+    if (ntiles == 0) return;
+    issue(0); commit(0, 0);
+    __syncthreads();
+    auto issue_next = [&](uint32_t ti) { if (ti + 1u < ntiles) issue(ti + 1u); };
+    auto commit_next = [&](uint32_t ti) { if (ti + 1u < ntiles) commit(ti + 1u, (ti + 1u) & 1u); };        /* (that buffer was last read in tile ti - 1, a barrier ago) */
+    double r;
+    switch (wave) {
+    case 0: r = stats_rows_chain<0>(xt, lane, ntiles, issue_next, commit_next); break;
+    case 1: r = stats_rows_chain<1>(xt, lane, ntiles, issue_next, commit_next); break;
+    case 2: r = stats_rows_chain<2>(xt, lane, ntiles, issue_next, commit_next); break;
+    case 3: r = stats_rows_chain<3>(xt, lane, ntiles, issue_next, commit_next); break;
+    default: r = stats_rows_chain<4>(xt, lane, ntiles, issue_next, commit_next); break;
+    }
+    rl[wave][lane] = r;
+    __syncthreads();
+    if (wave == 0 && mine) {
+        double a[8], pc[8], rr[8];
+        const uint32_t fr = row / C, ch = row % C;
+        double *st = p.stats + ((size_t)p.frame_map[fr] * C + ch) * LINNE_AMD_STAT_WORDS;
+        for (uint32_t i = 0; i <= P0; i++) rr[i] = rl[i][lane];
+        const double r0 = rr[0] * (1.0 + 0.0);
+        const int zero = (my_n < P0) || (fabs(r0) < (double)FLT_EPSILON);
+        for (uint32_t i = 0; i < 8; i++) pc[i] = 0.0;
+        if (!zero) levinson(rr, r0, P0, a, pc);
+        st[LINNE_AMD_ST_R0] = rr[0];
         st[LINNE_AMD_ST_K1 + 0] = pc[1]; st[LINNE_AMD_ST_K1 + 1] = pc[2]; st[LINNE_AMD_ST_K1 + 2] = pc[3];
         st[LINNE_AMD_ST_ZERO] = zero ? 1.0 : 0.0;
     }

@@ -857,3 +857,39 @@ def test_rice_decode_device_reads_no_further_than_its_contract(ctx):
         for f in range(k):
             assert np.array_equal(got[f, 0, :ns[f]], want[f, 0, :ns[f]]), f"{k} frames, frame {f}"
             assert int(eb[f]) == int(off[f]) * 8 + int(nbits[f]), f"{k} frames, frame {f}: end position"
+
+
+@pytest.mark.parametrize("stats_rows,prep_general", [("1", "0"), ("0", "1"), ("1", "1")])
+def test_prep_and_statistics_forms_agree(ctx, product, oracle, monkeypatch, stats_rows, prep_general):
+    """k_prep keeps the channel in registers (blocks up to 10 240 samples, exact-integer correlations) or streams it through
+    global memory (LINNE_AMD_PREP_GENERAL=1; any length; loud 24-bit material takes the ordered double chains either way); the
+    block-type statistics come from k_stats (a block per channel-frame) or k_stats_rows (lanes = channel-frames;
+    LINNE_AMD_STATS_ROWS).  Whatever the form: the oracle's pre-emphasis, SIN-window r0, parameters and residual on full
+    frames, ragged tails, both layer-0 orders (presets 0 / 7), 3 and 8 channels, loud 24-bit, and the oracle's bytes across
+    SILENT / RAW / COMPRESS blocks (the decision reads the statistics)"""
+    monkeypatch.setenv("LINNE_AMD_STATS_ROWS", stats_rows)
+    monkeypatch.setenv("LINNE_AMD_PREP_GENERAL", prep_general)
+    for nch, bits, block, preset, tail, loud in [(2, 16, 10240, 7, 9280, False), (1, 16, 1024, 0, 130, False), (8, 24, 4096, 7, 1000, True),
+                                                 (3, 8, 1024, 2, 1023, False), (2, 16, 2048, 1, 2048, False), (2, 24, 10240, 5, 681, True)]:
+        ms = nch >= 2
+        F = 5
+        frames = music_frames(F, nch, block, bits, seed=500 + block + preset)
+        if loud:
+            frames = np.clip(frames.astype(np.int64) * 3, -(1 << (bits - 1)), (1 << (bits - 1)) - 1).astype(np.int32)
+        frames[2] = waveform("chirp", nch, block, bits, seed=9)
+        ns = np.full(F, block, dtype=np.uint32); ns[-1] = tail
+        frames[-1, :, tail:] = 0
+        shape = ctx.shape(nch, bits, block, preset, ms)
+        res, prm, st = ctx.encode_frames_host(shape, frames, ns)
+        enc = oracle.encoder(nch, bits, 44100, block, preset, ms)
+        for f in range(F):
+            n = int(ns[f])
+            tap, ores = enc.hotpath(frames[f][:, :n])
+            _check_taps(tap, prm[f], st[f], preset, nch, f"{nch}ch {bits}bit block {block} -m {preset} frame {f}")
+            assert np.array_equal(ores, res[f][:, :n])
+        enc.close()
+    block = 2048
+    x = np.concatenate([music(2, 5 * block, 16, seed=31), np.zeros((2, 2 * block), dtype=np.int32), waveform("white_noise", 2, 2 * block, 16, seed=5),
+                        music(2, 3 * block + 555, 16, seed=32)], axis=1)
+    for preset in (7, 0):
+        assert product.encode_whole(x, 16, 44100, block, preset, True) == oracle.encode_whole(x, 16, 44100, block, preset, True)
