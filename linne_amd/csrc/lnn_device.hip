@@ -851,10 +851,16 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                     span_end(ctx, sp_, st);
                 }
             }
-            { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 0u); span_end(ctx, sp_, st); }
+            const bool sel_wave = Jq <= 256u && (uint64_t)((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64) <= SELW_MAXPART;       /* a handful of jobs: a wave per job */
+            { const int sp_ = span_begin(ctx, 7, st);
+              if (sel_wave) hipLaunchKernelGGL(k_select_wave, dim3((uint32_t)Jq), dim3(64), 0, st, q, l, 0u);
+              else hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 0u);
+              span_end(ctx, sp_, st); }
             /* exact ordered chains for the (rare) jobs the certified search flagged; everything else exits at once */
             { const int sp_ = span_begin(ctx, 6, st); if (l == 0) hipLaunchKernelGGL((k_fir2<0, true, false>), dim3((uint32_t)Jq, 1), dim3(FIR_THREADS), 0, st, q, l, cur); else hipLaunchKernelGGL((k_fir2<0, false, false>), dim3((uint32_t)Jq, 1), dim3(FIR_THREADS), 0, st, q, l, cur);
-              hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 1u); span_end(ctx, sp_, st); }
+              if (sel_wave) hipLaunchKernelGGL(k_select_wave, dim3((uint32_t)Jq), dim3(64), 0, st, q, l, 1u);
+              else hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 1u);
+              span_end(ctx, sp_, st); }
             /* the last layer's output is only ever summed: layers of <= 16 taps do the forward pass and the ordered loss in one
              * kernel and write nothing else */
             if (l + 1 == hs.L && fcfg && !final_pass) {

@@ -737,7 +737,7 @@ template <int P> struct ApCfg {
     static constexpr int NT = (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2;
     static constexpr int nch() { int s = 0; for (int t = 0; t < NT; t++) s += (P >> t) + 1; return s; }      /* 36, 19, 10, 5 */
     static constexpr int NCH = nch();
-    static constexpr int CHUNK = (P >= 16) ? 64 : (P >= 8) ? 128 : 256;
+    static constexpr int CHUNK = (P >= 16) ? 128 : (P >= 8) ? 128 : 256;      /* (64 for P = 16 was measured: 162 trips of ~1.1 us, whatever a trip held) */
     static constexpr int trial_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return t; }
     static constexpr int lag_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return ch; }
 };
@@ -749,9 +749,9 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
     static_assert(NCH <= 64, "one wave adds up all chains");
     __shared__ double sv[2][NT][CHUNK + P];
     __shared__ uint32_t srem[2][NT][CHUNK + P];
-    /* rows padded by one double: adder lane c walks row c, and a lane stride of CHUNK doubles (512 B .. 2 KB) would put every lane
-     * on the same LDS bank -- an NCH-way conflict on every read of the dependent chain */
-    __shared__ double sprod[2][NCH][CHUNK + 1];
+    /* rows padded by two doubles: adder lane c walks row c, and a lane stride of CHUNK doubles (512 B .. 2 KB) would put every lane
+     * on the same LDS bank -- an NCH-way conflict on every read of the dependent chain; two keep a row 16-byte aligned (ds_read_b128) */
+    __shared__ __attribute__((aligned(16))) double sprod[2][NCH][CHUNK + 2];
     const uint32_t row = blockIdx.x, tid = threadIdx.x, job = L0 ? row * p.R : row;
     const DevClass &c = job_class(p, job);
     const uint32_t na = c.na;
@@ -821,12 +821,12 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
                         for (int t = 0; t < NT; t++) { dst[t][i] = px[m] * pw[m][t]; drem[t][i] = prem[m][t]; }     /* (0.0 * 0.0 beyond the frame's end) */
                     }
                 }
-                if (k + 1u < nchunks) prefetch(k + 1u);
+                if (k + 1u < nchunks && p.dbg_maxtr != 103u) prefetch(k + 1u);
             }
-            if (k >= 1u && k - 1u < nchunks) {                      /* the pairs of chunk k - 1: both samples inside the same unit, else +0.0 (no effect on the bits) */
+            if (k >= 1u && k - 1u < nchunks && p.dbg_maxtr != 102u) {                      /* the pairs of chunk k - 1: both samples inside the same unit, else +0.0 (no effect on the bits) */
                 const double (*src)[CHUNK + P] = sv[(k - 1u) & 1u];
                 const uint32_t (*rem)[CHUNK + P] = srem[(k - 1u) & 1u];
-                double (*dst)[CHUNK + 1] = sprod[(k - 1u) & 1u];
+                double (*dst)[CHUNK + 2] = sprod[(k - 1u) & 1u];
                 /* all reads first, then all writes: the compiler cannot know that `src` and `dst` never overlap and would wait out
                  * every element's LDS trip before starting the next */
                 double av[NPM], bv[NPM]; uint32_t rv[NPM];
@@ -845,17 +845,32 @@ __global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, u
                     }
                 }
             }
-        } else if (k >= 2u && tid < (uint32_t)NCH) {                /* add up chunk k - 2 */
+        } else if (k >= 2u && tid < (uint32_t)NCH && p.dbg_maxtr != 101u) {                /* add up chunk k - 2 */
             const uint32_t base = (k - 2u) * CHUNK;
             const uint32_t cnt = (na - base < (uint32_t)CHUNK) ? (na - base) : (uint32_t)CHUNK;
             const double *q = sprod[k & 1u][tid];
             uint32_t i = 0;
             while (i < cnt) {                                       /* runs that end at the chunk's or the unit's end */
                 const uint32_t seg = (cnt - i < cn - cloc) ? (cnt - i) : (cn - cloc), end = i + seg;
-                for (; i + 8 <= end; i += 8) {
-                    const double q0 = q[i], q1 = q[i + 1], q2 = q[i + 2], q3 = q[i + 3], q4 = q[i + 4], q5 = q[i + 5], q6 = q[i + 6], q7 = q[i + 7];
-                    r += q0; r += q1; r += q2; r += q3; r += q4; r += q5; r += q6; r += q7;
+                /* The chain is all this lane does, and a lone wave issues an instruction every ~9 cycles: what counts is the number
+                 * of instructions per add.  Sixteen products per trip, in two register sets: the next eight are requested before the
+                 * current eight are added, nothing is copied (1.7 instructions per add; the plain loop's 8 reads + 8 adds + waits came to
+                 * 30 cycles per add, 127 us for the 4-tap layer of one block).  Unit lengths and chunks are even, so i is: 16-byte reads */
+#define AP_LOAD(A, OFF) { const lnn_d2 *q2_ = (const lnn_d2 *)(q + i + (OFF)); A##0 = q2_[0]; A##1 = q2_[1]; A##2 = q2_[2]; A##3 = q2_[3]; }
+#define AP_ADD(A) { r += (A##0).x; r += (A##0).y; r += (A##1).x; r += (A##1).y; r += (A##2).x; r += (A##2).y; r += (A##3).x; r += (A##3).y; }
+                if (i + 16 <= end) {
+                    lnn_d2 a0, a1, a2, a3, b0, b1, b2, b3;
+                    AP_LOAD(a, 0)
+                    for (; i + 16 <= end; i += 16) {
+                        AP_LOAD(b, 8)
+                        AP_ADD(a)
+                        if (i + 24 <= end) AP_LOAD(a, 16)
+                        AP_ADD(b)
+                    }
                 }
+                if (i + 8 <= end) { lnn_d2 a0, a1, a2, a3; AP_LOAD(a, 0) AP_ADD(a) i += 8; }
+#undef AP_LOAD
+#undef AP_ADD
                 for (; i < end; i++) r += q[i];
                 cloc += seg;
                 if (cloc == cn) { cout[(size_t)cunit * (cnp + 1)] = r; r = 0.0; cloc = 0; cunit++; }

@@ -603,5 +603,85 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
     }
 }
 
+/* k_select for a handful of jobs (block-at-a-time calls): a wave per job.  One thread per job walks ~180 partial sums and copies up
+ * to 128 coefficients one dependent trip to memory after the other (41 us for the 128-tap layer of a stereo block); here the lanes
+ * fetch everything at once into LDS, lane 0 takes the decision with k_select's own arithmetic in k_select's own order (the same
+ * flags, the same telemetry), and all lanes copy the winner's coefficients. */
+#define SELW_MAXPART 64u
+__global__ __launch_bounds__(64) void k_select_wave(Plan p, uint32_t layer, uint32_t exact)
+{
+    __shared__ double s_sum[LNN_MAXT][SELW_MAXPART], s_xmax[SELW_MAXPART], s_loss[LNN_MAXT], s_hsum[LNN_MAXT];
+    __shared__ uint32_t s_best;
+    const uint32_t job = blockIdx.x, lane = threadIdx.x;
+    if (exact && !p.uncertain[job]) return;
+    const DevClass &c = job_class(p, job);
+    const uint32_t nt = c.ntrials[layer];
+    const uint32_t np_used = ((c.na + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64);       /* <= SELW_MAXPART: the host checks */
+    if (exact) { if (lane < nt) s_loss[lane] = p.tloss[(size_t)job * LNN_MAXT + lane]; }
+    else {
+        for (uint32_t i = lane; i < nt * np_used; i += 64u) { const uint32_t t = i / np_used, k = i % np_used; s_sum[t][k] = p.tsum[((size_t)job * LNN_MAXT + t) * p.npart + k]; }
+        if (lane < np_used) s_xmax[lane] = p.txmax[(size_t)job * p.npart + lane];
+        if (lane < nt) s_hsum[lane] = p.thsum[(size_t)job * LNN_MAXT + lane];
+    }
+    __syncthreads();
+    if (lane == 0) {
+        double min_loss = (double)FLT_MAX;
+        uint32_t best = 0;
+        if (exact) {
+            for (uint32_t t = 0; t < nt; t++) { const double l = s_loss[t]; if (l < min_loss) { min_loss = l; best = t; } }
+        } else {        /* (k_select's certificate, statement for statement) */
+            double m[LNN_MAXT], slack[LNN_MAXT];
+            const double rel = (2.0 * (double)c.na + 8.0) * 1.1102230246251565e-16;
+            int ok = 1;
+            double xmax = 0.0;
+            for (uint32_t i = 0; i < np_used; i++) xmax = fmax(xmax, s_xmax[i]);
+            for (uint32_t t = 0; t < nt; t++) {
+                const double npt = (double)(p.P[layer] / c.trial_u[layer][t]);
+                slack[t] = 4.0 * (npt + 2.0) * 1.1102230246251565e-16 * xmax * (1.0 + s_hsum[t]);
+                if (!(slack[t] >= 0.0) || !(slack[t] < (double)FLT_MAX)) ok = 0;
+            }
+            for (uint32_t t = 0; t < nt; t++) {
+                double sm = 0.0;
+                for (uint32_t i = 0; i < np_used; i++) sm += s_sum[t][i];
+                m[t] = sm / (double)c.na;
+                if (!(m[t] >= 0.0) || !(m[t] < (double)FLT_MAX)) ok = 0;
+                if (m[t] < min_loss) { min_loss = m[t]; best = t; }
+            }
+            const double hi_best = min_loss * (1.0 + rel) + slack[best];
+            double gap = (double)FLT_MAX;
+            for (uint32_t t = 0; t < nt; t++) if (t != best) {
+                const double lo = m[t] * (1.0 - rel) - slack[t];
+                if (!(lo > hi_best)) ok = 0;
+                gap = fmin(gap, lo - hi_best);
+            }
+            if (ok && nt > 1 && min_loss > 0.0) atomicMin(p.min_margin, (unsigned long long)__double_as_longlong(gap / min_loss));
+            if (p.force_exact) ok = 0;
+            p.uncertain[job] = ok ? 0 : 1;
+            if (!ok) atomicAdd(p.ucount, 1u);
+        }
+        s_best = best;
+        p.lunits[(size_t)job * LNN_MAXL + layer] = c.trial_u[layer][best];
+        if (layer + 1 == p.L) {
+            double tail = 0.0; int set = 0;
+            const uint32_t bu = c.trial_u[layer][best];
+            for (int32_t unit = (int32_t)bu - 1; unit >= 0 && !set; unit--) {
+                const size_t o = ((size_t)job * LNN_MAXT + best) * LNN_MAXU + unit;
+                if (p.ptail_set[o]) { tail = p.ptail[o]; set = 1; }
+            }
+            for (int32_t t = (int32_t)c.ntrials[layer] - 1; t >= 0 && !set; t--)
+                for (int32_t unit = (int32_t)c.trial_u[layer][t] - 1; unit >= 0 && !set; unit--) {
+                    const size_t o = ((size_t)job * LNN_MAXT + t) * LNN_MAXU + unit;
+                    if (p.ptail_set[o]) { tail = p.ptail[o]; set = 1; }
+                }
+            p.jtail[job] = tail;
+        }
+    }
+    __syncthreads();
+    const uint32_t P = p.P[layer], best = s_best;
+    const double *h = p.tcoef + ((size_t)job * LNN_MAXT + best) * LNN_MAXP;
+    double *dst = p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP;
+    for (uint32_t k = lane; k < P; k += 64u) dst[k] = h[k];
+}
+
 
 #endif

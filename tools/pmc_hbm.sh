@@ -8,5 +8,5 @@ mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$out/f" -o p --output-format csv -- python3 tools/kbench.py --frames 4096 --reps 1 --no-timing --decode > "$out/f.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$out/w" -o p --output-format csv -- python3 tools/kbench.py --frames 4096 --reps 1 --no-timing --decode > "$out/w.log" 2>&1
-python3 tools/pmc_traffic.py "$out/f/p_counter_collection.csv" "$out/w/p_counter_collection.csv" 4096 2
+python3 tools/pmc_traffic.py "$out/f/p_counter_collection.csv" "$out/w/p_counter_collection.csv" 4096 2 "${2:-}"
 cp profiles/pmc_latest.json "$out/pmc_latest.json"
