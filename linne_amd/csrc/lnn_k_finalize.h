@@ -7,17 +7,18 @@
  * finalize per channel-frame: best regulariser, quantisation, int32 FIR cascade
  * ---------------------------------------------------------------------------------------------- */
 #define FIN_THREADS 256
-__global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
+#define FIN_TILE (4 * FIN_THREADS)          /* output samples per block of the cascade */
+#define FIN_HALO (LNN_MAXL * LNN_MAXP)      /* >= the taps of all layers together: what a tile recomputes in front of itself */
+
+/* k_quantize, per channel-frame: the best regulariser (linne_encoder.c:618-626), the quantiser (lpc.c:981-1040 over all units of a
+ * layer together), the parameter record and the statistics record.  One wave; lanes 0 .. L-1 quantise a layer each. */
+__global__ __launch_bounds__(64) void k_quantize(Plan p)
 {
-    __shared__ int32_t s_coef[LNN_MAXL][LNN_MAXP];
-    __shared__ uint32_t s_rshift[LNN_MAXL], s_units[LNN_MAXL], s_best;
+    __shared__ uint32_t s_best;
     const uint32_t cf = blockIdx.x, tid = threadIdx.x;
-    const DevClass &c = p.cls[p.cls_of_frame[cf / p.C]];
-    const uint32_t n = c.n, S = p.S;
     const size_t ocf = (size_t)p.frame_map[cf / p.C] * p.C + cf % p.C;     /* the caller's channel-frame behind row cf of the class-sorted chunk */
     int32_t *rec = p.prm + ocf * LINNE_AMD_PARAM_WORDS;
     double *st = p.stats + ocf * LINNE_AMD_STAT_WORDS;
-
     if (tid == 0) {     /* linne_network.c:618-626 */
         double min_loss = (double)FLT_MAX; uint32_t best = 0;
         for (uint32_t r = 0; r < p.R; r++) { const double l = p.jloss[(size_t)cf * p.R + r]; if (l < min_loss) { min_loss = l; best = r; } }
@@ -27,18 +28,22 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
         st[LINNE_AMD_ST_LOSS] = p.af_loss ? p.af_loss[cf] : p.jloss[(size_t)cf * p.R + best];
     }
     /* the record is written completely, whatever the caller's buffer held: words this preset does not use are zero */
-    for (uint32_t i = LINNE_AMD_PRM_UNITS + tid; i < LINNE_AMD_PARAM_WORDS; i += FIN_THREADS) rec[i] = 0;
+    uint32_t used = LINNE_AMD_PRM_COEF;
+    for (uint32_t l = 0; l < p.L; l++) used += p.P[l];
+    for (uint32_t i = LINNE_AMD_PRM_UNITS + tid; i < LINNE_AMD_PARAM_WORDS; i += 64u)
+        if ((i >= LINNE_AMD_PRM_UNITS + p.L && i < LINNE_AMD_PRM_RSHIFT) || (i >= LINNE_AMD_PRM_RSHIFT + p.L && i < LINNE_AMD_PRM_COEF) || i >= used) rec[i] = 0;
     __syncthreads();
     const uint32_t job = cf * p.R + s_best;
     if (tid < p.L) {    /* lpc.c:981-1040 over all units of the layer together */
         const uint32_t l = tid, P = p.P[l];
         const double *d = p.lparams + ((size_t)job * LNN_MAXL + l) * LNN_MAXP;
+        int32_t *cq = rec + LINNE_AMD_PRM_COEF + p.coef_off[l];
         double mx = 0.0;
         for (uint32_t k = 0; k < P; k++) if (mx < fabs(d[k])) mx = fabs(d[k]);
         uint32_t rshift;
         if (mx <= 0.0078125) {                              /* 2^-(8-1) */
             rshift = 8;
-            for (uint32_t k = 0; k < P; k++) s_coef[l][k] = 0;
+            for (uint32_t k = 0; k < P; k++) cq[k] = 0;
         } else {
             int ndigit; (void)frexp(mx, &ndigit);
             rshift = (uint32_t)(7 - ndigit);
@@ -49,90 +54,140 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(Plan p)
                 int32_t q = (int32_t)round_away(qerr);
                 if (q >= 128) q = 127; else if (q < -128) q = -128;
                 qerr -= (double)q;
-                s_coef[l][k] = q;
+                cq[k] = q;
             }
         }
-        s_rshift[l] = rshift;
-        s_units[l] = p.lunits[(size_t)job * LNN_MAXL + l];
-        rec[LINNE_AMD_PRM_UNITS + l] = (int32_t)s_units[l];
+        rec[LINNE_AMD_PRM_UNITS + l] = (int32_t)p.lunits[(size_t)job * LNN_MAXL + l];
         rec[LINNE_AMD_PRM_RSHIFT + l] = (int32_t)rshift;
-        for (uint32_t k = 0; k < P; k++) rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + k] = s_coef[l][k];
+    }
+}
+
+/* k_fir_cascade: the int32 FIR cascade (linne_encoder.c:687-696, linne_lpc_predict.c:7-38) of a channel-frame, a block per tile of
+ * 1024 outputs.  The cascade has no recurrence -- layer l's output at s is a function of layer l - 1's outputs at s - np .. s of the
+ * same unit -- so a tile recomputes what it needs of the layers in front of it: the input with sum P taps of history goes into LDS
+ * once, every layer works LDS to LDS (its output range shrinks by its own taps), and only the residual is written.  Traffic: the
+ * channel in (plus 14 % of halo), the residual out -- the form that streamed every layer through xint / xtmp moved 250 KB per
+ * channel-frame and kept a channel-frame in ONE block (two blocks busy on a 256-CU chip for a stereo block-at-a-time call). */
+__global__ __launch_bounds__(FIN_THREADS) void k_fir_cascade(Plan p)
+{
+    __shared__ __attribute__((aligned(16))) int32_t s_coef[LNN_MAXL][LNN_MAXP];
+    __shared__ __attribute__((aligned(16))) int32_t bufs[2][FIN_HALO + 4 + FIN_TILE];
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x, s0 = blockIdx.y * FIN_TILE;
+    const DevClass &c = p.cls[p.cls_of_frame[cf / p.C]];
+    const uint32_t n = c.n, S = p.S, L = p.L;
+    const size_t ocf = (size_t)p.frame_map[cf / p.C] * p.C + cf % p.C;
+    const int32_t *rec = p.prm + ocf * LINNE_AMD_PARAM_WORDS;
+    int32_t *out = p.resid + ocf * S;
+    if (s0 >= n) {                                            /* behind the frame's end: zeros (linne_encoder.c:613-621 padded the input) */
+        for (uint32_t i = tid; i < FIN_TILE; i += FIN_THREADS) if (s0 + i < S) out[s0 + i] = 0;
+        return;
+    }
+    uint32_t H = 0;
+    for (uint32_t l = 0; l < L; l++) H += p.P[l];            /* taps of all layers: the history the tile needs (<= FIN_HALO) */
+    const uint32_t Hp = (H + 3u) & ~3u;                       /* rounded up: sample s0 sits at a 16-byte boundary of the buffers */
+    const int32_t *src = p.xint + (size_t)cf * S;
+    /* buffer index i <-> sample s0 - Hp + i */
+    {
+        constexpr int NPF = (FIN_HALO + 4 + FIN_TILE + FIN_THREADS - 1) / FIN_THREADS;
+        int32_t pf[NPF];
+#pragma unroll
+        for (int m = 0; m < NPF; m++) {
+            const uint32_t i = tid + (uint32_t)m * FIN_THREADS;
+            const int64_t g = (int64_t)s0 - Hp + i;
+            pf[m] = (i < Hp + FIN_TILE && g >= 0 && g < (int64_t)n) ? src[g] : 0;
+        }
+        for (uint32_t i = tid; i < L * LNN_MAXP; i += FIN_THREADS) { const uint32_t l = i / LNN_MAXP, k = i % LNN_MAXP; if (k < p.P[l]) s_coef[l][k] = rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + k]; }
+#pragma unroll
+        for (int m = 0; m < NPF; m++) { const uint32_t i = tid + (uint32_t)m * FIN_THREADS; if (i < Hp + FIN_TILE) bufs[0][i] = pf[m]; }
     }
     __syncthreads();
-    /* FIR cascade (linne_encoder.c:687-696, linne_lpc_predict.c:7-38) on the n valid samples; each layer streams the
-     * channel through an LDS tile (1024 samples + 128 of history) so the tap loop reads LDS, not global memory */
-    __shared__ int32_t xt[LNN_MAXP + 4 * FIN_THREADS];
-    int32_t *src = p.xint + (size_t)cf * S, *dst = p.xtmp + (size_t)cf * S;
-    for (uint32_t l = 0; l < p.L; l++) {
-        const uint32_t units = s_units[l], np = p.P[l] / units, ns = n / units, rs = s_rshift[l];
+    uint32_t lead = H;                                        /* samples in front of s0 that the current input buffer holds valid */
+    for (uint32_t l = 0; l < L; l++) {
+        const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
+        const uint32_t np = p.P[l] / (units ? units : 1u), ns = units ? n / units : 0u;
         const uint32_t half = 1u << ((rs - 1u) & 31u);
-        int32_t *out = (l + 1 == p.L) ? (p.resid + ocf * S) : dst;
-        /* the tile's samples are requested one tile ahead (registers), so that a block does not sit out a trip to memory per tile */
-        constexpr int NPF = (LNN_MAXP + 4 * FIN_THREADS + FIN_THREADS - 1) / FIN_THREADS;
-        int32_t pf[NPF];
-        auto prefetch = [&](uint32_t s0_) {
-#pragma unroll
-            for (int m = 0; m < NPF; m++) {
-                const uint32_t i = tid + (uint32_t)m * FIN_THREADS;
-                const int64_t g = (int64_t)s0_ - LNN_MAXP + i;
-                pf[m] = (i < LNN_MAXP + 4 * FIN_THREADS && g >= 0 && g < (int64_t)n) ? src[g] : 0;
-            }
-        };
-        prefetch(0);
-        for (uint32_t s0 = 0; s0 < n; s0 += 4 * FIN_THREADS) {
-            __syncthreads();
-#pragma unroll
-            for (int m = 0; m < NPF; m++) { const uint32_t i = tid + (uint32_t)m * FIN_THREADS; if (i < LNN_MAXP + 4 * FIN_THREADS) xt[i] = pf[m]; }
-            if (s0 + 4 * FIN_THREADS < n) prefetch(s0 + 4 * FIN_THREADS);
-            __syncthreads();
-            {   /* a lane owns 4 consecutive samples: when they sit in one unit past its first np samples (the usual case) the
-                 * taps slide a 4-wide register window over the tile, one coefficient and one new sample per tap for four
-                 * multiply-adds (int32 wrap-around: any order); otherwise sample by sample */
-                const uint32_t e0 = 4 * tid, sb = s0 + e0;
-                const uint32_t nsd = ns ? ns : 1u;
-                const uint32_t unit0 = sb / nsd, loc0 = sb - unit0 * nsd;
-                const bool quad = (sb + 3 < n) && (ns >= np) && (unit0 < units) && (loc0 >= np) && (loc0 + 3 < ns);
+        const bool last = (l + 1 == L);
+        const int32_t *in = bufs[l & 1u];
+        int32_t *ob = bufs[(l & 1u) ^ 1u];
+        const uint32_t olead = lead - p.P[l];                 /* this layer's outputs start olead samples in front of s0 */
+        const uint32_t count = olead + FIN_TILE;
+        /* a lane owns 4 consecutive samples: when they sit in one unit past its first np samples (the usual case) the taps slide a
+         * 4-wide register window over the buffer, one coefficient and one new sample per tap for four multiply-adds (int32
+         * wrap-around: any order); otherwise sample by sample */
+        for (uint32_t e0 = 4u * tid; e0 < count; e0 += 4u * FIN_THREADS) {
+            const int64_t sb64 = (int64_t)s0 - olead + e0;    /* first of my 4 samples (may lie before sample 0 in the first tile) */
+            const uint32_t bi = Hp - olead + e0;              /* its buffer index */
+            int32_t o[4];
+            const uint32_t nsd = ns ? ns : 1u;
+            bool quad = false;
+            if (sb64 >= 0 && sb64 + 3 < (int64_t)n && units && ns >= np) {
+                const uint32_t sb = (uint32_t)sb64, unit0 = sb / nsd, loc0 = sb - unit0 * nsd;
+                quad = (unit0 < units) && (loc0 >= np) && (loc0 + 3 < ns);
                 if (quad) {
                     const int32_t *cc = s_coef[l] + unit0 * np;
-                    const int32_t *xx = xt + LNN_MAXP + e0 - np;      /* -> x[sb - np] */
+                    const int32_t *xx = in + bi - np;             /* -> x[sb - np] */
                     uint32_t p0 = half, p1 = half, p2 = half, p3 = half;
+                    if ((np & 3u) == 0 && ((bi - np) & 3u) == 0) {
+                        /* four taps a trip: one 16-byte read of samples, one of coefficients (a broadcast) for 16 multiply-adds -- with
+                         * a read of each per tap the loop spent its life waiting for LDS (63 % of the wave cycles, round 2's counters) */
+                        const int4 *xx4 = (const int4 *)xx, *cc4 = (const int4 *)cc;
+                        int4 xa = xx4[0];
+                        for (uint32_t k4 = 0; k4 < (np >> 2); k4++) {
+                            const int4 xb = xx4[k4 + 1], c4 = cc4[k4];
+                            const uint32_t v0 = (uint32_t)xa.x, v1 = (uint32_t)xa.y, v2 = (uint32_t)xa.z, v3 = (uint32_t)xa.w, v4 = (uint32_t)xb.x, v5 = (uint32_t)xb.y, v6 = (uint32_t)xb.z;
+                            const uint32_t c0 = (uint32_t)c4.x, c1 = (uint32_t)c4.y, c2 = (uint32_t)c4.z, c3 = (uint32_t)c4.w;
+                            p0 += c0 * v0 + c1 * v1 + c2 * v2 + c3 * v3;
+                            p1 += c0 * v1 + c1 * v2 + c2 * v3 + c3 * v4;
+                            p2 += c0 * v2 + c1 * v3 + c2 * v4 + c3 * v5;
+                            p3 += c0 * v3 + c1 * v4 + c2 * v5 + c3 * v6;
+                            xa = xb;
+                        }
+                    } else {
                     uint32_t w0 = (uint32_t)xx[0], w1 = (uint32_t)xx[1], w2 = (uint32_t)xx[2];
                     for (uint32_t k = 0; k < np; k++) {
                         const uint32_t ck = (uint32_t)cc[k], w3 = (uint32_t)xx[k + 3];
                         p0 += ck * w0; p1 += ck * w1; p2 += ck * w2; p3 += ck * w3;
                         w0 = w1; w1 = w2; w2 = w3;
                     }
-                    const int32_t *xv = xt + LNN_MAXP + e0;
-                    int4 o;
-                    o.x = (int32_t)((uint32_t)xv[0] + (uint32_t)((int32_t)p0 >> (rs & 31u)));
-                    o.y = (int32_t)((uint32_t)xv[1] + (uint32_t)((int32_t)p1 >> (rs & 31u)));
-                    o.z = (int32_t)((uint32_t)xv[2] + (uint32_t)((int32_t)p2 >> (rs & 31u)));
-                    o.w = (int32_t)((uint32_t)xv[3] + (uint32_t)((int32_t)p3 >> (rs & 31u)));
-                    *(int4 *)(out + sb) = o;                          /* sb is a multiple of 4, rows are 16-byte aligned */
-                } else {
-                    for (uint32_t j = 0; j < 4; j++) {
-                        const uint32_t e = e0 + j, s = s0 + e;
-                        if (s >= n) continue;
-                        int32_t v = xt[LNN_MAXP + e];
-                        const uint32_t unit = s / nsd;
-                        if (ns >= np && unit < units) {
+                    }
+                    const int32_t *xv = in + bi;
+                    o[0] = (int32_t)((uint32_t)xv[0] + (uint32_t)((int32_t)p0 >> (rs & 31u)));
+                    o[1] = (int32_t)((uint32_t)xv[1] + (uint32_t)((int32_t)p1 >> (rs & 31u)));
+                    o[2] = (int32_t)((uint32_t)xv[2] + (uint32_t)((int32_t)p2 >> (rs & 31u)));
+                    o[3] = (int32_t)((uint32_t)xv[3] + (uint32_t)((int32_t)p3 >> (rs & 31u)));
+                }
+            }
+            if (!quad) {
+                for (uint32_t j = 0; j < 4; j++) {
+                    const int64_t s64 = sb64 + j;
+                    int32_t v = 0;
+                    if (s64 >= 0 && s64 < (int64_t)n && e0 + j < count) {
+                        const uint32_t s = (uint32_t)s64, unit = s / nsd;
+                        v = in[bi + j];
+                        if (units && ns >= np && unit < units) {
                             const uint32_t loc = s - unit * ns;
                             if (loc >= np) {
                                 uint32_t pred = half;
                                 const int32_t *cc = s_coef[l] + unit * np;
-                                const int32_t *xx = xt + LNN_MAXP + e - np;
+                                const int32_t *xx = in + bi + j - np;
                                 for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
                                 v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
                             }
                         }
-                        out[s] = v;
                     }
+                    o[j] = v;
                 }
             }
+            if (last) {                                       /* olead = 0: e0 is the offset inside the tile */
+                const uint32_t sb = s0 + e0;
+                if (sb + 3 < S && (S & 3u) == 0) { int4 q; q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3]; *(int4 *)(out + sb) = q; }      /* (samples behind n are zero) */
+                else for (uint32_t j = 0; j < 4; j++) if (sb + j < S) out[sb + j] = o[j];
+            } else {
+                for (uint32_t j = 0; j < 4; j++) if (e0 + j < count) ob[bi + j] = o[j];
+            }
         }
-        if (l + 1 == p.L) for (uint32_t s = n + tid; s < S; s += FIN_THREADS) out[s] = 0;
+        lead = olead;
         __syncthreads();
-        if (l + 1 < p.L) { int32_t *t = src; src = dst; dst = t; }
     }
 }
 
