@@ -36,8 +36,8 @@
 #include "lnn_k_fwdloss.h"
 #include "lnn_k_af.h"
 #include "lnn_k_train.h"
-#include "lnn_k_finalize.h"
 #include "lnn_k_decode.h"
+#include "lnn_k_finalize.h"
 #include "lnn_k_rice.h"
 
 /* ================================================================================================
@@ -916,7 +916,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 hipLaunchKernelGGL(k_af_best, dim3(((uint32_t)CF + 255) / 256), dim3(256), 0, st, p, af_best, af_loss, af_reg);
                 if ((ret = run_train(p, af_best)) != LNN_OK) return ret;
             }
-            const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_quantize, dim3((uint32_t)CF), dim3(64), 0, st, p); hipLaunchKernelGGL(k_fir_cascade, dim3((uint32_t)CF, (S + FIN_TILE - 1) / FIN_TILE), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st);
+            const int sp_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_quantize, dim3((uint32_t)CF), dim3(64), 0, st, p); hipLaunchKernelGGL(k_fir_cascade, dim3((uint32_t)CF, CF >= 1024u ? 1u : (S + FIN_TILE - 1) / FIN_TILE), dim3(FIN_THREADS), 0, st, p); span_end(ctx, sp_, st);
         } else {
             /* -a N: the final pass is real -- the winner's regulariser, the refinement after every layer's search, and therefore
              * new inputs (and possibly new unit counts) for the layers behind it.  One job per channel-frame, general kernels. */
@@ -931,7 +931,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             if ((ret = run_layers(q, CF, false, none, false, false, af_iters, true)) != LNN_OK) return ret;
             span_end(ctx, sp_, st);
             if (ctx->learning && (ret = run_train(q, NULL)) != LNN_OK) return ret;
-            { const int sp2_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_quantize, dim3((uint32_t)CF), dim3(64), 0, st, q); hipLaunchKernelGGL(k_fir_cascade, dim3((uint32_t)CF, (S + FIN_TILE - 1) / FIN_TILE), dim3(FIN_THREADS), 0, st, q); span_end(ctx, sp2_, st); }
+            { const int sp2_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_quantize, dim3((uint32_t)CF), dim3(64), 0, st, q); hipLaunchKernelGGL(k_fir_cascade, dim3((uint32_t)CF, CF >= 1024u ? 1u : (S + FIN_TILE - 1) / FIN_TILE), dim3(FIN_THREADS), 0, st, q); span_end(ctx, sp2_, st); }
         }
         HIPCHK(ctx, hipGetLastError());
     }

@@ -1,4 +1,4 @@
-/* lnn_k_finalize.h -- k_finalize: best regulariser, quantiser, int32 FIR cascade.
+/* lnn_k_finalize.h -- k_quantize (best regulariser, quantiser, records) and k_fir_cascade (the int32 FIR cascade).
  * Part of the single translation unit lnn_device.hip (included there, in this order); not a stand-alone header. */
 #ifndef LNN_K_FINALIZE_H_INCLUDED
 #define LNN_K_FINALIZE_H_INCLUDED
@@ -67,58 +67,168 @@ __global__ __launch_bounds__(64) void k_quantize(Plan p)
  * same unit -- so a tile recomputes what it needs of the layers in front of it: the input with sum P taps of history goes into LDS
  * once, every layer works LDS to LDS (its output range shrinks by its own taps), and only the residual is written.  Traffic: the
  * channel in (plus 14 % of halo), the residual out -- the form that streamed every layer through xint / xtmp moved 250 KB per
- * channel-frame and kept a channel-frame in ONE block (two blocks busy on a 256-CU chip for a stereo block-at-a-time call). */
-__global__ __launch_bounds__(FIN_THREADS) void k_fir_cascade(Plan p)
+ * channel-frame and kept a channel-frame in ONE block (two blocks busy on a 256-CU chip for a stereo block-at-a-time call).
+ *
+ * Layers of >= 16 taps per unit run on the MATRIX unit.  The coefficients are 8-bit (the quantiser's range), the samples are cut
+ * into four signed base-256 digits (sp_digits), and sum_k c[k] x[s - np + k] for 64 consecutive outputs is one Toeplitz product
+ * v_mfma_i32_16x16x64_i8 per 64 window samples: A = the digit planes of four 16-output groups' windows (rows 4 q + b), B = the
+ * unit's coefficients as a Toeplitz band (the same for every group: it depends on relative positions only), C[4 q + b][i] = plane b
+ * of output i of group q -- which is exactly the lane (i, q)'s four accumulator registers.  The planes recombine by shifts modulo
+ * 2^32, what the reference's wrap-around int32 sum holds.  148 multiply-adds per sample on v_mul_lo_u32 (the cascade was bound by
+ * them: 4 ms per 31 008 channel-frames) become 0.3 instructions per output and layer.  Layers of fewer taps, chunks that straddle
+ * a unit boundary or the frame's ends, take the integer multiplier as before. */
+#define FIN_FRONT 192u                       /* buffer entries in front of the history: the matrix windows reach back 64 KS - 16 samples from a chunk */
+#define FIN_BUF (FIN_FRONT + ((FIN_HALO + 63u) & ~63u) + FIN_TILE)
+__global__ __launch_bounds__(FIN_THREADS, 4) void k_fir_cascade(Plan p)
 {
     __shared__ __attribute__((aligned(16))) int32_t s_coef[LNN_MAXL][LNN_MAXP];
-    __shared__ __attribute__((aligned(16))) int32_t bufs[2][FIN_HALO + 4 + FIN_TILE];
-    const uint32_t cf = blockIdx.x, tid = threadIdx.x, s0 = blockIdx.y * FIN_TILE;
+    __shared__ __attribute__((aligned(16))) int32_t bufs[2][FIN_BUF];
+    __shared__ __attribute__((aligned(16))) int8_t dig[2][4][FIN_BUF];          /* digit planes of a layer's input, when that layer takes the matrix path */
+    const uint32_t cf = blockIdx.x, tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const DevClass &c = p.cls[p.cls_of_frame[cf / p.C]];
     const uint32_t n = c.n, S = p.S, L = p.L;
     const size_t ocf = (size_t)p.frame_map[cf / p.C] * p.C + cf % p.C;
     const int32_t *rec = p.prm + ocf * LINNE_AMD_PARAM_WORDS;
     int32_t *out = p.resid + ocf * S;
-    if (s0 >= n) {                                            /* behind the frame's end: zeros (linne_encoder.c:613-621 padded the input) */
-        for (uint32_t i = tid; i < FIN_TILE; i += FIN_THREADS) if (s0 + i < S) out[s0 + i] = 0;
-        return;
-    }
     uint32_t H = 0;
-    for (uint32_t l = 0; l < L; l++) H += p.P[l];            /* taps of all layers: the history the tile needs (<= FIN_HALO) */
-    const uint32_t Hp = (H + 3u) & ~3u;                       /* rounded up: sample s0 sits at a 16-byte boundary of the buffers */
+    for (uint32_t l = 0; l < L; l++) H += p.P[l];            /* taps of all layers: the history a tile needs (<= FIN_HALO) */
+    /* the layers' unit counts and shifts go to LDS once (read from the record where they are needed they cost every layer a trip to memory) */
+    __shared__ uint32_t l_units[LNN_MAXL], l_rs[LNN_MAXL], l_matrix[LNN_MAXL + 1];
+    if (tid <= LNN_MAXL) {
+        const uint32_t l = tid;
+        uint32_t m = 0;
+        if (l < L) {
+            const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l];
+            l_units[l] = units; l_rs[l] = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
+            /* which layers take the matrix path (never layer 0: its input has no digit planes) */
+            if (l > 0 && units != 0 && p.P[l] <= 128u) { const uint32_t np = p.P[l] / units; m = (np >= 16u && n / units >= np) ? 1u : 0u; }
+        }
+        l_matrix[l] = m;
+    }
+    const uint32_t ORG = FIN_FRONT + ((H + 63u) & ~63u);      /* buffer index of a tile's first sample s0: a multiple of 64 */
     const int32_t *src = p.xint + (size_t)cf * S;
-    /* buffer index i <-> sample s0 - Hp + i */
-    {
-        constexpr int NPF = (FIN_HALO + 4 + FIN_TILE + FIN_THREADS - 1) / FIN_THREADS;
-        int32_t pf[NPF];
+    /* A block takes the tiles blockIdx.y, blockIdx.y + gridDim.y, ... of its channel-frame (batches: gridDim.y = 1, the block walks the
+     * channel-frame and pays its start-up -- class, map and parameter loads, each a dependent trip to memory -- once; block-at-a-time
+     * calls: a tile per block).  The next tile's samples are requested before this one is worked on. */
+    const uint32_t ntile = (S + FIN_TILE - 1u) / FIN_TILE;
+    constexpr int NPF = (FIN_HALO + FIN_TILE + FIN_THREADS - 1) / FIN_THREADS;
+    int32_t pf[NPF];
+    auto fetch = [&](uint32_t s0_) {                          /* buffer index i <-> sample s0 - ORG + i; loaded: [ORG - H, ORG + FIN_TILE) */
 #pragma unroll
         for (int m = 0; m < NPF; m++) {
             const uint32_t i = tid + (uint32_t)m * FIN_THREADS;
-            const int64_t g = (int64_t)s0 - Hp + i;
-            pf[m] = (i < Hp + FIN_TILE && g >= 0 && g < (int64_t)n) ? src[g] : 0;
+            const int64_t g = (int64_t)s0_ - H + i;
+            pf[m] = (i < H + FIN_TILE && g >= 0 && g < (int64_t)n) ? src[g] : 0;
         }
-        for (uint32_t i = tid; i < L * LNN_MAXP; i += FIN_THREADS) { const uint32_t l = i / LNN_MAXP, k = i % LNN_MAXP; if (k < p.P[l]) s_coef[l][k] = rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + k]; }
-#pragma unroll
-        for (int m = 0; m < NPF; m++) { const uint32_t i = tid + (uint32_t)m * FIN_THREADS; if (i < Hp + FIN_TILE) bufs[0][i] = pf[m]; }
+    };
+    if (blockIdx.y < ntile && blockIdx.y * FIN_TILE < n) fetch(blockIdx.y * FIN_TILE);
+    for (uint32_t i = tid; i < L * LNN_MAXP; i += FIN_THREADS) { const uint32_t l = i / LNN_MAXP, k = i % LNN_MAXP; if (k < p.P[l]) s_coef[l][k] = rec[LINNE_AMD_PRM_COEF + p.coef_off[l] + k]; }
+    for (uint32_t tile = blockIdx.y; tile < ntile; tile += gridDim.y) {
+    const uint32_t s0 = tile * FIN_TILE;
+    if (s0 >= n) {                                            /* behind the frame's end: zeros (linne_encoder.c:613-621 padded the input) */
+        for (uint32_t i = tid; i < FIN_TILE; i += FIN_THREADS) if (s0 + i < S) out[s0 + i] = 0;
+        continue;
     }
+    __syncthreads();                                          /* the tile before is through with the buffers */
+#pragma unroll
+    for (int m = 0; m < NPF; m++) { const uint32_t i = tid + (uint32_t)m * FIN_THREADS; if (i < H + FIN_TILE) bufs[0][ORG - H + i] = pf[m]; }
+    { const uint32_t tn = tile + gridDim.y; if (tn < ntile && tn * FIN_TILE < n) fetch(tn * FIN_TILE); }
     __syncthreads();
     uint32_t lead = H;                                        /* samples in front of s0 that the current input buffer holds valid */
+#pragma unroll 1
     for (uint32_t l = 0; l < L; l++) {
-        const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + l];
+        const uint32_t units = l_units[l], rs = l_rs[l];
         const uint32_t np = p.P[l] / (units ? units : 1u), ns = units ? n / units : 0u;
         const uint32_t half = 1u << ((rs - 1u) & 31u);
-        const bool last = (l + 1 == L);
+        const bool last = (l + 1 == L), digits_out = l_matrix[l + 1] != 0;
         const int32_t *in = bufs[l & 1u];
         int32_t *ob = bufs[(l & 1u) ^ 1u];
+        int8_t (*dgo)[FIN_BUF] = dig[(l & 1u) ^ 1u];
         const uint32_t olead = lead - p.P[l];                 /* this layer's outputs start olead samples in front of s0 */
         const uint32_t count = olead + FIN_TILE;
+        const uint32_t nsd = ns ? ns : 1u;
+        /* one output by the positional rule (the general form: any unit layout, the frame's ends) */
+        auto scalar_out = [&](uint32_t idx) -> int32_t {
+            const int64_t s64 = (int64_t)s0 - ORG + idx;
+            if (s64 < 0 || s64 >= (int64_t)n) return 0;
+            const uint32_t s = (uint32_t)s64, unit = s / nsd;
+            int32_t v = in[idx];
+            if (units && ns >= np && unit < units) {
+                const uint32_t loc = s - unit * ns;
+                if (loc >= np) {
+                    uint32_t pred = half;
+                    const int32_t *cc = s_coef[l] + unit * np;
+                    const int32_t *xx = in + idx - np;
+                    for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
+                    v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
+                }
+            }
+            return v;
+        };
+        auto put_digits = [&](uint32_t idx, int32_t v) {
+            const uint32_t dg = sp_digits(v);
+            dgo[0][idx] = (int8_t)dg; dgo[1][idx] = (int8_t)(dg >> 8); dgo[2][idx] = (int8_t)(dg >> 16); dgo[3][idx] = (int8_t)(dg >> 24);
+        };
+        if (l_matrix[l] != 0) {
+            /* chunks of 64 outputs at buffer indices that are multiples of 64; wave w takes the chunks w, w + 4, ... */
+            const uint32_t KS = (np + 15u + 63u) / 64u;                         /* 64-sample steps of a chunk's windows (1 .. 3) */
+            const int8_t (*dgi)[FIN_BUF] = dig[l & 1u];
+            const uint32_t first = (ORG - olead) & ~63u, nchunk = (ORG + FIN_TILE - first) / 64u;
+            const uint32_t i = lane & 15u, g4 = lane >> 4, qa = (lane & 15u) >> 2, ba = lane & 3u;
+            lnn_v4i bfrag[3];
+            uint32_t have_unit = 0xFFFFFFFFu;
+            for (uint32_t ck = wave; ck < nchunk; ck += FIN_THREADS / 64u) {
+                const uint32_t bc = first + 64u * ck;
+                const int64_t sa = (int64_t)s0 - ORG + bc, sz = sa + 63;         /* first and last sample of the chunk */
+                const uint32_t idx = bc + 16u * g4 + i;                           /* my output */
+                int32_t o;
+                bool mat = sa >= 0 && sz < (int64_t)n;
+                uint32_t unit = 0;
+                if (mat) { unit = (uint32_t)sa / nsd; mat = unit < units && (uint32_t)sz / nsd == unit; }
+                if (mat) {
+                    if (unit != have_unit) {                                      /* the unit's Toeplitz band: window element m of a group meets tap m + 16 - 64 KS - i + np of output i */
+                        const int32_t *cc = s_coef[l] + unit * np;
+#pragma unroll
+                        for (uint32_t st = 0; st < 3u; st++) {
+                            uint32_t w[4] = { 0u, 0u, 0u, 0u };
+                            if (st < KS) {
+#pragma unroll
+                                for (uint32_t e = 0; e < 16u; e++) {
+                                    const int32_t kx = (int32_t)(64u * st + 16u * g4 + e + 16u + np) - (int32_t)(64u * KS + i);
+                                    const int32_t cv = (kx >= 0 && (uint32_t)kx < np) ? cc[kx] : 0;
+                                    w[e >> 2] |= ((uint32_t)cv & 0xFFu) << (8u * (e & 3u));
+                                }
+                            }
+                            bfrag[st][0] = (int)w[0]; bfrag[st][1] = (int)w[1]; bfrag[st][2] = (int)w[2]; bfrag[st][3] = (int)w[3];
+                        }
+                        have_unit = unit;
+                    }
+                    lnn_v4i acc4 = { 0, 0, 0, 0 };
+                    const uint32_t w0 = bc + 16u * qa + 16u - 64u * KS + 16u * g4;   /* my 16 bytes of group qa's window, plane ba, step 0 */
+#pragma unroll
+                    for (uint32_t st = 0; st < 3u; st++) {
+                        if (st < KS) {
+                            const lnn_v4i a = *(const lnn_v4i *)&dgi[ba][w0 + 64u * st];
+                            acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, bfrag[st], acc4, 0, 0, 0);
+                        }
+                    }
+                    const uint32_t sum = (uint32_t)acc4[0] + ((uint32_t)acc4[1] << 8) + ((uint32_t)acc4[2] << 16) + ((uint32_t)acc4[3] << 24);
+                    const uint32_t s = (uint32_t)((int64_t)s0 - ORG + idx), loc = s - unit * ns;
+                    const int32_t v = in[idx];
+                    o = (loc >= np) ? (int32_t)((uint32_t)v + (uint32_t)((int32_t)(half + sum) >> (rs & 31u))) : v;
+                } else o = scalar_out(idx);
+                if (last) { const int64_t s64 = (int64_t)s0 - ORG + idx; if (s64 >= (int64_t)s0 && s64 < (int64_t)S) out[s64] = o; }
+                else { ob[idx] = o; if (digits_out) put_digits(idx, o); }
+            }
+        } else {
         /* a lane owns 4 consecutive samples: when they sit in one unit past its first np samples (the usual case) the taps slide a
          * 4-wide register window over the buffer, one coefficient and one new sample per tap for four multiply-adds (int32
          * wrap-around: any order); otherwise sample by sample */
         for (uint32_t e0 = 4u * tid; e0 < count; e0 += 4u * FIN_THREADS) {
             const int64_t sb64 = (int64_t)s0 - olead + e0;    /* first of my 4 samples (may lie before sample 0 in the first tile) */
-            const uint32_t bi = Hp - olead + e0;              /* its buffer index */
+            const uint32_t bi = ORG - olead + e0;             /* its buffer index */
             int32_t o[4];
-            const uint32_t nsd = ns ? ns : 1u;
             bool quad = false;
             if (sb64 >= 0 && sb64 + 3 < (int64_t)n && units && ns >= np) {
                 const uint32_t sb = (uint32_t)sb64, unit0 = sb / nsd, loc0 = sb - unit0 * nsd;
@@ -128,8 +238,7 @@ __global__ __launch_bounds__(FIN_THREADS) void k_fir_cascade(Plan p)
                     const int32_t *xx = in + bi - np;             /* -> x[sb - np] */
                     uint32_t p0 = half, p1 = half, p2 = half, p3 = half;
                     if ((np & 3u) == 0 && ((bi - np) & 3u) == 0) {
-                        /* four taps a trip: one 16-byte read of samples, one of coefficients (a broadcast) for 16 multiply-adds -- with
-                         * a read of each per tap the loop spent its life waiting for LDS (63 % of the wave cycles, round 2's counters) */
+                        /* four taps a trip: one 16-byte read of samples, one of coefficients (a broadcast) for 16 multiply-adds */
                         const int4 *xx4 = (const int4 *)xx, *cc4 = (const int4 *)cc;
                         int4 xa = xx4[0];
                         for (uint32_t k4 = 0; k4 < (np >> 2); k4++) {
@@ -143,12 +252,12 @@ __global__ __launch_bounds__(FIN_THREADS) void k_fir_cascade(Plan p)
                             xa = xb;
                         }
                     } else {
-                    uint32_t w0 = (uint32_t)xx[0], w1 = (uint32_t)xx[1], w2 = (uint32_t)xx[2];
-                    for (uint32_t k = 0; k < np; k++) {
-                        const uint32_t ck = (uint32_t)cc[k], w3 = (uint32_t)xx[k + 3];
-                        p0 += ck * w0; p1 += ck * w1; p2 += ck * w2; p3 += ck * w3;
-                        w0 = w1; w1 = w2; w2 = w3;
-                    }
+                        uint32_t w0 = (uint32_t)xx[0], w1 = (uint32_t)xx[1], w2 = (uint32_t)xx[2];
+                        for (uint32_t k = 0; k < np; k++) {
+                            const uint32_t ck = (uint32_t)cc[k], w3 = (uint32_t)xx[k + 3];
+                            p0 += ck * w0; p1 += ck * w1; p2 += ck * w2; p3 += ck * w3;
+                            w0 = w1; w1 = w2; w2 = w3;
+                        }
                     }
                     const int32_t *xv = in + bi;
                     o[0] = (int32_t)((uint32_t)xv[0] + (uint32_t)((int32_t)p0 >> (rs & 31u)));
@@ -157,37 +266,19 @@ __global__ __launch_bounds__(FIN_THREADS) void k_fir_cascade(Plan p)
                     o[3] = (int32_t)((uint32_t)xv[3] + (uint32_t)((int32_t)p3 >> (rs & 31u)));
                 }
             }
-            if (!quad) {
-                for (uint32_t j = 0; j < 4; j++) {
-                    const int64_t s64 = sb64 + j;
-                    int32_t v = 0;
-                    if (s64 >= 0 && s64 < (int64_t)n && e0 + j < count) {
-                        const uint32_t s = (uint32_t)s64, unit = s / nsd;
-                        v = in[bi + j];
-                        if (units && ns >= np && unit < units) {
-                            const uint32_t loc = s - unit * ns;
-                            if (loc >= np) {
-                                uint32_t pred = half;
-                                const int32_t *cc = s_coef[l] + unit * np;
-                                const int32_t *xx = in + bi + j - np;
-                                for (uint32_t k = 0; k < np; k++) pred += (uint32_t)cc[k] * (uint32_t)xx[k];
-                                v = (int32_t)((uint32_t)v + (uint32_t)((int32_t)pred >> (rs & 31u)));
-                            }
-                        }
-                    }
-                    o[j] = v;
-                }
-            }
+            if (!quad) { for (uint32_t j = 0; j < 4; j++) o[j] = (e0 + j < count) ? scalar_out(bi + j) : 0; }
             if (last) {                                       /* olead = 0: e0 is the offset inside the tile */
                 const uint32_t sb = s0 + e0;
                 if (sb + 3 < S && (S & 3u) == 0) { int4 q; q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3]; *(int4 *)(out + sb) = q; }      /* (samples behind n are zero) */
                 else for (uint32_t j = 0; j < 4; j++) if (sb + j < S) out[sb + j] = o[j];
             } else {
-                for (uint32_t j = 0; j < 4; j++) if (e0 + j < count) ob[bi + j] = o[j];
+                for (uint32_t j = 0; j < 4; j++) if (e0 + j < count) { ob[bi + j] = o[j]; if (digits_out) put_digits(bi + j, o[j]); }
             }
+        }
         }
         lead = olead;
         __syncthreads();
+    }
     }
 }
 
