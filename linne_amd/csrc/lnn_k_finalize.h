@@ -94,9 +94,11 @@ __global__ __launch_bounds__(FIN_THREADS, 4) void k_fir_cascade(Plan p)
     uint32_t H = 0;
     for (uint32_t l = 0; l < L; l++) H += p.P[l];            /* taps of all layers: the history a tile needs (<= FIN_HALO) */
     /* the layers' unit counts and shifts go to LDS once (read from the record where they are needed they cost every layer a trip to memory) */
-    __shared__ uint32_t l_units[LNN_MAXL], l_rs[LNN_MAXL], l_matrix[LNN_MAXL + 1];
+    __shared__ uint32_t l_units[LNN_MAXL], l_rs[LNN_MAXL], l_matrix[LNN_MAXL + 1], s_toep_unit[LNN_MAXL];
+    __shared__ lnn_v4i s_toep[LNN_MAXL][3][64];
     if (tid <= LNN_MAXL) {
         const uint32_t l = tid;
+        if (l < LNN_MAXL) s_toep_unit[l] = 0xFFFFFFFFu;
         uint32_t m = 0;
         if (l < L) {
             const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + l];
@@ -176,6 +178,36 @@ __global__ __launch_bounds__(FIN_THREADS, 4) void k_fir_cascade(Plan p)
             const int8_t (*dgi)[FIN_BUF] = dig[l & 1u];
             const uint32_t first = (ORG - olead) & ~63u, nchunk = (ORG + FIN_TILE - first) / 64u;
             const uint32_t i = lane & 15u, g4 = lane >> 4, qa = (lane & 15u) >> 2, ba = lane & 3u;
+            /* the Toeplitz band of a unit: window element m of a group meets tap m + 16 - 64 KS - i + np of output i */
+            auto build_band = [&](uint32_t unit, lnn_v4i *frag) {
+                const int32_t *cc = s_coef[l] + unit * np;
+#pragma unroll
+                for (uint32_t st = 0; st < 3u; st++) {
+                    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+                    if (st < KS) {
+#pragma unroll
+                        for (uint32_t e = 0; e < 16u; e++) {
+                            const int32_t kx = (int32_t)(64u * st + 16u * g4 + e + 16u + np) - (int32_t)(64u * KS + i);
+                            const int32_t cv = (kx >= 0 && (uint32_t)kx < np) ? cc[kx] : 0;
+                            w[e >> 2] |= ((uint32_t)cv & 0xFFu) << (8u * (e & 3u));
+                        }
+                    }
+                    frag[st][0] = (int)w[0]; frag[st][1] = (int)w[1]; frag[st][2] = (int)w[2]; frag[st][3] = (int)w[3];
+                }
+            };
+            /* The band of the unit the tile starts in lives in LDS, shared by the waves, and stays there from tile to tile (a block
+             * that walks its channel-frame builds it once per unit: building it costs as many instructions as five chunks of
+             * outputs).  A chunk in another unit -- a tile with a unit boundary in it -- builds its own in registers. */
+            const uint32_t u0 = ((s0 > olead) ? (s0 - olead) / nsd : 0u) < units ? ((s0 > olead) ? (s0 - olead) / nsd : 0u) : units - 1u;
+            {
+                const uint32_t held = s_toep_unit[l];
+                __syncthreads();
+                if (held != u0) {
+                    if (wave == 0) { lnn_v4i fr[3]; build_band(u0, fr); s_toep[l][0][lane] = fr[0]; s_toep[l][1][lane] = fr[1]; s_toep[l][2][lane] = fr[2]; }
+                    if (tid == 0) s_toep_unit[l] = u0;
+                }
+                __syncthreads();
+            }
             lnn_v4i bfrag[3];
             uint32_t have_unit = 0xFFFFFFFFu;
             for (uint32_t ck = wave; ck < nchunk; ck += FIN_THREADS / 64u) {
@@ -187,21 +219,9 @@ __global__ __launch_bounds__(FIN_THREADS, 4) void k_fir_cascade(Plan p)
                 uint32_t unit = 0;
                 if (mat) { unit = (uint32_t)sa / nsd; mat = unit < units && (uint32_t)sz / nsd == unit; }
                 if (mat) {
-                    if (unit != have_unit) {                                      /* the unit's Toeplitz band: window element m of a group meets tap m + 16 - 64 KS - i + np of output i */
-                        const int32_t *cc = s_coef[l] + unit * np;
-#pragma unroll
-                        for (uint32_t st = 0; st < 3u; st++) {
-                            uint32_t w[4] = { 0u, 0u, 0u, 0u };
-                            if (st < KS) {
-#pragma unroll
-                                for (uint32_t e = 0; e < 16u; e++) {
-                                    const int32_t kx = (int32_t)(64u * st + 16u * g4 + e + 16u + np) - (int32_t)(64u * KS + i);
-                                    const int32_t cv = (kx >= 0 && (uint32_t)kx < np) ? cc[kx] : 0;
-                                    w[e >> 2] |= ((uint32_t)cv & 0xFFu) << (8u * (e & 3u));
-                                }
-                            }
-                            bfrag[st][0] = (int)w[0]; bfrag[st][1] = (int)w[1]; bfrag[st][2] = (int)w[2]; bfrag[st][3] = (int)w[3];
-                        }
+                    if (unit != have_unit) {
+                        if (unit == u0) { bfrag[0] = s_toep[l][0][lane]; bfrag[1] = s_toep[l][1][lane]; bfrag[2] = s_toep[l][2][lane]; }
+                        else build_band(unit, bfrag);
                         have_unit = unit;
                     }
                     lnn_v4i acc4 = { 0, 0, 0, 0 };
