@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblinne_amd.so")
+LIB_PATH = os.environ.get("LINNE_AMD_LIB") or os.path.join(_HERE, "liblinne_amd.so")     # (LINNE_AMD_LIB: another build of the library, for A/B runs on one box)
 
 PARAM_WORDS = 160
 STAT_WORDS = 8
