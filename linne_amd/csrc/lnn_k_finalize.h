@@ -34,9 +34,14 @@ __global__ __launch_bounds__(64) void k_quantize(Plan p)
         if ((i >= LINNE_AMD_PRM_UNITS + p.L && i < LINNE_AMD_PRM_RSHIFT) || (i >= LINNE_AMD_PRM_RSHIFT + p.L && i < LINNE_AMD_PRM_COEF) || i >= used) rec[i] = 0;
     __syncthreads();
     const uint32_t job = cf * p.R + s_best;
+    /* the winner's coefficients go to LDS with all lanes' loads in flight together: the quantiser below is a serial recurrence, and
+     * read from global memory it paid a trip per coefficient (35 us for a block-at-a-time call) */
+    __shared__ double s_d[LNN_MAXL][LNN_MAXP];
+    for (uint32_t i = tid; i < p.L * LNN_MAXP; i += 64u) { const uint32_t l = i / LNN_MAXP, k = i % LNN_MAXP; if (k < p.P[l]) s_d[l][k] = p.lparams[((size_t)job * LNN_MAXL + l) * LNN_MAXP + k]; }
+    __syncthreads();
     if (tid < p.L) {    /* lpc.c:981-1040 over all units of the layer together */
         const uint32_t l = tid, P = p.P[l];
-        const double *d = p.lparams + ((size_t)job * LNN_MAXL + l) * LNN_MAXP;
+        const double *d = s_d[l];
         int32_t *cq = rec + LINNE_AMD_PRM_COEF + p.coef_off[l];
         double mx = 0.0;
         for (uint32_t k = 0; k < P; k++) if (mx < fabs(d[k])) mx = fabs(d[k]);
