@@ -294,7 +294,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     constexpr int NT = (P >= 16) ? 5 : (P >= 8) ? 4 : (P >= 4) ? 3 : 2;
     constexpr int HP = (P < 2) ? 2 : P;                           /* history kept in front of the tile (even, >= P) */
     __shared__ __attribute__((aligned(16))) double xs[HP + FIR_TILE];
-    __shared__ __attribute__((aligned(16))) double hs[NT][HP];
+    __shared__ __attribute__((aligned(16))) double hs_all[L0 ? LNN_MAXR : 1][NT][HP];    /* the coefficients of every job the block serves */
     __shared__ __attribute__((aligned(16))) double obuf[SPEC ? FIR_TILE : 2];      /* store transpose of the fused forward output */
     /* layer 0: the regulariser passes of a channel-frame read the same input, so one block stages the tile once and serves all
      * R jobs (grid.x = channel-frames); other layers: grid.x = jobs */
@@ -305,9 +305,23 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     const double *x = p.sig + ((size_t)job0 * 2 + cur) * p.S;
     const int32_t *xi = p.xint + (size_t)(job0 / p.R) * p.S;
     const uint32_t ntr = c.ntrials[layer];
+    /* all jobs' coefficients are requested with the tile (fetched job by job behind a barrier they cost the block a trip to memory per
+     * job: 76 % of the layer-0 kernel's wave cycles were waiting) */
+    static_assert((L0 ? LNN_MAXR : 1) * NT * P <= 2 * FIR_THREADS, "two coefficient loads per thread");
+    double hreg[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t i = tid + (uint32_t)q * FIR_THREADS;
+        hreg[q] = (i < nr * NT * P) ? p.tcoef[((size_t)(job0 + i / (NT * P)) * LNN_MAXT + (i % (NT * P)) / P) * LNN_MAXP + i % P] : 0.0;
+    }
     for (uint32_t i = tid; i < HP + FIR_TILE; i += FIR_THREADS) {
         const int64_t g = (int64_t)s0 - HP + i;
         xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const uint32_t i = tid + (uint32_t)q * FIR_THREADS;
+        if (i < nr * NT * P) hs_all[i / (NT * P)][(i % (NT * P)) / P][i % P] = hreg[q];
     }
     __syncthreads();
     const uint32_t s = s0 + FIR_SPL * tid;
@@ -320,9 +334,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     const uint32_t fine_unit = fast ? s / (na >> (NT - 1)) : 0u;   /* my samples' unit under the finest split (one division for all trials: the units nest) */
     for (uint32_t rr_ = 0; rr_ < nr; rr_++) {
     const uint32_t job = job0 + rr_;
-    if (rr_) __syncthreads();                                       /* the previous job's coefficients are no longer read */
-    for (uint32_t i = tid; i < NT * P; i += FIR_THREADS) hs[i / P][i % P] = p.tcoef[((size_t)job * LNN_MAXT + i / P) * LNN_MAXP + i % P];
-    __syncthreads();
+    const double (*hs)[HP] = hs_all[rr_];
     double ps[NT], fwd[FIR_SPL];
 #pragma unroll
     for (int j = 0; j < FIR_SPL; j++) fwd[j] = 0.0;
