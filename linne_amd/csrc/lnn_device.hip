@@ -597,7 +597,7 @@ extern "C" uint64_t LINNEAmd_ScratchBytesPerFrame(const struct LINNEAmdShape *sh
  * (MODE 2) / the forward pass skips the jobs that chose one unit (MODE 1) */
 template <int MODE> static void launch_fir(hipStream_t st, const Plan &p, uint32_t l, uint32_t cur, uint32_t J, uint32_t tiles, bool spec)
 {
-    const dim3 grid(J, tiles), blk(FIR_THREADS);
+    const dim3 grid(J, (MODE == 1 && spec && J >= 4096u) ? 1u : tiles), blk(FIR_THREADS);      /* forward pass in batches: a block per job walks the tiles (few jobs have any work) */
     if (l == 0) { if (spec) hipLaunchKernelGGL((k_fir2<MODE, true, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<MODE, true, false>), grid, blk, 0, st, p, l, cur); }
     else        { if (spec) hipLaunchKernelGGL((k_fir2<MODE, false, true>), grid, blk, 0, st, p, l, cur); else hipLaunchKernelGGL((k_fir2<MODE, false, false>), grid, blk, 0, st, p, l, cur); }
 }

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
         }
     }
     /* MODE 0 walks every tile of the job in order inside one block; MODE 1/2 take one tile per block */
-    for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.y * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : 0x40000000u) {
+    /* (MODE 1 in batches: grid.y = 1 and the block walks its job's tiles -- most jobs chose one unit and leave at once, and 620 k
+     * blocks that only look up their job and go cost 1.7 ms of dispatch) */
+    for (uint32_t s0 = (MODE == 0) ? 0u : blockIdx.y * FIR_TILE; s0 < na; s0 += (MODE == 0) ? FIR_TILE : (MODE == 1 ? gridDim.y * FIR_TILE : 0x40000000u)) {
     __syncthreads();
     if (!L0 && s0 >= LNN_MAXP && s0 + FIR_TILE + 8 <= na) {          /* interior tile: 16-byte loads (S, s0, MAXP are even) */
         for (uint32_t i = 2 * tid; i < LNN_MAXP + FIR_TILE + 8; i += 2 * FIR_THREADS)
