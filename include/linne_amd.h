@@ -164,7 +164,8 @@ struct LINNEAmdSlot;
 struct LINNEAmdSlot *LINNEAmd_SlotCreate(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         uint32_t max_frames, int for_encode);
 /* Encode slots with less PCIe traffic (what LINNEEncoder_EncodeWhole uses):
- *   LINNE_AMD_SLOT_PCM16  the input is staged as int16 (SlotPcm16; ignored above 16 bits per sample) and widened on the device;
+ *   LINNE_AMD_SLOT_PCM16  the input is staged NARROW (SlotPcm16; LINNEAmd_SlotPcmWidth bytes per sample: int16 up to 16 bits per sample,
+ *                         packed little-endian 3-byte samples up to 24, ignored above) and widened on the device;
  *   LINNE_AMD_SLOT_EMIT   the device also WRITES the residual's Rice code (linne_coder.c:281-302; LINNEAmd_RiceEmitDevice): after
  *                         SlotWait, SlotPacked holds the channels' codes back to back, SlotOffsets[cf] the byte offset of
  *                         channel-frame cf's code (0xFFFFFFFF: not emitted -- flagged plan or no room; the host then fetches that
@@ -194,6 +195,9 @@ uint64_t *LINNEAmd_SlotBitPos(struct LINNEAmdSlot *slot);
 uint64_t *LINNEAmd_SlotBitEnd(struct LINNEAmdSlot *slot);
 const uint64_t *LINNEAmd_SlotEndBits(struct LINNEAmdSlot *slot);
 int LINNEAmd_SlotPcm16Valid(const struct LINNEAmdSlot *slot);
+/* bytes per staged PCM sample of this slot: 4 (int32), 2 (int16) or 3 (packed little-endian: a LINNE_AMD_SLOT_PCM16 slot of 17 .. 24-bit
+ * audio; SlotPcm16 then points at bytes) */
+uint32_t LINNEAmd_SlotPcmWidth(const struct LINNEAmdSlot *slot);
 int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *slot, uint64_t stream_bytes, const uint32_t *num_samples, uint32_t num_frames);
 int LINNEAmd_SlotFetchPcm32(struct LINNEAmdSlot *slot, uint32_t num_frames);
 void      LINNEAmd_SlotDestroy(struct LINNEAmdSlot *slot);

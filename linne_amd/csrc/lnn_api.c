@@ -92,7 +92,7 @@ static int want_slots(struct lnn_gpus *g, const struct LINNEAmdShape *shape, uin
 {
     /* mode: 1 encode, 0 decode (residual in, PCM out), 2 decode in stream mode (the blocks' bytes in, int16 PCM out where it fits) */
     const int for_encode = (mode == 1);
-    uint32_t d, i, flags = (mode == 2) ? (LINNE_AMD_SLOT_STREAM | (shape->bits_per_sample <= 16 ? LINNE_AMD_SLOT_PCM16 : 0u)) : 0;
+    uint32_t d, i, flags = (mode == 2) ? (LINNE_AMD_SLOT_STREAM | (shape->bits_per_sample <= 24 ? LINNE_AMD_SLOT_PCM16 : 0u)) : 0;
     if (for_encode) {       /* 16-bit staging and Rice emission on the device (LINNE_AMD_EMIT=0: int32 both ways, the host codes the residual) */
         const char *e = getenv("LINNE_AMD_EMIT");
         if (!e || atoi(e) != 0) flags = LINNE_AMD_SLOT_PCM16 | LINNE_AMD_SLOT_EMIT;
@@ -302,7 +302,7 @@ LINNEApiResult LINNEEncoder_EncodeBlock(struct LINNEEncoder *encoder, const int3
 
 /* whole stream (linne_encoder.c:865-932): groups of frames rotate over LNN_SLOTS staging slots -- while the GPU analyses
  * one group, the host threads pack the previous one into the stream and fill the next */
-struct fill_job { const int32_t *const *input; int32_t *pcm; int16_t *pcm16; uint32_t *nsm; uint32_t C, S, num_samples, base; };
+struct fill_job { const int32_t *const *input; int32_t *pcm; int16_t *pcm16; uint32_t width; uint32_t *nsm; uint32_t C, S, num_samples, base; };
 static void fill_frames(void *arg, uint32_t first, uint32_t count)
 {
     const struct fill_job *j = arg;
@@ -313,7 +313,11 @@ static void fill_frames(void *arg, uint32_t first, uint32_t count)
         j->nsm[f] = n;
         for (ch = 0; ch < j->C; ch++) {
             const int32_t *src = j->input[ch] + start;
-            if (j->pcm16) {             /* <= 16 bits per sample: half the bytes over PCIe, widened again by k_prep */
+            if (j->pcm16 && j->width == 3) {    /* 17 .. 24 bits per sample: packed 3-byte samples (tools/linne_codec right-justifies them into int32, linne_codec.c:101-105) */
+                uint8_t *dst = (uint8_t *)j->pcm16 + 3u * (((size_t)f * j->C + ch) * j->S);
+                for (s = 0; s < n; s++) { const uint32_t v = (uint32_t)src[s]; dst[3u * s] = (uint8_t)v; dst[3u * s + 1u] = (uint8_t)(v >> 8); dst[3u * s + 2u] = (uint8_t)(v >> 16); }
+                if (n < j->S) memset(dst + 3u * n, 0, 3u * (j->S - n));
+            } else if (j->pcm16) {      /* <= 16 bits per sample: half the bytes over PCIe, widened again by k_prep */
                 int16_t *dst = j->pcm16 + ((size_t)f * j->C + ch) * j->S;
                 for (s = 0; s < n; s++) dst[s] = (int16_t)src[s];
                 if (n < j->S) memset(dst + n, 0, sizeof(int16_t) * (j->S - n));
@@ -382,7 +386,7 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
             struct LINNEAmdSlot *sl = gp->slot[submitted % ndev][(submitted / ndev) % nslots];
             struct fill_job fj;
             const uint32_t base = gbase[submitted], cnt = gbase[submitted + 1] - base;
-            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.pcm16 = LINNEAmd_SlotPcm16(sl); fj.nsm = nsm + (size_t)(submitted % window) * group;
+            fj.input = input; fj.pcm = LINNEAmd_SlotPcm(sl); fj.pcm16 = LINNEAmd_SlotPcm16(sl); fj.width = LINNEAmd_SlotPcmWidth(sl); fj.nsm = nsm + (size_t)(submitted % window) * group;
             fj.C = C; fj.S = S; fj.num_samples = num_samples; fj.base = base;
             t0 = now_s();
             lnn_parallel_for(cnt, threads, fill_frames, &fj);
@@ -567,7 +571,7 @@ struct dgroup {
 struct unpack_job {
     const struct LINNEDecoder *dec; const uint8_t *data; struct dgroup *g; int32_t *sdata, *sprm; int32_t **buffer;
     /* stream mode (the device decodes the Rice codes): the group's bytes go to the slot as they are, from seg_first on */
-    uint8_t *sstream; uint64_t *sbitpos, *sbitend; uint64_t seg_first, seg_bytes; const int16_t *s16;
+    uint8_t *sstream; uint64_t *sbitpos, *sbitend; uint64_t seg_first, seg_bytes; const int16_t *s16; uint32_t swidth;
 };
 static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
 {
@@ -609,7 +613,12 @@ static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
     for (f = first; f < first + count; f++) {
         if (g->types[f] != LNN_BLOCK_COMPRESS) continue;
         for (ch = 0; ch < C; ch++) {
-            if (j->s16) {               /* the PCM came back as int16: widen on the way into the caller's planes */
+            if (j->s16 && j->swidth == 3) {   /* the PCM came back as packed 3-byte samples: widen (sign-extend) on the way into the caller's planes */
+                const uint8_t *src = (const uint8_t *)j->s16 + 3u * (((size_t)g->cidx[f] * C + ch) * S);
+                int32_t *dst = j->buffer[ch] + g->prog[f];
+                uint32_t s_;
+                for (s_ = 0; s_ < g->ns[f]; s_++) dst[s_] = (int32_t)((uint32_t)src[3u * s_] | ((uint32_t)src[3u * s_ + 1u] << 8)) | ((int32_t)(int8_t)src[3u * s_ + 2u] << 16);
+            } else if (j->s16) {        /* the PCM came back as int16: widen on the way into the caller's planes */
                 const int16_t *src = j->s16 + ((size_t)g->cidx[f] * C + ch) * S;
                 int32_t *dst = j->buffer[ch] + g->prog[f];
                 uint32_t s_;
@@ -790,7 +799,7 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
                         if (eb[g->cidx[f]] == ~(uint64_t)0 || eb[g->cidx[f]] < pay || 11u + ((eb[g->cidx[f]] - pay + 7u) >> 3) != g->cons[f]) anomaly = 1;
                     }
                     if (!anomaly && LINNEAmd_SlotPcm16(sl)) {
-                        if (LINNEAmd_SlotPcm16Valid(sl) && !getenv("LINNE_AMD_DEBUG_NO_PCM16")) uj.s16 = LINNEAmd_SlotPcm16(sl);      /* (the knob: tests take the int32 way) */
+                        if (LINNEAmd_SlotPcm16Valid(sl) && !getenv("LINNE_AMD_DEBUG_NO_PCM16")) { uj.s16 = LINNEAmd_SlotPcm16(sl); uj.swidth = LINNEAmd_SlotPcmWidth(sl); }      /* (the knob: tests take the int32 way) */
                         else if (LINNEAmd_SlotFetchPcm32(sl, g->ncomp) != LNN_OK) anomaly = 1;
                         else uj.sdata = LINNEAmd_SlotData(sl);             /* (allocated by the fetch) */
                     }

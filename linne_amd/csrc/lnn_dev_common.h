@@ -49,7 +49,7 @@ struct Plan {
     double regs[LNN_MAXR];
     double scale;                       /* 2^-(bits-1), exact */
     const int32_t *pcm; int32_t *resid; int32_t *prm; double *stats;
-    uint32_t pcm16;                     /* pcm points at int16 samples (a staging slot of <= 16-bit audio): half the H2D bytes */
+    uint32_t pcm16;                     /* how the caller staged the PCM: 0 int32, 1 int16 (<= 16-bit audio: half the H2D bytes), 2 packed little-endian 3-byte samples (<= 24 bits: three quarters) */
     const uint32_t *cls_of_frame; const uint32_t *frame_map; const DevClass *cls; const double *sintab; const double *wtab;
     int32_t *xint, *xtmp;               /* [F*C][S]                    */
     double *sig;                        /* [J][2][S]                   */
@@ -96,7 +96,12 @@ __device__ __host__ __forceinline__ bool search_long_takes(const Plan &p, uint32
 }
 
 /* input sample i of the caller's PCM array */
-__device__ __forceinline__ int32_t pcm_at(const Plan &p, size_t i) { return p.pcm16 ? (int32_t)((const int16_t *)p.pcm)[i] : p.pcm[i]; }
+__device__ __forceinline__ int32_t pcm24_at(const void *base, size_t i)
+{
+    const uint8_t *b = (const uint8_t *)base + 3u * i;
+    return (int32_t)((uint32_t)b[0] | ((uint32_t)b[1] << 8)) | ((int32_t)(int8_t)b[2] << 16);
+}
+__device__ __forceinline__ int32_t pcm_at(const Plan &p, size_t i) { return p.pcm16 == 1u ? (int32_t)((const int16_t *)p.pcm)[i] : (p.pcm16 == 2u ? pcm24_at(p.pcm, i) : p.pcm[i]); }
 
 /* does k_fwd_loss (lnn_k_fwdloss.h) produce this job's last-layer loss?  (na: the job's analysis length) */
 __device__ __forceinline__ bool fwd_loss_takes(const Plan &p, uint32_t layer, uint32_t na) { return p.fused_last && layer + 1 == p.L && (na % (4u * p.P[layer])) == 0; }

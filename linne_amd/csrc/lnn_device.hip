@@ -78,7 +78,7 @@ struct LINNEAmdContext {
     uint32_t learning;                  /* -l: the SGD trainer after the analysis (LINNEAmd_SetLearning), 0 = off */
     uint32_t af_iters;                  /* -a N: auxiliary-function iterations of the final pass (LINNEAmd_SetAfIterations), 0 = off */
     double *af_h; uint32_t af_h_cap;    /* pinned: a Cholesky step's pivots on their way through the host's pow() */
-    int pcm16_next;                     /* the next EncodeFramesDevice call reads int16 samples (set by the staging slots, cleared by the call) */
+    int pcm16_next;                     /* the next EncodeFramesDevice call reads narrow samples: 1 int16, 2 packed 3-byte (set by the staging slots, cleared by the call) */
     int force_exact;                    /* LINNE_AMD_EXACT=1: every unit-count search runs the exact ordered chains (diff against the certified search) */
     int fir_spec;                       /* LINNE_AMD_SPECULATE (default 1): fuse the one-unit forward into the search of layers 0 .. L-2 */
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
@@ -619,7 +619,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
 {
     if (!ctx) return LNN_INVALID_ARGUMENT;
     ctx->err[0] = 0;
-    const uint32_t pcm16 = ctx->pcm16_next ? 1u : 0u;
+    const uint32_t pcm16 = (uint32_t)ctx->pcm16_next;        /* 0 int32, 1 int16, 2 packed 3-byte samples (set by the staging slots) */
     ctx->pcm16_next = 0;
     if (!shape || !d_pcm || !d_residual || !d_params || !d_stats) { snprintf(ctx->err, sizeof(ctx->err), "null argument"); return LNN_INVALID_ARGUMENT; }
     if (num_frames == 0) return LNN_OK;
@@ -674,7 +674,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         const int sp_ = span_begin(ctx, 13, ss);
         /* batches: lanes = channel-frames (k_stats_rows); a few channel-frames: a block each (k_stats finishes one block sooner).  LINNE_AMD_STATS_ROWS forces either */
         const bool rows_form = ctx->knob.stats_rows >= 0 ? (ctx->knob.stats_rows != 0) : ((uint64_t)num_frames * C >= 1024u);
-        if (rows_form && (S & 3u) == 0 && (hs.P[0] == 2u || hs.P[0] == 4u)) {
+        if (rows_form && pcm16 <= 1u && (S & 3u) == 0 && (hs.P[0] == 2u || hs.P[0] == 4u)) {
             const dim3 g((num_frames * C + 63u) / 64u);
             if (hs.P[0] == 4u) { if (pcm16) hipLaunchKernelGGL((k_stats_rows<5, true>), g, dim3(320), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<5, false>), g, dim3(320), 0, ss, ps); }
             else               { if (pcm16) hipLaunchKernelGGL((k_stats_rows<3, true>), g, dim3(192), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<3, false>), g, dim3(192), 0, ss, ps); }
@@ -1270,13 +1270,14 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
     LINNEAmdSlot *s = (LINNEAmdSlot *)calloc(1, sizeof(*s));
     if (!s) return NULL;
     if (!for_encode) flags &= (LINNE_AMD_SLOT_STREAM | LINNE_AMD_SLOT_PCM16); else flags &= ~(uint32_t)LINNE_AMD_SLOT_STREAM;
-    if (shape->bits_per_sample > 16) flags &= ~(uint32_t)LINNE_AMD_SLOT_PCM16;
+    if (shape->bits_per_sample > 24) flags &= ~(uint32_t)LINNE_AMD_SLOT_PCM16;          /* narrow staging: 2 bytes up to 16 bits, 3 packed bytes up to 24 */
     s->ctx = ctx; s->shape = *shape; s->max_frames = max_frames; s->for_encode = for_encode; s->flags = flags;
     const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * max_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * max_frames,
                    sb = sizeof(double) * LINNE_AMD_STAT_WORDS * (uint64_t)shape->num_channels * max_frames;
     hipError_t e = hipSuccess;
     const bool emit = (flags & LINNE_AMD_SLOT_EMIT) != 0, pcm16 = (flags & LINNE_AMD_SLOT_PCM16) != 0;
+    const uint64_t nbn = pcm16 ? nb / 4u * (shape->bits_per_sample <= 16 ? 2u : 3u) : nb;      /* bytes of the narrow PCM image */
     /* emit mode: the residual stays on the device; stream-mode decode with int16 PCM: the int32 PCM is only fetched when a block's
      * samples leave the 16-bit range (LINNEAmd_SlotFetchPcm32 allocates then) */
     const bool lazy_data = !for_encode && (flags & LINNE_AMD_SLOT_STREAM) && pcm16;
@@ -1285,9 +1286,9 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_data, nb);
     if (e == hipSuccess) e = hipMalloc((void **)&s->d_prm, pb);
     if (for_encode) {
-        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pcm, pcm16 ? nb / 2 : nb, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_pcm, nbn, hipHostMallocDefault);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_st, sb, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&s->d_pcm, pcm16 ? nb / 2 : nb);
+        if (e == hipSuccess) e = hipMalloc((void **)&s->d_pcm, nbn);
         if (emit) {
             /* room for the code of a group: what the samples' own width would take, a little more than any audio that is
              * not emitted RAW anyway needs; channels that do not fit fall back to the host (offset 0xFFFFFFFF) */
@@ -1317,8 +1318,8 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_flag, sizeof(uint32_t) * 4, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_flag, sizeof(uint32_t) * 4);
         if (flags & LINNE_AMD_SLOT_PCM16) {
-            if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out16, nb / 2, hipHostMallocDefault);
-            if (e == hipSuccess) e = hipMalloc((void **)&s->d_out16, nb / 2);
+            if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_out16, nbn, hipHostMallocDefault);
+            if (e == hipSuccess) e = hipMalloc((void **)&s->d_out16, nbn);
         }
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ev_in, hipEventDisableTiming);
@@ -1330,6 +1331,7 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
 
 extern "C" int32_t *LINNEAmd_SlotPcm(struct LINNEAmdSlot *s) { return (s && !(s->flags & LINNE_AMD_SLOT_PCM16)) ? s->h_pcm : NULL; }
 extern "C" int16_t *LINNEAmd_SlotPcm16(struct LINNEAmdSlot *s) { return (s && (s->flags & LINNE_AMD_SLOT_PCM16)) ? (s->for_encode ? (int16_t *)s->h_pcm : s->h_out16) : NULL; }
+extern "C" uint32_t LINNEAmd_SlotPcmWidth(const struct LINNEAmdSlot *s) { return !s ? 0u : (!(s->flags & LINNE_AMD_SLOT_PCM16) ? 4u : (s->shape.bits_per_sample <= 16 ? 2u : 3u)); }
 extern "C" uint8_t *LINNEAmd_SlotStream(struct LINNEAmdSlot *s) { return s ? s->h_stream : NULL; }
 extern "C" uint64_t LINNEAmd_SlotStreamCapacity(const struct LINNEAmdSlot *s) { return s ? s->stream_cap : 0; }
 extern "C" uint64_t *LINNEAmd_SlotBitPos(struct LINNEAmdSlot *s) { return s ? s->h_bitpos : NULL; }
@@ -1375,11 +1377,12 @@ extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t 
     const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames, sb = sizeof(double) * LINNE_AMD_STAT_WORDS * C * num_frames;
     const bool emit = (s->flags & LINNE_AMD_SLOT_EMIT) != 0, pcm16 = (s->flags & LINNE_AMD_SLOT_PCM16) != 0;
-    HIPCHK(ctx, hipMemcpyAsync(s->d_pcm, s->h_pcm, pcm16 ? nb / 2 : nb, hipMemcpyHostToDevice, ctx->copy_in));
+    const uint32_t width = LINNEAmd_SlotPcmWidth(s);
+    HIPCHK(ctx, hipMemcpyAsync(s->d_pcm, s->h_pcm, nb / 4u * width, hipMemcpyHostToDevice, ctx->copy_in));
     HIPCHK(ctx, hipEventRecord(s->ev_in, ctx->copy_in));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
     HIPCHK(ctx, hipMemsetAsync(s->d_st, 0, sb, ctx->stream));
-    ctx->pcm16_next = pcm16 ? 1 : 0;
+    ctx->pcm16_next = pcm16 ? (width == 2u ? 1 : 2) : 0;
     if ((ret = LINNEAmd_EncodeFramesDevice(ctx, &s->shape, s->d_pcm, num_samples, num_frames, s->d_data, s->d_prm, s->d_st)) != LNN_OK) return ret;
     /* The Rice planning and emission are light integer kernels behind the analysis: they run on the copy-out stream, where
      * they overlap the next group's (FP64-bound) analysis instead of delaying it; the slots of a context share that stream,
@@ -1471,15 +1474,19 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
     if ((ret = LINNEAmd_DecodeFramesDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_prm)) != LNN_OK) return ret;
     if (s->d_out16) {
         HIPCHK(ctx, hipMemsetAsync(s->d_flag, 0, sizeof(uint32_t), ctx->stream));
-        hipLaunchKernelGGL(k_narrow16, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, s->d_out16, CS * num_frames, s->d_flag,
-                (const uint32_t *)(s->d_bitpos + 2 * (size_t)s->max_frames), (uint32_t)C, s->shape.num_samples_per_block);
+        if (LINNEAmd_SlotPcmWidth(s) == 2u)
+            hipLaunchKernelGGL(k_narrow16, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, s->d_out16, CS * num_frames, s->d_flag,
+                    (const uint32_t *)(s->d_bitpos + 2 * (size_t)s->max_frames), (uint32_t)C, s->shape.num_samples_per_block);
+        else
+            hipLaunchKernelGGL(k_narrow24, dim3(1024), dim3(256), 0, ctx->stream, (const int32_t *)s->d_data, (uint8_t *)s->d_out16, CS * num_frames, s->d_flag,
+                    (const uint32_t *)(s->d_bitpos + 2 * (size_t)s->max_frames), (uint32_t)C, s->shape.num_samples_per_block);
     }
     HIPCHK(ctx, hipEventRecord(s->ev_k, ctx->stream));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_out, s->ev_k, 0));
     HIPCHK(ctx, hipMemcpyAsync(s->h_endbit, s->d_endbit, sizeof(uint64_t) * num_frames, hipMemcpyDeviceToHost, ctx->copy_out));
     if (s->d_out16) {
         HIPCHK(ctx, hipMemcpyAsync(s->h_flag, s->d_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->copy_out));
-        HIPCHK(ctx, hipMemcpyAsync(s->h_out16, s->d_out16, nb / 2, hipMemcpyDeviceToHost, ctx->copy_out));
+        HIPCHK(ctx, hipMemcpyAsync(s->h_out16, s->d_out16, nb / 4u * LINNEAmd_SlotPcmWidth(s), hipMemcpyDeviceToHost, ctx->copy_out));
     } else
         HIPCHK(ctx, hipMemcpyAsync(s->h_data, s->d_data, nb, hipMemcpyDeviceToHost, ctx->copy_out));
     HIPCHK(ctx, hipEventRecord(s->ev_done, ctx->copy_out));

@@ -597,6 +597,18 @@ __global__ void k_ms_to_lr(DecPlan p)
 /* the decoded PCM of <= 16-bit audio as int16 (half the D2H bytes); a sample outside the int16 range -- only a stream no encoder
  * wrote can decode to one -- raises *flag, and the host takes the int32 path.  Only a frame's own samples count (what lies behind a
  * short frame's end is nobody's data). */
+/* the same for audio of 17 .. 24 bits: packed little-endian 3-byte samples (three quarters of the D2H bytes) */
+__global__ void k_narrow24(const int32_t *src, uint8_t *dst, uint64_t count, uint32_t *flag, const uint32_t *nsmp, uint32_t C, uint32_t S)
+{
+    uint32_t bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const int32_t v = src[i];
+        const uint32_t s = (uint32_t)(i % S), f = (uint32_t)(i / ((uint64_t)C * S));
+        if ((v < -8388608 || v > 8388607) && s < nsmp[f]) bad = 1;
+        dst[3u * i] = (uint8_t)v; dst[3u * i + 1u] = (uint8_t)(v >> 8); dst[3u * i + 2u] = (uint8_t)(v >> 16);
+    }
+    if (bad) atomicOr(flag, 1u);
+}
 __global__ void k_narrow16(const int32_t *src, int16_t *dst, uint64_t count, uint32_t *flag, const uint32_t *nsmp, uint32_t C, uint32_t S)
 {
     uint32_t bad = 0;

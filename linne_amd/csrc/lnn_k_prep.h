@@ -139,7 +139,7 @@ __device__ void prep_general(const Plan &p, int64_t *sh, int32_t &sh_coef, doubl
 /* one round's tile of the fast form: samples t0 .. t0 + 2562 of the channel after copy / zero padding / LR -> MS (0 outside
  * [0, n)), coalesced, ALL of a thread's loads issued before the first is used (a load waited for on the spot costs the block a trip
  * to memory per element: 11 trips per round) */
-template <bool P16, bool MS>
+template <int FMT, bool MS>           /* FMT: 0 int32, 1 int16, 2 packed 3-byte samples */
 __device__ __forceinline__ void prep2_fill_t(const Plan &p, int32_t *tile, int64_t t0, uint32_t n, size_t inbase, uint32_t ch, uint32_t tid)
 {
     constexpr uint32_t NQ = (PREP_THREADS * 10u + 3u + PREP_THREADS - 1u) / PREP_THREADS;      /* 11 */
@@ -150,8 +150,8 @@ __device__ __forceinline__ void prep2_fill_t(const Plan &p, int32_t *tile, int64
     for (uint32_t q = 0; q < NQ; q++) {
         const int64_t s = t0 + (int64_t)(tid + PREP_THREADS * q);
         const size_t idx = (s >= 0 && s < (int64_t)n) ? (size_t)s : 0u;                       /* (n >= 1: index 0 is always readable) */
-        a[q] = P16 ? (int32_t)p16[b0 + idx] : p.pcm[b0 + idx];
-        b[q] = MS ? (P16 ? (int32_t)p16[b1 + idx] : p.pcm[b1 + idx]) : 0;
+        a[q] = FMT == 1 ? (int32_t)p16[b0 + idx] : (FMT == 2 ? pcm24_at(p.pcm, b0 + idx) : p.pcm[b0 + idx]);
+        b[q] = MS ? (FMT == 1 ? (int32_t)p16[b1 + idx] : (FMT == 2 ? pcm24_at(p.pcm, b1 + idx) : p.pcm[b1 + idx])) : 0;
     }
 #pragma unroll
     for (uint32_t q = 0; q < NQ; q++) {
@@ -165,8 +165,9 @@ __device__ __forceinline__ void prep2_fill_t(const Plan &p, int32_t *tile, int64
 }
 __device__ __forceinline__ void prep2_fill(const Plan &p, int32_t *tile, int64_t t0, uint32_t n, size_t inbase, uint32_t ch, bool ms, uint32_t tid)
 {
-    if (p.pcm16) { if (ms) prep2_fill_t<true, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<true, false>(p, tile, t0, n, inbase, ch, tid); }
-    else         { if (ms) prep2_fill_t<false, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<false, false>(p, tile, t0, n, inbase, ch, tid); }
+    if (p.pcm16 == 1u)      { if (ms) prep2_fill_t<1, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<1, false>(p, tile, t0, n, inbase, ch, tid); }
+    else if (p.pcm16 == 2u) { if (ms) prep2_fill_t<2, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<2, false>(p, tile, t0, n, inbase, ch, tid); }
+    else                    { if (ms) prep2_fill_t<0, true>(p, tile, t0, n, inbase, ch, tid); else prep2_fill_t<0, false>(p, tile, t0, n, inbase, ch, tid); }
 }
 
 /* k_prep: copy / zero padding, MS, the two pre-emphasis stages (linne_encoder.c:613-641, linne_utility.c:120-212), one block per
