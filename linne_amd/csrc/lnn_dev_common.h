@@ -42,6 +42,7 @@ struct Plan {
     uint32_t hist;                      /* the long layer's lags come from k_autocorr_hist / k_autocorr_sub where they take the frame (LINNE_AMD_HIST, default 1) */
     uint32_t rows16;                    /* order-16 layers take the register-ring autocorrelation form (LINNE_AMD_ROWS16, default 1) */
     uint32_t search_long;               /* the long layer's search comes from k_search_long where it takes the job (LINNE_AMD_SEARCH_LONG, default 1) */
+    uint32_t job_off;                   /* k_fir2: the launch covers the jobs job_off .. (its blockIdx.x is relative: the search of the frames k_search_long leaves) */
     uint32_t prep_general;              /* LINNE_AMD_PREP_GENERAL=1 (tests, A/B runs): k_prep streams the channel through global memory whatever its size */
     uint32_t fused_last;                /* the last layer's forward pass and loss come from k_fwd_loss where it takes the job (fwd_loss_takes) */
     RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */

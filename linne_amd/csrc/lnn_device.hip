@@ -847,6 +847,19 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 if (!(long_any && long_all)) {
                     const int sp_ = span_begin(ctx, (l == 0) ? 15 : (fir_spec ? 5 : 18), st);
                     if (hs.P[l] <= 16u && ctx->fir_small) launch_fir_small_search(st, q, l, cur, (uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0, hs.P[l]);
+                    else if (long_any) {
+                        /* the frames k_search_long leaves -- usually the one ragged tail -- are runs of consecutive rows (the chunk is sorted by
+                         * class): a launch per run, not 620 k blocks of which all but a handful look up their job and go (0.7 ms) */
+                        const uint32_t rpf = (uint32_t)(Jq / Fc);
+                        for (uint32_t f = f0; f < f0 + Fc; ) {
+                            if (search_long_takes(q, l, ctx->sig_cls[ctx->cur_idx[f]])) { f++; continue; }
+                            uint32_t g = f + 1;
+                            while (g < f0 + Fc && !search_long_takes(q, l, ctx->sig_cls[ctx->cur_idx[g]])) g++;
+                            Plan qq = q; qq.job_off = (f - f0) * rpf;
+                            launch_fir<2>(st, qq, l, cur, (g - f) * rpf, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0);
+                            f = g;
+                        }
+                    }
                     else launch_fir<2>(st, q, l, cur, (uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0);
                     span_end(ctx, sp_, st);
                 }

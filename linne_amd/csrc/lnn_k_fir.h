@@ -55,7 +55,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
     __shared__ __attribute__((aligned(16))) double hs[(MODE == 1) ? 1 : LNN_MAXT][LNN_MAXP + 8];   /* every trial's coefficients; +8: the pipelined loop reads one step ahead */
     __shared__ __attribute__((aligned(16))) double ob[(MODE == 2) ? 1 : FIR_THREADS / 64][(MODE == 2) ? 2 : 64 * FIR_SPL];   /* per-wave store transpose (MODE 0/1) */
     __shared__ double chain[LNN_MAXT];                              /* MODE 0: the ordered sums, carried across tiles */
-    const uint32_t job = blockIdx.x, tid = threadIdx.x;          /* grid = (jobs, tiles): the job count is not bound by 65535 */
+    const uint32_t job = blockIdx.x + p.job_off, tid = threadIdx.x;          /* grid = (jobs, tiles): the job count is not bound by 65535 */
     if (MODE == 0 && !p.uncertain[job]) return;                     /* exact search only where the certified one gave up */
     /* speculation (layers whose search usually picks one unit): the search pass already wrote the forward output of the
      * one-unit trial -- same coefficients, same products, its own accumulation chain -- so such a job has nothing to do here */
