@@ -741,11 +741,12 @@ template <int P> struct ApCfg {
     static constexpr int trial_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return t; }
     static constexpr int lag_of(int ch) { int t = 0; while (ch >= (P >> t) + 1) { ch -= (P >> t) + 1; t++; } return ch; }
 };
-template <int P, bool L0>
-__global__ __launch_bounds__(256) void k_autocorr_prod(Plan p, uint32_t layer, uint32_t cur)
+template <int P, bool L0, int NTH>       /* NTH threads: wave 0 adds, the others produce (512 for the 16-tap layer: its 36 chains x 128 samples of products per trip
+                                          * took three producer waves as long as the adder's 128 adds) */
+__global__ __launch_bounds__(NTH) void k_autocorr_prod(Plan p, uint32_t layer, uint32_t cur)
 {
     using Cfg = ApCfg<P>;
-    constexpr int NT = Cfg::NT, NCH = Cfg::NCH, CHUNK = Cfg::CHUNK, NPROD = 192;      /* producer threads: waves 1 .. 3 */
+    constexpr int NT = Cfg::NT, NCH = Cfg::NCH, CHUNK = Cfg::CHUNK, NPROD = NTH - 64;      /* producer threads: waves 1 .. */
     static_assert(NCH <= 64, "one wave adds up all chains");
     __shared__ double sv[2][NT][CHUNK + P];
     __shared__ uint32_t srem[2][NT][CHUNK + P];
@@ -980,9 +981,9 @@ static void dispatch_autocorr2(hipStream_t st, const Plan &p, uint32_t layer, ui
         const uint32_t rows = (layer == 0) ? p.J / p.R : p.J;
         const bool small = (layer == 0) ? (rows < 6144u) : (rows <= 512u);
         if (small) {
-#define LNN_AP(PP) do { if (layer == 0) hipLaunchKernelGGL((k_autocorr_prod<PP, true>), dim3(rows), dim3(256), 0, st, p, layer, cur); \
-                        else hipLaunchKernelGGL((k_autocorr_prod<PP, false>), dim3(rows), dim3(256), 0, st, p, layer, cur); } while (0)
-            switch (p.P[layer]) { case 2: LNN_AP(2); break; case 4: LNN_AP(4); break; case 8: LNN_AP(8); break; default: LNN_AP(16); break; }
+#define LNN_AP(PP, NTH_) do { if (layer == 0) hipLaunchKernelGGL((k_autocorr_prod<PP, true, NTH_>), dim3(rows), dim3(NTH_), 0, st, p, layer, cur); \
+                        else hipLaunchKernelGGL((k_autocorr_prod<PP, false, NTH_>), dim3(rows), dim3(NTH_), 0, st, p, layer, cur); } while (0)
+            switch (p.P[layer]) { case 2: LNN_AP(2, 256); break; case 4: LNN_AP(4, 256); break; case 8: LNN_AP(8, 512); break; default: LNN_AP(16, 512); break; }
 #undef LNN_AP
             return;
         }
