@@ -961,6 +961,22 @@ __global__ __launch_bounds__(64 * ((P + 64) / 64)) void k_autocorr_wide(Plan p, 
             const uint32_t cnt = (nt - loc0 < (uint32_t)AW_TILE) ? (nt - loc0) : (uint32_t)AW_TILE;
             const double *xa = xs, *xb = xs + tid;
             uint32_t j = 0;
+            /* 32 (16) samples a trip: every trip waits out one LDS round trip before its first add (the adds themselves are ~18 cycles
+             * apart: the FP64 unit's dependent latency), so the trip is made long */
+            for (; j + 32 <= cnt; j += 32) {
+                double m[32];
+#pragma unroll
+                for (int q = 0; q < 32; q += 2) { const lnn_d2 a = *(const lnn_d2 *)(xa + j + q); m[q] = a.x * xb[j + q]; m[q + 1] = a.y * xb[j + q + 1]; }
+#pragma unroll
+                for (int q = 0; q < 32; q++) acc += m[q];
+            }
+            for (; j + 16 <= cnt; j += 16) {
+                double m[16];
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) { const lnn_d2 a = *(const lnn_d2 *)(xa + j + q); m[q] = a.x * xb[j + q]; m[q + 1] = a.y * xb[j + q + 1]; }
+#pragma unroll
+                for (int q = 0; q < 16; q++) acc += m[q];
+            }
             for (; j + 8 <= cnt; j += 8) {
                 const lnn_d2 a0 = *(const lnn_d2 *)(xa + j), a1 = *(const lnn_d2 *)(xa + j + 2), a2 = *(const lnn_d2 *)(xa + j + 4), a3 = *(const lnn_d2 *)(xa + j + 6);
                 const double b0 = xb[j], b1 = xb[j + 1], b2 = xb[j + 2], b3 = xb[j + 3], b4 = xb[j + 4], b5 = xb[j + 5], b6 = xb[j + 6], b7 = xb[j + 7];

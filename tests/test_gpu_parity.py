@@ -319,6 +319,11 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     if seed % 2:
         monkeypatch.setenv("LINNE_AMD_HIST", "1")
         monkeypatch.setenv("LINNE_AMD_FWD_LOSS", "1")
+        monkeypatch.setenv("LINNE_AMD_STATS_ROWS", "1")          # the batch form of the block-type statistics (round 3)
+    if seed % 3 == 2:
+        monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "lanes")   # (the default for these short streams is the pipelined latency form)
+    if seed % 4 == 3:
+        monkeypatch.setenv("LINNE_AMD_PREP_GENERAL", "1")
     rng = np.random.default_rng(1000 + seed)
     nch = int(rng.integers(1, 9))
     bits = int(rng.choice([8, 16, 24]))
