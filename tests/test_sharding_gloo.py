@@ -31,7 +31,7 @@ def _stream():
     return x, frames, ns
 
 
-def _worker(rank, world, port, chunk, q):
+def _worker(rank, world, port, chunk, q, own_group=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -56,9 +56,12 @@ def _worker(rank, world, port, chunk, q):
             p, s, full = taps_to_arrays(tap, r, NCH, PRESET, BLOCK)
             res[i] = torch.from_numpy(full); prm[i] = torch.from_numpy(p); st[i] = torch.from_numpy(s)
 
+    # own_group: the transfers run on a group of their own (bench.py keeps its control traffic on the default group and hands the
+    # exchange the group RCCL serves)
+    group = dist.new_group(backend="gloo") if own_group else None
     ex = sharding.ChunkExchange(dist, F, chunk, [((NCH, BLOCK), torch.int32)],
                                 [((NCH, BLOCK), torch.int32), ((NCH, linne_amd.PARAM_WORDS), torch.int32), ((NCH, linne_amd.STAT_WORDS), torch.float64)],
-                                torch.device("cpu"), root=0)
+                                torch.device("cpu"), root=0, group=group)
     if rank == 0:
         pcm = torch.from_numpy(frames)
         out = [torch.zeros((F, NCH, BLOCK), dtype=torch.int32), torch.zeros((F, NCH, linne_amd.PARAM_WORDS), dtype=torch.int32),
@@ -82,11 +85,11 @@ def _worker(rank, world, port, chunk, q):
     dist.destroy_process_group()
 
 
-def _run(chunk):
+def _run(chunk, own_group=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000) + chunk
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunk, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, chunk, q, own_group)) for r in range(2)]
     for p in procs:
         p.start()
     got = [q.get(timeout=240) for _ in range(2)]
@@ -99,6 +102,10 @@ def _run(chunk):
 
 def test_two_rank_scatter_gather_reassembles_the_stream():
     _run(chunk=3)           # 13 frames: chunks 3 3 3 3 1 -> three rounds, the last one with the root only
+
+
+def test_two_rank_scatter_gather_on_a_group_of_its_own():
+    _run(chunk=4, own_group=True)
 
 
 def test_two_rank_scatter_gather_with_one_chunk_per_rank():
