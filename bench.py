@@ -612,7 +612,7 @@ def worker(args):
     dev = torch.device("cuda", local)
     backend = os.environ.get("BENCH_BACKEND", "nccl")       # the transfers' backend: "nccl" is RCCL on ROCm; "gloo" only for one-GPU rehearsals
     guard = Guard(rank)
-    dist, xgroup, xgroup_err = None, None, None
+    dist, xgroup = None, None
     if world > 1:
         import datetime
         import torch.distributed as dist
@@ -620,13 +620,9 @@ def worker(args):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")       # one node: the container's hostname may not resolve
         # control plane (barriers, MAX of the times, agreement flags): gloo over 127.0.0.1 -- nothing the headline needs rides on RCCL
         dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=240))
-        if backend == "nccl":
-            try:            # the communicator itself comes up lazily, inside the exchange leg's deadline
-                xgroup = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
-            except Exception as exc:
-                xgroup_err = repr(exc)
-        else:
+        if backend != "nccl":
             xgroup = dist.group.WORLD
+        # (backend "nccl": the RCCL group is created INSIDE the exchange leg, under its deadline -- new_group is a collective too)
     scaling = "weak"
     if args.tracks_total:
         assert args.tracks_total % world == 0, "--tracks-total must be a multiple of the GPU count"
@@ -862,11 +858,11 @@ def worker(args):
             # the exchange comes LAST: should RCCL hang, everything else is already in the line.  Every rank agrees on the outcome
             # over the gloo group before anyone believes the record; after a failure nothing touches the RCCL group again.
             name = "rccl_scatter_gather" if backend == "nccl" else f"{backend}_scatter_gather_rehearsal"
-            if xgroup is None:
-                rec = {"error": f"no {backend} group: {xgroup_err}"}
-            else:
-                rec = guard.run("transports." + name, 1.5 * L, lambda: leg_exchange(dist, xgroup, ctx, shape, frames, nsm, res, prm, tsteps, chunk, barrier, world, rank, red_max),
-                                on_timeout=put(name))
+            def exchange():
+                import datetime
+                g = xgroup if xgroup is not None else dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=120))
+                return leg_exchange(dist, g, ctx, shape, frames, nsm, res, prm, tsteps, chunk, barrier, world, rank, red_max)
+            rec = guard.run("transports." + name, 1.5 * L, exchange, on_timeout=put(name))
             agreed = guard.run("transports." + name + ".agreement", L, lambda: {"ok": all_ok("error" not in rec)}, on_timeout=put(name))
             if not agreed.get("ok") and "error" not in rec:
                 rec = {"error": "another rank failed or timed out in this leg", "this_rank": rec}
