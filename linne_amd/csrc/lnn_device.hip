@@ -37,6 +37,7 @@
 #include "lnn_k_af.h"
 #include "lnn_k_train.h"
 #include "lnn_k_decode.h"
+#include "lnn_k_decode_rows.h"
 #include "lnn_k_finalize.h"
 #include "lnn_k_rice.h"
 
@@ -84,7 +85,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -275,7 +276,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
-    { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : 2)); }
+    { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : (strcmp(e, "rows") == 0 ? 4 : 2))); }
     ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
 }
 /* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
@@ -986,13 +987,28 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
          * above all -- take the pipelined latency form (k_synth_pipe: a wave per stage of the cascade, 16-sample blocks) when the
          * frame fits its LDS image; k_synthesize is its fallback for longer frames */
         const bool pipe_fits = SP_LDS_BYTES(p.S) <= LEV_LDS_BUDGET;
-        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < 6144u ? 3 : 2);
+        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < 6144u ? 3 : 0);
         const bool use_pipe = (form == 3) && pipe_fits, use_wave = (form == 1) || (form == 3 && !pipe_fits);
-        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe */
+        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows */
         if (use_pipe) { const int sp_ = span_begin(ctx, 32, ctx->stream); hipLaunchKernelGGL(k_synth_pipe, dim3(CF), dim3(64 * (hs.L + 1)), SP_LDS_BYTES(p.S), ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
         else if (use_wave) { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u); span_end(ctx, sp_, ctx->stream); }
         else for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
             const bool de = (l == 0);
+            /* k_synth_rows (four channel-frames per wave, the old taps on the matrix unit) takes the layers without de-emphasis whose
+             * order is a preset's, when the samples can travel as 16-byte groups; by default the long ones (LINNE_AMD_DECODE_KERNEL=rows: all) */
+            const int nch = hs.P[l] <= 16u ? 0 : (hs.P[l] == 32u ? 1 : (hs.P[l] == 64u ? 3 : (hs.P[l] == 128u ? 7 : -1)));
+            if (!de && nch >= 0 && form != 2 && (form == 4 || nch > 0) && (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u) {
+                const int sp_ = span_begin(ctx, 33, ctx->stream);
+                const dim3 grows((CF + 3) / 4);
+                switch (nch) {
+                case 0: hipLaunchKernelGGL((k_synth_rows<0>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+                case 1: hipLaunchKernelGGL((k_synth_rows<1>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+                case 3: hipLaunchKernelGGL((k_synth_rows<3>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+                default: hipLaunchKernelGGL((k_synth_rows<7>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+                }
+                span_end(ctx, sp_, ctx->stream);
+                continue;
+            }
             const int sp_ = span_begin(ctx, hs.P[l] <= 16u ? 31 : (hs.P[l] <= 128u && (hs.P[l] & (hs.P[l] - 1u)) == 0 ? 30 : 11), ctx->stream);
             switch (hs.P[l]) {
             case 2:  if (de) hipLaunchKernelGGL((k_synth_small<2, true>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_small<2, false>), dim3(gsmall), dim3(64), 0, ctx->stream, p, (uint32_t)l); break;

@@ -1,0 +1,245 @@
+/* lnn_k_decode_rows.h -- k_synth_rows: the THROUGHPUT form of a synthesis layer (linne_lpc_synthesize.c:8-83), four channel-frames
+ * per wave, one per 16-lane DPP row.
+ * Part of the single translation unit lnn_device.hip (included there behind lnn_k_decode.h); not a stand-alone header.
+ *
+ * The lanes = channel-frames kernels (k_synth_small / k_synth_big) are few, long waves: a pass costs one wave's 10 240-step
+ * recurrence whatever the batch, and the long layer's 128 taps per step are FP64 multiply-adds on the vector unit.  Here the
+ * recurrence is split by the distance d of a tap as in k_synth_pipe (y[t] = r[t] - ((half + sum_d c_d y[t - d]) >> rshift), blocks
+ * of 16 outputs, lane i of a row = output i of the block):
+ *   d <= i            the block's own outputs: lane i holds output i's sum; when y_j is final every later lane of the ROW adds its
+ *                     tap times y_j -- the broadcast is a DPP row_newbcast, so the four rows run their own recurrences in the same
+ *                     instructions (shift, subtract, broadcast, two 24-bit multiply-adds per step and four channel-frames);
+ *   i < d <= i + 16   the previous block's outputs: added in the same steps into the NEXT block's sums (second coefficient set);
+ *   d > i + 16        older samples (layers of more than 16 taps): v_mfma_i32_16x16x64_i8 with K = 4 channel-frames x 16 samples --
+ *                     A = the outputs' signed base-256 digit planes (row 4 q + b = plane b of channel-frame q, non-zero only in
+ *                     that channel-frame's K group), B = each channel-frame's Toeplitz slice of its 8-bit coefficients (held by
+ *                     its own 16 lanes), one MFMA per 16 samples of history, issued a block ahead; C comes out with the four
+ *                     planes of output i of channel-frame q in lane (q, i): recombined by shifts, modulo 2^32 like the reference.
+ * Blocks are aligned to the frame (sample 16 m + i), not to the unit: a lane is `pred` (its sample is predicted from its unit's
+ * coefficients) or not (the unit's first np samples, what lies behind the last unit, a layer linne_decoder.c skips), and a row's
+ * coefficient registers are built for ONE state -- all 16 lanes predicting in unit u, or none (zeros: the steady code then copies).
+ * A block in which a row's lanes disagree (a unit's boundary inside it, orders below 16) takes the generic routine for that row:
+ * tap by tap over the row's lanes from the previous outputs (registers for d <= 16, the digit ring beyond), a DPP row sum per
+ * sample.  Frames of any length and unit count take this kernel; the steady code is what a frame spends its time in.
+ * The samples travel in 64-sample chunks: one 16-byte load and store per lane and chunk, staged through LDS. */
+#ifndef LNN_K_DECODE_ROWS_H_INCLUDED
+#define LNN_K_DECODE_ROWS_H_INCLUDED
+
+template <int J> __device__ __forceinline__ int32_t row_bcast(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }   /* row_newbcast:J */
+__device__ __forceinline__ uint32_t row_sum_all(uint32_t v)      /* wrap-around sum over the 16 lanes of a row, in every lane of it */
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   /* row_ror:8 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xf, 0xf, false);   /* row_ror:4 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xf, 0xf, false);   /* row_ror:2 */
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xf, 0xf, false);   /* row_ror:1 */
+    return v;
+}
+
+#define SR_STEPS(MUL_) \
+    SR_STEP(0, MUL_) SR_STEP(1, MUL_) SR_STEP(2, MUL_) SR_STEP(3, MUL_) SR_STEP(4, MUL_) SR_STEP(5, MUL_) SR_STEP(6, MUL_) SR_STEP(7, MUL_) \
+    SR_STEP(8, MUL_) SR_STEP(9, MUL_) SR_STEP(10, MUL_) SR_STEP(11, MUL_) SR_STEP(12, MUL_) SR_STEP(13, MUL_) SR_STEP(14, MUL_) SR_STEP(15, MUL_)
+
+#define SR_PAD 160u      /* zeros in front of the staged coefficients: distances up to 128 + 16 + 15 beyond np */
+#define SR_CST 320u      /* SR_PAD + 128 coefficients + 16 zeros (distances <= 0), rounded */
+template <int NCH>      /* 16-sample chunks of older history on the matrix unit: 0 for layers of <= 16 taps, 1 for 32, 3 for 64, 7 for 128 */
+__global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p, uint32_t layer)
+{
+    __shared__ __attribute__((aligned(16))) int8_t ring[4][4][256];          /* [channel-frame][digit plane][sample mod 256] */
+    __shared__ __attribute__((aligned(16))) int8_t zeros[256];               /* what the A operand's other K groups read */
+    __shared__ __attribute__((aligned(16))) int32_t stg_in[2][4][64], stg_out[4][64];
+    __shared__ __attribute__((aligned(16))) int8_t cst[4][SR_CST];           /* a row's coefficients while its registers are built */
+    const uint32_t lane = threadIdx.x, i = lane & 15u, q = lane >> 4, S = p.S;
+    const uint32_t nrows = p.F * p.C;
+    uint32_t cf = 4u * blockIdx.x + q;
+    const bool have = cf < nrows;
+    if (!have) cf = nrows - 1u;
+    const uint32_t n = have ? p.nsmp[cf / p.C] : 0u;
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    int32_t *g = p.data + (size_t)cf * S;
+    const uint32_t P = p.P[layer];
+    const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + layer], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + layer];
+    const uint32_t np = units ? P / units : 0u, ns = units ? n / units : 0u;
+    const bool skip = (units == 0 || np == 0 || ns < np);                    /* linne_decoder.c: such a layer leaves the data unchanged */
+    const uint32_t half = 1u << ((rs - 1u) & 31u), sh_ = rs & 31u;
+    const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    const uint32_t nchunk = (nmax + 63u) / 64u;
+    for (uint32_t k = lane; k < 256u; k += 64u) { zeros[k] = 0; }
+    for (uint32_t k = lane; k < 4u * SR_CST / 4u; k += 64u) ((uint32_t *)&cst[0][0])[k] = 0u;
+    if (NCH) for (uint32_t k = lane; k < 4096u / 4u; k += 64u) ((uint32_t *)&ring[0][0][0])[k] = 0u;
+    /* the A operand of lane l: row l & 15 = plane b of channel-frame qa, K group l >> 4: its own channel-frame's, or zeros */
+    const int8_t *abase = (((lane & 15u) >> 2) == q) ? &ring[(lane & 15u) >> 2][lane & 3u][0] : &zeros[0];
+
+    /* place of my sample in its unit; the state my row's coefficient registers are built for */
+    uint32_t unit = 0, tl = i;
+    auto settle = [&]() { while (!skip && unit < units && tl >= ns) { tl -= ns; unit++; } };
+    settle();
+    bool arr_pred = false; uint32_t arr_unit = 0u, half_l = 0u;
+    int32_t ccA[16], ccB[16];
+    lnn_v4i tz[NCH ? NCH : 1];
+#pragma unroll
+    for (int j = 0; j < 16; j++) { ccA[j] = 0; ccB[j] = 0; }
+#pragma unroll
+    for (int c = 0; c < (NCH ? NCH : 1); c++) tz[c] = lnn_v4i{ 0, 0, 0, 0 };
+    int32_t yprev = 0;
+    uint32_t nxt = 0, mcur = 0;
+
+    auto window = [&](uint32_t m) -> uint32_t {                 /* matrix-unit part of block m's sums: the 16 NCH samples that end 16 before it */
+        if (!NCH) return 0u;
+        lnn_v4i acc4 = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int c = 0; c < NCH; c++) {
+            const lnn_v4i a = *(const lnn_v4i *)(abase + ((16u * m - 32u - 16u * (uint32_t)c) & 255u));
+            acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, tz[c], acc4, 0, 0, 0);
+        }
+        return (uint32_t)acc4[0] + ((uint32_t)acc4[1] << 8) + ((uint32_t)acc4[2] << 16) + ((uint32_t)acc4[3] << 24);
+    };
+
+    /* 64-sample chunks: chunk c + 1 is requested while chunk c is worked on */
+    auto fetch = [&](uint32_t c) -> lnn_v4i {
+        lnn_v4i v = { 0, 0, 0, 0 };
+        const uint32_t s0 = 64u * c + 4u * i;
+        if (s0 + 3u < S) v = *(const lnn_v4i *)(g + s0);
+        else { if (s0 < S) v[0] = g[s0]; if (s0 + 1u < S) v[1] = g[s0 + 1u]; if (s0 + 2u < S) v[2] = g[s0 + 2u]; }
+        return v;
+    };
+    lnn_v4i pre = { 0, 0, 0, 0 };
+    if (nchunk) { const lnn_v4i first = fetch(0); *(lnn_v4i *)&stg_in[0][q][4u * i] = first; }
+    if (nchunk > 1u) pre = fetch(1);
+
+#pragma unroll 1
+    for (uint32_t c = 0; c < nchunk; c++) {
+        if (c + 1u < nchunk) { *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][4u * i] = pre; if (c + 2u < nchunk) pre = fetch(c + 2u); }
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t m = 4u * c + k;
+            if (16u * m >= nmax) break;
+            const int32_t res = stg_in[c & 1u][q][16u * k + i];
+            const bool pred = !skip && unit < units && tl >= np;
+            /* my row's class in this block: all lanes predicting in one unit, none predicting, or mixed (generic) */
+            const bool ok = (pred == arr_pred) && (!pred || unit == arr_unit);
+            bool gen = false;
+            if (!__all(ok)) {
+                const uint64_t bp = __ballot(pred);
+                const uint32_t rb = (uint32_t)(bp >> (16u * q)) & 0xFFFFu;
+                const uint32_t u0 = (uint32_t)row_bcast<0>((int32_t)unit);
+                const uint64_t bu = __ballot(pred && unit != u0);
+                const bool same_unit = ((uint32_t)(bu >> (16u * q)) & 0xFFFFu) == 0u;
+                const bool all_pred = (rb == 0xFFFFu) && same_unit, all_pass = (rb == 0u);
+                gen = !(all_pred || all_pass);
+                {   /* the coefficient registers of every row for the state it is in now (rows that keep theirs get the same values again: the
+                     * branch is the wave's, not the lane's, so the registers are written in place); a mixed row: zeros, no state */
+                    const bool bpred = pred && !gen;
+                    /* the unit's coefficients (8 bits by format), staged as bytes between two runs of zeros: tap of distance d =
+                     * cu[np - d] (linne_lpc_synthesize.c:30) sits at SR_PAD + np - d, and every distance outside 1 .. np reads a zero */
+                    if (bpred) {
+                        const int32_t *cu = crec + (size_t)unit * np;
+                        int32_t cv[8];
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) { const uint32_t k = i + 16u * (uint32_t)kk; cv[kk] = (k < np) ? cu[k] : 0; }
+#pragma unroll
+                        for (int kk = 0; kk < 8; kk++) { const uint32_t k = i + 16u * (uint32_t)kk; if (k < np) cst[q][SR_PAD + k] = (int8_t)cv[kk]; }
+                    }
+                    const int8_t *cb = &cst[q][0] + (bpred ? SR_PAD + np - i : SR_PAD - 17u);      /* (no state: zeros whatever the distance) */
+#pragma unroll
+                    for (int j = 0; j < 16; j++) { ccA[j] = cb[j]; ccB[j] = cb[j - 16]; }         /* distances i - j and 16 + i - j */
+                    __builtin_amdgcn_sched_barrier(0);          /* (a group of reads at a time: the registers are the steady code's) */
+#pragma unroll
+                    for (int cc = 0; cc < NCH; cc++) {
+                        uint32_t w[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                        for (int e = 0; e < 16; e++)            /* element e of chunk cc lies d = 32 + 16 cc + i - e samples before output i */
+                            w[e >> 2] |= ((uint32_t)cb[e - 32 - 16 * cc] & 0xFFu) << (8 * (e & 3));
+                        tz[cc] = lnn_v4i{ (int)w[0], (int)w[1], (int)w[2], (int)w[3] };
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    arr_pred = bpred; arr_unit = unit; half_l = bpred ? half : 0u;
+                }
+                if (gen) { arr_pred = true; arr_unit = 0xFFFFFFFFu; }          /* no state: the next steady block builds */
+                /* what the previous block adds to this one's sums, and the matrix-unit part, with the registers as they are now
+                 * (rows that kept their state get the values they had: the sums are associative) */
+                nxt = 0;
+#define SR_STEP(J, MUL_) { const int32_t sv = row_bcast<J>(yprev); nxt += sp_mul8(ccB[J], sv & 0xFFFF, sv >> 16); }
+                SR_STEPS(0)
+#undef SR_STEP
+                mcur = window(m);
+            }
+            const uint32_t mnext = window(m + 1u);              /* issued now, needed a block later */
+            const uint32_t acc0 = half_l + mcur + nxt;
+            uint32_t acc = acc0;
+            nxt = 0;
+            /* speculation as in k_synth_pipe: every output of the block fits 24 bits -- one full-rate multiply-add per sum */
+#define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
+                acc += (uint32_t)__mul24(ccA[J], sv); nxt += (uint32_t)__mul24(ccB[J], sv); }
+            SR_STEPS(0)
+#undef SR_STEP
+            int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+            const bool fits = gen || (((int32_t)((uint32_t)yout << 8) >> 8) == yout);
+            if (!__all(fits)) {
+                acc = acc0; nxt = 0;
+#define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
+                const int32_t sl = sv & 0xFFFF, shh = sv >> 16; acc += sp_mul8(ccA[J], sl, shh); nxt += sp_mul8(ccB[J], sl, shh); }
+                SR_STEPS(0)
+#undef SR_STEP
+                yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+            }
+            if (__any(gen)) {
+                /* the generic routine, sample by sample: the row's lanes share the taps (lane k: distances k + 1, k + 17, ...) */
+                int32_t ycur = 0;
+                const uint32_t rowbase = 16u * q;
+#pragma unroll 1
+                for (uint32_t j = 0; j < 16u; j++) {
+                    const uint32_t src = (rowbase + j) * 4u;
+                    const int32_t resj = __builtin_amdgcn_ds_bpermute((int)src, res);
+                    const uint32_t pj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)pred);
+                    const uint32_t uj = (uint32_t)__builtin_amdgcn_ds_bpermute((int)src, (int)unit);
+                    const int32_t *cu = crec + (size_t)uj * np;
+                    uint32_t sum = 0;
+                    {
+                        const uint32_t d = i + 1u;
+                        const int32_t hsel = (i < j) ? ycur : yprev;
+                        const int32_t val = __builtin_amdgcn_ds_bpermute((int)((rowbase + ((j - d) & 15u)) * 4u), hsel);
+                        if (gen && pj && d <= np) sum = (uint32_t)cu[np - d] * (uint32_t)val;
+                    }
+                    if (NCH) {
+                        for (uint32_t d = i + 17u; d <= (uint32_t)(16 * NCH + 16); d += 16u) {
+                            const uint32_t ix = (16u * m + j - d) & 255u;
+                            const uint32_t val = (uint32_t)(int32_t)ring[q][0][ix] + ((uint32_t)(int32_t)ring[q][1][ix] << 8)
+                                               + ((uint32_t)(int32_t)ring[q][2][ix] << 16) + ((uint32_t)(int32_t)ring[q][3][ix] << 24);
+                            if (gen && pj && d <= np) sum += (uint32_t)cu[np - d] * val;
+                        }
+                    }
+                    sum = row_sum_all(sum);
+                    const int32_t y = pj ? (int32_t)((uint32_t)resj - (uint32_t)((int32_t)(half + sum) >> sh_)) : resj;
+                    if (i == j) ycur = y;
+                }
+                if (gen) yout = ycur;
+            }
+            stg_out[q][16u * k + i] = yout;
+            if (NCH) {
+                const uint32_t dg = sp_digits(yout), ix = (16u * m + i) & 255u;
+                ring[q][0][ix] = (int8_t)dg; ring[q][1][ix] = (int8_t)(dg >> 8); ring[q][2][ix] = (int8_t)(dg >> 16); ring[q][3][ix] = (int8_t)(dg >> 24);
+            }
+            yprev = yout;
+            mcur = mnext;
+            tl += 16u; settle();
+        }
+        /* the chunk's outputs: 16 bytes per lane; nothing behind a frame's end is written */
+        {
+            const uint32_t s0 = 64u * c + 4u * i;
+            const lnn_v4i v = *(const lnn_v4i *)&stg_out[q][4u * i];
+            if (have) {
+                if (s0 + 3u < n) *(lnn_v4i *)(g + s0) = v;
+                else { if (s0 < n) g[s0] = v[0]; if (s0 + 1u < n) g[s0 + 1u] = v[1]; if (s0 + 2u < n) g[s0 + 2u] = v[2]; }
+            }
+        }
+    }
+}
+#undef SR_STEPS
+#undef SR_PAD
+#undef SR_CST
+
+#endif

@@ -289,7 +289,7 @@ def test_own_cli_matches_the_reference_cli(tmp_path):
         assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows"])
 @pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
 def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
     """DecodeFramesDevice picks its kernels by batch size (one wave per channel-frame for small batches; lanes =
@@ -322,6 +322,8 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
         monkeypatch.setenv("LINNE_AMD_STATS_ROWS", "1")          # the batch form of the block-type statistics (round 3)
     if seed % 3 == 2:
         monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "lanes")   # (the default for these short streams is the pipelined latency form)
+    if seed % 3 == 1:
+        monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows")    # four channel-frames per wave (the batch form of every layer but the de-emphasised one)
     if seed % 4 == 3:
         monkeypatch.setenv("LINNE_AMD_PREP_GENERAL", "1")
     rng = np.random.default_rng(1000 + seed)
@@ -354,7 +356,7 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     assert ret == 0 and np.array_equal(dec, x)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows"])
 def test_corrupt_streams_do_not_hang_or_fault(product, oracle, monkeypatch, kernel):
     """with the CRC check off a damaged payload reaches the parser and the GPU with arbitrary parameters (unit counts,
     shifts, coefficients, residuals): decoding must come back with a result code (and the device must stay usable)"""
