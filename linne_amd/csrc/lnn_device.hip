@@ -995,9 +995,9 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
         else for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
             const bool de = (l == 0);
             /* k_synth_rows (four channel-frames per wave, the old taps on the matrix unit) takes the layers without de-emphasis whose
-             * order is a preset's, when the samples can travel as 16-byte groups; by default the long ones (LINNE_AMD_DECODE_KERNEL=rows: all) */
+             * order is a preset's, when the samples can travel as 16-byte groups (LINNE_AMD_DECODE_KERNEL=lanes: none) */
             const int nch = hs.P[l] <= 16u ? 0 : (hs.P[l] == 32u ? 1 : (hs.P[l] == 64u ? 3 : (hs.P[l] == 128u ? 7 : -1)));
-            if (!de && nch >= 0 && form != 2 && (form == 4 || nch > 0) && (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u) {
+            if (!de && nch >= 0 && form != 2 && (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u) {
                 const int sp_ = span_begin(ctx, 33, ctx->stream);
                 const dim3 grows((CF + 3) / 4);
                 switch (nch) {

@@ -25,7 +25,7 @@
 #ifndef LNN_K_DECODE_ROWS_H_INCLUDED
 #define LNN_K_DECODE_ROWS_H_INCLUDED
 
-template <int J> __device__ __forceinline__ int32_t row_bcast(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, false); }   /* row_newbcast:J */
+template <int J> __device__ __forceinline__ int32_t row_bcast(int32_t v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true); }   /* row_newbcast:J (every lane has a source: nothing is bound) */
 __device__ __forceinline__ uint32_t row_sum_all(uint32_t v)      /* wrap-around sum over the 16 lanes of a row, in every lane of it */
 {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);   /* row_ror:8 */
@@ -74,10 +74,8 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
     const int8_t *abase = (((lane & 15u) >> 2) == q) ? &ring[(lane & 15u) >> 2][lane & 3u][0] : &zeros[0];
 
     /* place of my sample in its unit; the state my row's coefficient registers are built for */
-    uint32_t unit = 0, tl = i;
-    auto settle = [&]() { while (!skip && unit < units && tl >= ns) { tl -= ns; unit++; } };
-    settle();
-    bool arr_pred = false; uint32_t arr_unit = 0u, half_l = 0u;
+    uint32_t unit = 0, m_event = 0u, half_l = 0u;               /* m_event: the first block in which my sample's class may be another */
+    bool pred = false;
     int32_t ccA[16], ccB[16];
     lnn_v4i tz[NCH ? NCH : 1];
 #pragma unroll
@@ -118,11 +116,22 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
             const uint32_t m = 4u * c + k;
             if (16u * m >= nmax) break;
             const int32_t res = stg_in[c & 1u][q][16u * k + i];
-            const bool pred = !skip && unit < units && tl >= np;
-            /* my row's class in this block: all lanes predicting in one unit, none predicting, or mixed (generic) */
-            const bool ok = (pred == arr_pred) && (!pred || unit == arr_unit);
             bool gen = false;
-            if (!__all(ok)) {
+            if (!__all(m < m_event)) {
+                /* a lane's class changes here: every row's class in this block -- all lanes predicting in one unit, none
+                 * predicting, or mixed (the generic routine) -- and for how many blocks every lane keeps its own */
+                {
+                    const uint32_t t = 16u * m + i;
+                    unit = skip ? units : t / (ns ? ns : 1u);
+                    uint32_t ahead = 0xFFFFFFFFu;               /* behind the last unit (or a skipped layer): copied to the end */
+                    pred = false;
+                    if (unit < units) {
+                        const uint32_t tl = t - unit * ns;
+                        pred = tl >= np;
+                        ahead = ((pred ? ns : np) - tl + 15u) / 16u;
+                    }
+                    m_event = (ahead == 0xFFFFFFFFu) ? ahead : m + ahead;
+                }
                 const uint64_t bp = __ballot(pred);
                 const uint32_t rb = (uint32_t)(bp >> (16u * q)) & 0xFFFFu;
                 const uint32_t u0 = (uint32_t)row_bcast<0>((int32_t)unit);
@@ -156,9 +165,9 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
                         tz[cc] = lnn_v4i{ (int)w[0], (int)w[1], (int)w[2], (int)w[3] };
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    arr_pred = bpred; arr_unit = unit; half_l = bpred ? half : 0u;
+                    half_l = bpred ? half : 0u;
                 }
-                if (gen) { arr_pred = true; arr_unit = 0xFFFFFFFFu; }          /* no state: the next steady block builds */
+                if (gen) m_event = m + 1u;                      /* a mixed row has no state: the next block builds */
                 /* what the previous block adds to this one's sums, and the matrix-unit part, with the registers as they are now
                  * (rows that kept their state get the values they had: the sums are associative) */
                 nxt = 0;
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
             nxt = 0;
             /* speculation as in k_synth_pipe: every output of the block fits 24 bits -- one full-rate multiply-add per sum */
 #define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
-                acc += (uint32_t)__mul24(ccA[J], sv); nxt += (uint32_t)__mul24(ccB[J], sv); }
+                acc += (uint32_t)__mul24(ccA[J], sv); asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nxt) : "v"(ccB[J]), "v"(sv)); }     /* (a multiply-add per tap: the compiler's tree of products and three-operand adds is half as many again) */
             SR_STEPS(0)
 #undef SR_STEP
             int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
@@ -225,7 +234,6 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
             }
             yprev = yout;
             mcur = mnext;
-            tl += 16u; settle();
         }
         /* the chunk's outputs: 16 bytes per lane; nothing behind a frame's end is written */
         {
