@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
 FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25)
-DECODE_KINDS = (11, 12, 30, 31, 32, 33)
+DECODE_KINDS = (11, 12, 30, 31, 32, 33, 34)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
                 5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)",
                 25: "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)",
@@ -65,7 +65,8 @@ KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocor
                 11: "k_synthesize (one wave per channel-frame, all layers)", 12: "k_ms_to_lr",
                 30: "k_synth_big<P> (synthesis of the long layer)", 31: "k_synth_small<P> (synthesis of the short layers, de-emphasis)",
                 32: "k_synth_pipe (a wave per stage of the cascade, 16-sample blocks: the latency form)",
-                33: "k_synth_rows<NCH> (four channel-frames per wave, the old taps on the matrix unit: the throughput form)"}
+                33: "k_synth_rows<NCH> (four channel-frames per wave, the old taps on the matrix unit: the throughput form)",
+                34: "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out)"}
 
 
 def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):

@@ -975,6 +975,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
     p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
     ctx->nspans = 0;
+    bool ms_done = false;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
     {   /* layers in reverse order (linne_decoder.c:503-509): long layers one wave per channel-frame, short ones (order <= 16)
          * with lanes = channel-frames; the de-emphasis rides on layer 0's pass */
@@ -989,7 +990,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
         const bool pipe_fits = SP_LDS_BYTES(p.S) <= LEV_LDS_BUDGET;
         const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < 6144u ? 3 : 0);
         const bool use_pipe = (form == 3) && pipe_fits, use_wave = (form == 1) || (form == 3 && !pipe_fits);
-        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows */
+        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows, 34 = k_deemph_lr */
         if (use_pipe) { const int sp_ = span_begin(ctx, 32, ctx->stream); hipLaunchKernelGGL(k_synth_pipe, dim3(CF), dim3(64 * (hs.L + 1)), SP_LDS_BYTES(p.S), ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
         else if (use_wave) { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u); span_end(ctx, sp_, ctx->stream); }
         else for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
@@ -997,7 +998,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
             /* k_synth_rows (four channel-frames per wave, the old taps on the matrix unit) takes the layers without de-emphasis whose
              * order is a preset's, when the samples can travel as 16-byte groups (LINNE_AMD_DECODE_KERNEL=lanes: none) */
             const int nch = hs.P[l] <= 16u ? 0 : (hs.P[l] == 32u ? 1 : (hs.P[l] == 64u ? 3 : (hs.P[l] == 128u ? 7 : -1)));
-            if (!de && nch >= 0 && form != 2 && (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u) {
+            if (nch >= 0 && form != 2 && (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u) {
                 const int sp_ = span_begin(ctx, 33, ctx->stream);
                 const dim3 grows((CF + 3) / 4);
                 switch (nch) {
@@ -1007,6 +1008,12 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 default: hipLaunchKernelGGL((k_synth_rows<7>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
                 }
                 span_end(ctx, sp_, ctx->stream);
+                if (de) {       /* the de-emphasis behind layer 0 (lanes = channel-frames), MS -> LR on its way out when a block of 64 rows holds whole frames */
+                    const int sd_ = span_begin(ctx, 34, ctx->stream);
+                    if (p.ms && p.C >= 2u && 64u % p.C == 0u) { hipLaunchKernelGGL((k_deemph_lr<true>), dim3(gsmall), dim3(64), 0, ctx->stream, p); ms_done = true; }
+                    else hipLaunchKernelGGL((k_deemph_lr<false>), dim3(gsmall), dim3(64), 0, ctx->stream, p);
+                    span_end(ctx, sd_, ctx->stream);
+                }
                 continue;
             }
             const int sp_ = span_begin(ctx, hs.P[l] <= 16u ? 31 : (hs.P[l] <= 128u && (hs.P[l] & (hs.P[l] - 1u)) == 0 ? 30 : 11), ctx->stream);
@@ -1023,7 +1030,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
             span_end(ctx, sp_, ctx->stream);
         }
     }
-    if (p.ms)
+    if (p.ms && !ms_done)
         { const int sp_ = span_begin(ctx, 12, ctx->stream); hipLaunchKernelGGL(k_ms_to_lr, dim3(num_frames, (p.S + 255) / 256), dim3(256), 0, ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
     HIPCHK(ctx, hipGetLastError());
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[1], ctx->stream)); ctx->ev_valid = 1; }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(64) void k_synth_small(DecPlan p, uint32_t layer)
 #pragma unroll
         for (int r = 0; r < 64; r++) {
             const uint32_t row = row0 + r, sidx = t * SYN_T + lane;
-            if (row < nrows && sidx < p.nsmp[row / p.C]) p.data[(size_t)row * S + sidx] = tile[lane][r];
+            if (row < nrows && sidx < (uint32_t)__builtin_amdgcn_readlane((int)n, r)) p.data[(size_t)row * S + sidx] = tile[lane][r];      /* (lane r holds row r's length: no division by the channel count and no load per row) */
         }
         __syncthreads();
     }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const uint32_t row = row0 + r, sidx = t * SYB_T + lane;
-            if (row < nrows && sidx < p.nsmp[row / p.C]) p.data[(size_t)row * S + sidx] = tile[r][lane];
+            if (row < nrows && sidx < (uint32_t)__builtin_amdgcn_readlane((int)n, 4 * r)) p.data[(size_t)row * S + sidx] = tile[r][lane];    /* (lanes 4 r .. 4 r + 3 hold row r's length) */
         }
         __syncthreads();
     }

@@ -246,6 +246,66 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
         }
     }
 }
+
+/* k_deemph_lr: what follows layer 0 when k_synth_rows took it -- the two-stage de-emphasis (linne_utility.c:215-241), a scalar
+ * recurrence per channel-frame, with lanes = channel-frames (64 x 64 tiles transposed through LDS as in k_synth_small: coalesced
+ * loads and stores, the next tile requested ahead), and MS -> LR (linne_utility.c:135-147) on the way out when the frames of a
+ * block of 64 rows are whole (FUSE_MS: 64 % C == 0; k_ms_to_lr otherwise).  A pass costs one wave's 10 240 steps of ten
+ * instructions whatever the batch. */
+template <bool FUSE_MS>
+__global__ __launch_bounds__(64) void k_deemph_lr(DecPlan p)
+{
+    __shared__ int32_t tile[64][65];
+    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64u, S = p.S, C = p.C;
+    const uint32_t nrows = p.F * C;
+    uint32_t cf = row0 + lane;
+    if (cf >= nrows) cf = nrows - 1u;
+    const uint32_t n = p.nsmp[cf / C];
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    const int32_t c0e = rec[LINNE_AMD_PRM_PCOEF + 0], c1e = rec[LINNE_AMD_PRM_PCOEF + 1];
+    int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    const uint32_t ntiles = (nmax + 63u) / 64u;
+    int32_t pre[64];
+    auto issue = [&](uint32_t t) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const uint32_t row = (row0 + r < nrows) ? row0 + r : nrows - 1u, sidx = t * 64u + lane;
+            pre[r] = (sidx < S) ? p.data[(size_t)row * S + sidx] : 0;
+        }
+    };
+    if (ntiles) issue(0);
+    for (uint32_t t = 0; t < ntiles; t++) {
+#pragma unroll
+        for (int r = 0; r < 64; r++) tile[lane][r] = pre[r];      /* transposed: tile[sample][row] */
+        if (t + 1u < ntiles) issue(t + 1u);
+        __syncthreads();
+#pragma unroll 16
+        for (uint32_t s = 0; s < 64u; s++) {                      /* (behind a frame's end the state runs on: nothing of it is stored) */
+            const int32_t z = (int32_t)((uint32_t)tile[s][lane] + (uint32_t)mulshr5(zp, c1e));
+            const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+            zp = z; yp = y;
+            tile[s][lane] = y;
+        }
+        __syncthreads();
+        const uint32_t sidx = t * 64u + lane;
+        uint32_t ch = 0;                                          /* row r's channel (row0 is a multiple of C when FUSE_MS) */
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const uint32_t row = row0 + r;
+            int32_t v = tile[lane][r];
+            if (FUSE_MS) {                                        /* channels 0 and 1 of a frame are rows r, r + 1 of this block */
+                if (ch == 0u && C >= 2u) v = (int32_t)((uint32_t)v - (uint32_t)(tile[lane][(r + 1) & 63] >> 1));
+                else if (ch == 1u) { const uint32_t l = (uint32_t)tile[lane][(r - 1) & 63] - (uint32_t)(v >> 1); v = (int32_t)((uint32_t)v + l); }
+            }
+            if (row < nrows && sidx < (uint32_t)__builtin_amdgcn_readlane((int)n, r)) p.data[(size_t)row * S + sidx] = v;      /* (lane r holds row r's length) */
+            if (FUSE_MS) { ch++; if (ch == C) ch = 0u; }
+        }
+        __syncthreads();
+    }
+}
 #undef SR_STEPS
 #undef SR_PAD
 #undef SR_CST
