@@ -973,7 +973,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     DecPlan p; memset(&p, 0, sizeof(p));
     p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
     for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
-    p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
+    p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp; p.dbg = ctx->knob.dbg_maxtr;
     ctx->nspans = 0;
     bool ms_done = false;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
@@ -1010,8 +1010,8 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 span_end(ctx, sp_, ctx->stream);
                 if (de) {       /* the de-emphasis behind layer 0 (lanes = channel-frames), MS -> LR on its way out when a block of 64 rows holds whole frames */
                     const int sd_ = span_begin(ctx, 34, ctx->stream);
-                    if (p.ms && p.C >= 2u && 64u % p.C == 0u) { hipLaunchKernelGGL((k_deemph_lr<true>), dim3(gsmall), dim3(64), 0, ctx->stream, p); ms_done = true; }
-                    else hipLaunchKernelGGL((k_deemph_lr<false>), dim3(gsmall), dim3(64), 0, ctx->stream, p);
+                    if (p.ms && p.C >= 2u && p.C <= 64u && (p.C & (p.C - 1u)) == 0u) { hipLaunchKernelGGL((k_deemph_lr<true>), dim3(gsmall), dim3(192), 0, ctx->stream, p); ms_done = true; }
+                    else hipLaunchKernelGGL((k_deemph_lr<false>), dim3(gsmall), dim3(192), 0, ctx->stream, p);
                     span_end(ctx, sd_, ctx->stream);
                 }
                 continue;

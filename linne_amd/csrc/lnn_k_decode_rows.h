@@ -42,7 +42,7 @@ __device__ __forceinline__ uint32_t row_sum_all(uint32_t v)      /* wrap-around 
 #define SR_PAD 160u      /* zeros in front of the staged coefficients: distances up to 128 + 16 + 15 beyond np */
 #define SR_CST 320u      /* SR_PAD + 128 coefficients + 16 zeros (distances <= 0), rounded */
 template <int NCH>      /* 16-sample chunks of older history on the matrix unit: 0 for layers of <= 16 taps, 1 for 32, 3 for 64, 7 for 128 */
-__global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p, uint32_t layer)
+__global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p, uint32_t layer)
 {
     __shared__ __attribute__((aligned(16))) int8_t ring[4][4][256];          /* [channel-frame][digit plane][sample mod 256] */
     __shared__ __attribute__((aligned(16))) int8_t zeros[256];               /* what the A operand's other K groups read */
@@ -107,75 +107,79 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
     lnn_v4i pre = { 0, 0, 0, 0 };
     if (nchunk) { const lnn_v4i first = fetch(0); *(lnn_v4i *)&stg_in[0][q][4u * i] = first; }
     if (nchunk > 1u) pre = fetch(1);
+    const uint32_t nblk = (nmax + 15u) / 16u;
 
+    /* Outer loop: a block in which some lane's class changes -- the rows' classes, their coefficient registers (written HERE and
+     * nowhere else, so the inner loop holds them in place), what the previous outputs add.  Inner loop: blocks while every lane
+     * keeps its class. */
+    uint32_t m = 0;
 #pragma unroll 1
-    for (uint32_t c = 0; c < nchunk; c++) {
-        if (c + 1u < nchunk) { *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][4u * i] = pre; if (c + 2u < nchunk) pre = fetch(c + 2u); }
-#pragma unroll 1
-        for (uint32_t k = 0; k < 4u; k++) {
-            const uint32_t m = 4u * c + k;
-            if (16u * m >= nmax) break;
-            const int32_t res = stg_in[c & 1u][q][16u * k + i];
-            bool gen = false;
-            if (!__all(m < m_event)) {
-                /* a lane's class changes here: every row's class in this block -- all lanes predicting in one unit, none
-                 * predicting, or mixed (the generic routine) -- and for how many blocks every lane keeps its own */
-                {
-                    const uint32_t t = 16u * m + i;
-                    unit = skip ? units : t / (ns ? ns : 1u);
-                    uint32_t ahead = 0xFFFFFFFFu;               /* behind the last unit (or a skipped layer): copied to the end */
-                    pred = false;
-                    if (unit < units) {
-                        const uint32_t tl = t - unit * ns;
-                        pred = tl >= np;
-                        ahead = ((pred ? ns : np) - tl + 15u) / 16u;
-                    }
-                    m_event = (ahead == 0xFFFFFFFFu) ? ahead : m + ahead;
+    while (m < nblk) {
+        bool gen = false;
+        {
+            /* a lane's class changes here: every row's class in this block -- all lanes predicting in one unit, none
+             * predicting, or mixed (the generic routine) -- and for how many blocks every lane keeps its own */
+            {
+                const uint32_t t = 16u * m + i;
+                unit = skip ? units : t / (ns ? ns : 1u);
+                uint32_t ahead = 0xFFFFFFFFu;               /* behind the last unit (or a skipped layer): copied to the end */
+                pred = false;
+                if (unit < units) {
+                    const uint32_t tl = t - unit * ns;
+                    pred = tl >= np;
+                    ahead = ((pred ? ns : np) - tl + 15u) / 16u;
                 }
-                const uint64_t bp = __ballot(pred);
-                const uint32_t rb = (uint32_t)(bp >> (16u * q)) & 0xFFFFu;
-                const uint32_t u0 = (uint32_t)row_bcast<0>((int32_t)unit);
-                const uint64_t bu = __ballot(pred && unit != u0);
-                const bool same_unit = ((uint32_t)(bu >> (16u * q)) & 0xFFFFu) == 0u;
-                const bool all_pred = (rb == 0xFFFFu) && same_unit, all_pass = (rb == 0u);
-                gen = !(all_pred || all_pass);
-                {   /* the coefficient registers of every row for the state it is in now (rows that keep theirs get the same values again: the
-                     * branch is the wave's, not the lane's, so the registers are written in place); a mixed row: zeros, no state */
-                    const bool bpred = pred && !gen;
-                    /* the unit's coefficients (8 bits by format), staged as bytes between two runs of zeros: tap of distance d =
-                     * cu[np - d] (linne_lpc_synthesize.c:30) sits at SR_PAD + np - d, and every distance outside 1 .. np reads a zero */
-                    if (bpred) {
-                        const int32_t *cu = crec + (size_t)unit * np;
-                        int32_t cv[8];
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) { const uint32_t k = i + 16u * (uint32_t)kk; cv[kk] = (k < np) ? cu[k] : 0; }
-#pragma unroll
-                        for (int kk = 0; kk < 8; kk++) { const uint32_t k = i + 16u * (uint32_t)kk; if (k < np) cst[q][SR_PAD + k] = (int8_t)cv[kk]; }
-                    }
-                    const int8_t *cb = &cst[q][0] + (bpred ? SR_PAD + np - i : SR_PAD - 17u);      /* (no state: zeros whatever the distance) */
-#pragma unroll
-                    for (int j = 0; j < 16; j++) { ccA[j] = cb[j]; ccB[j] = cb[j - 16]; }         /* distances i - j and 16 + i - j */
-                    __builtin_amdgcn_sched_barrier(0);          /* (a group of reads at a time: the registers are the steady code's) */
-#pragma unroll
-                    for (int cc = 0; cc < NCH; cc++) {
-                        uint32_t w[4] = { 0u, 0u, 0u, 0u };
-#pragma unroll
-                        for (int e = 0; e < 16; e++)            /* element e of chunk cc lies d = 32 + 16 cc + i - e samples before output i */
-                            w[e >> 2] |= ((uint32_t)cb[e - 32 - 16 * cc] & 0xFFu) << (8 * (e & 3));
-                        tz[cc] = lnn_v4i{ (int)w[0], (int)w[1], (int)w[2], (int)w[3] };
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    half_l = bpred ? half : 0u;
-                }
-                if (gen) m_event = m + 1u;                      /* a mixed row has no state: the next block builds */
-                /* what the previous block adds to this one's sums, and the matrix-unit part, with the registers as they are now
-                 * (rows that kept their state get the values they had: the sums are associative) */
-                nxt = 0;
-#define SR_STEP(J, MUL_) { const int32_t sv = row_bcast<J>(yprev); nxt += sp_mul8(ccB[J], sv & 0xFFFF, sv >> 16); }
-                SR_STEPS(0)
-#undef SR_STEP
-                mcur = window(m);
+                m_event = (ahead == 0xFFFFFFFFu) ? ahead : m + ahead;
             }
+            const uint64_t bp = __ballot(pred);
+            const uint32_t rb = (uint32_t)(bp >> (16u * q)) & 0xFFFFu;
+            const uint32_t u0 = (uint32_t)row_bcast<0>((int32_t)unit);
+            const uint64_t bu = __ballot(pred && unit != u0);
+            const bool same_unit = ((uint32_t)(bu >> (16u * q)) & 0xFFFFu) == 0u;
+            const bool all_pred = (rb == 0xFFFFu) && same_unit, all_pass = (rb == 0u);
+            gen = !(all_pred || all_pass);
+            {   /* the coefficient registers of every row for the state it is in now (rows that keep theirs get the same values
+                 * again); a mixed row: zeros, no state */
+                const bool bpred = pred && !gen;
+                /* the unit's coefficients (8 bits by format), staged as bytes between two runs of zeros: tap of distance d =
+                 * cu[np - d] (linne_lpc_synthesize.c:30) sits at SR_PAD + np - d, and every distance outside 1 .. np reads a zero */
+                if (bpred) {
+                    const int32_t *cu = crec + (size_t)unit * np;
+                    int32_t cv[8];
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++) { const uint32_t k = i + 16u * (uint32_t)kk; cv[kk] = (k < np) ? cu[k] : 0; }
+#pragma unroll
+                    for (int kk = 0; kk < 8; kk++) { const uint32_t k = i + 16u * (uint32_t)kk; if (k < np) cst[q][SR_PAD + k] = (int8_t)cv[kk]; }
+                }
+                const int8_t *cb = &cst[q][0] + (bpred ? SR_PAD + np - i : SR_PAD - 17u);      /* (no state: zeros whatever the distance) */
+#pragma unroll
+                for (int j = 0; j < 16; j++) { ccA[j] = cb[j]; ccB[j] = cb[j - 16]; }         /* distances i - j and 16 + i - j */
+                __builtin_amdgcn_sched_barrier(0);          /* (a group of reads at a time: the registers are the steady code's) */
+#pragma unroll
+                for (int cc = 0; cc < NCH; cc++) {
+                    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                    for (int e = 0; e < 16; e++)            /* element e of chunk cc lies d = 32 + 16 cc + i - e samples before output i */
+                        w[e >> 2] |= ((uint32_t)cb[e - 32 - 16 * cc] & 0xFFu) << (8 * (e & 3));
+                    tz[cc] = lnn_v4i{ (int)w[0], (int)w[1], (int)w[2], (int)w[3] };
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                half_l = bpred ? half : 0u;
+            }
+            if (gen) m_event = m + 1u;                      /* a mixed row has no state: the next block builds */
+            /* what the previous block adds to this one's sums, and the matrix-unit part, with the registers as they are now
+             * (rows that kept their state get the values they had: the sums are associative) */
+            nxt = 0;
+#define SR_STEP(J, MUL_) { const int32_t sv = row_bcast<J>(yprev); nxt += sp_mul8(ccB[J], sv & 0xFFFF, sv >> 16); }
+            SR_STEPS(0)
+#undef SR_STEP
+            mcur = window(m);
+        }
+#pragma unroll 1
+        do {
+            const uint32_t c = m >> 2, k = m & 3u;
+            if (k == 0u && c + 1u < nchunk) { *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][4u * i] = pre; if (c + 2u < nchunk) pre = fetch(c + 2u); }
+            const int32_t res = stg_in[c & 1u][q][16u * k + i];
             const uint32_t mnext = window(m + 1u);              /* issued now, needed a block later */
             const uint32_t acc0 = half_l + mcur + nxt;
             uint32_t acc = acc0;
@@ -234,29 +238,34 @@ __global__ __launch_bounds__(64, (NCH >= 3 ? 2 : 4)) void k_synth_rows(DecPlan p
             }
             yprev = yout;
             mcur = mnext;
-        }
-        /* the chunk's outputs: 16 bytes per lane; nothing behind a frame's end is written */
-        {
-            const uint32_t s0 = 64u * c + 4u * i;
-            const lnn_v4i v = *(const lnn_v4i *)&stg_out[q][4u * i];
-            if (have) {
-                if (s0 + 3u < n) *(lnn_v4i *)(g + s0) = v;
-                else { if (s0 < n) g[s0] = v[0]; if (s0 + 1u < n) g[s0 + 1u] = v[1]; if (s0 + 2u < n) g[s0 + 2u] = v[2]; }
+            m++;
+            if (k == 3u || m == nblk) {
+                /* the chunk's outputs: 16 bytes per lane; nothing behind a frame's end is written */
+                const uint32_t s0 = 64u * c + 4u * i;
+                const lnn_v4i v = *(const lnn_v4i *)&stg_out[q][4u * i];
+                if (have) {
+                    if (s0 + 3u < n) *(lnn_v4i *)(g + s0) = v;
+                    else { if (s0 < n) g[s0] = v[0]; if (s0 + 1u < n) g[s0 + 1u] = v[1]; if (s0 + 2u < n) g[s0 + 2u] = v[2]; }
+                }
             }
-        }
+        } while (m < nblk && __all(m < m_event));
     }
 }
 
 /* k_deemph_lr: what follows layer 0 when k_synth_rows took it -- the two-stage de-emphasis (linne_utility.c:215-241), a scalar
- * recurrence per channel-frame, with lanes = channel-frames (64 x 64 tiles transposed through LDS as in k_synth_small: coalesced
- * loads and stores, the next tile requested ahead), and MS -> LR (linne_utility.c:135-147) on the way out when the frames of a
- * block of 64 rows are whole (FUSE_MS: 64 % C == 0; k_ms_to_lr otherwise).  A pass costs one wave's 10 240 steps of ten
- * instructions whatever the batch. */
+ * recurrence per channel-frame, with lanes = channel-frames, and MS -> LR (linne_utility.c:135-147) on the way out when the frames
+ * of a block of 64 rows are whole (FUSE_MS: C a power of two <= 64; k_ms_to_lr otherwise).  Tiles of 64 rows x 64 samples go through
+ * LDS; a load or store instruction moves 16 bytes per lane = 256 bytes of four rows (16 instructions per tile and direction).
+ * A wave alone on its SIMD issues an instruction every ~9 cycles, so a pass costs what ONE wave executes per tile: the block is three
+ * waves with a role each -- wave 0 requests tile t + 2 and writes tile t + 1 into LDS, wave 1 runs the recurrences over tile t (the
+ * only serial part: 64 steps of eight instructions), wave 2 turns tile t - 1 into left / right and stores it -- three tile buffers, a
+ * barrier per tile. */
 template <bool FUSE_MS>
-__global__ __launch_bounds__(64) void k_deemph_lr(DecPlan p)
+__global__ __launch_bounds__(192) void k_deemph_lr(DecPlan p)
 {
-    __shared__ int32_t tile[64][65];
-    const uint32_t lane = threadIdx.x, row0 = blockIdx.x * 64u, S = p.S, C = p.C;
+    __shared__ int32_t tile[3][64][65];                           /* [tile mod 3][row][sample]: bank = row + sample, no conflicts either way */
+    const uint32_t lane = threadIdx.x & 63u, row0 = blockIdx.x * 64u, S = p.S, C = p.C;
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t nrows = p.F * C;
     uint32_t cf = row0 + lane;
     if (cf >= nrows) cf = nrows - 1u;
@@ -267,41 +276,71 @@ __global__ __launch_bounds__(64) void k_deemph_lr(DecPlan p)
     uint32_t nmax = n;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
-    const uint32_t ntiles = (nmax + 63u) / 64u;
-    int32_t pre[64];
+    const uint32_t ntiles = (uint32_t)__builtin_amdgcn_readfirstlane((int)((nmax + 63u) / 64u));
+    /* instruction k of a tile: rows 4 k + (lane >> 4), samples 4 (lane & 15) .. + 3; rows behind the last one read the last one again */
+    const uint32_t rq = lane >> 4, i4 = 4u * (lane & 15u);
+    const uint32_t nv = (nrows - row0 < 64u) ? nrows - row0 : 64u;
+    int32_t *blk = p.data + (size_t)row0 * S;
+    lnn_v4i pre[16];
     auto issue = [&](uint32_t t) {
+        const uint32_t s0 = t * 64u + i4;
 #pragma unroll
-        for (int r = 0; r < 64; r++) {
-            const uint32_t row = (row0 + r < nrows) ? row0 + r : nrows - 1u, sidx = t * 64u + lane;
-            pre[r] = (sidx < S) ? p.data[(size_t)row * S + sidx] : 0;
+        for (int k = 0; k < 16; k++) {
+            const uint32_t r = 4u * (uint32_t)k + rq, rr = (r < nv) ? r : nv - 1u;
+            pre[k] = (s0 < S) ? *(const lnn_v4i *)(blk + rr * S + s0) : lnn_v4i{ 0, 0, 0, 0 };      /* (S is a multiple of 4) */
         }
     };
-    if (ntiles) issue(0);
-    for (uint32_t t = 0; t < ntiles; t++) {
+    auto commit = [&](uint32_t t) {
 #pragma unroll
-        for (int r = 0; r < 64; r++) tile[lane][r] = pre[r];      /* transposed: tile[sample][row] */
-        if (t + 1u < ntiles) issue(t + 1u);
-        __syncthreads();
-#pragma unroll 16
-        for (uint32_t s = 0; s < 64u; s++) {                      /* (behind a frame's end the state runs on: nothing of it is stored) */
-            const int32_t z = (int32_t)((uint32_t)tile[s][lane] + (uint32_t)mulshr5(zp, c1e));
-            const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
-            zp = z; yp = y;
-            tile[s][lane] = y;
+        for (int k = 0; k < 16; k++) {
+            int32_t *w = &tile[t % 3u][4 * k + rq][i4];
+            w[0] = pre[k][0]; w[1] = pre[k][1]; w[2] = pre[k][2]; w[3] = pre[k][3];
         }
-        __syncthreads();
-        const uint32_t sidx = t * 64u + lane;
-        uint32_t ch = 0;                                          /* row r's channel (row0 is a multiple of C when FUSE_MS) */
-#pragma unroll
-        for (int r = 0; r < 64; r++) {
-            const uint32_t row = row0 + r;
-            int32_t v = tile[lane][r];
-            if (FUSE_MS) {                                        /* channels 0 and 1 of a frame are rows r, r + 1 of this block */
-                if (ch == 0u && C >= 2u) v = (int32_t)((uint32_t)v - (uint32_t)(tile[lane][(r + 1) & 63] >> 1));
-                else if (ch == 1u) { const uint32_t l = (uint32_t)tile[lane][(r - 1) & 63] - (uint32_t)(v >> 1); v = (int32_t)((uint32_t)v + l); }
+    };
+    if (role == 0u && ntiles) { issue(0); commit(0); if (ntiles > 1u) issue(1); }
+    __syncthreads();
+    /* iteration t: tile t + 1 goes into LDS, tile t is de-emphasised, tile t - 1 leaves */
+    for (uint32_t t = 0; t < ntiles + 1u; t++) {
+        if (role == 0u) {
+            if (t + 1u < ntiles) { commit(t + 1u); if (t + 2u < ntiles) issue(t + 2u); }
+        } else if (role == 1u) {
+            if (t < ntiles) {
+                int32_t (*tl)[65] = tile[t % 3u];
+#pragma unroll 16
+                for (uint32_t s = 0; s < 64u; s++) {              /* (behind a frame's end the state runs on: nothing of it is stored) */
+                    const int32_t z = (int32_t)((uint32_t)tl[lane][s] + (uint32_t)mulshr5(zp, c1e));
+                    const int32_t y = (int32_t)((uint32_t)z + (uint32_t)mulshr5(yp, c0e));
+                    zp = z; yp = y;
+                    tl[lane][s] = y;
+                }
             }
-            if (row < nrows && sidx < (uint32_t)__builtin_amdgcn_readlane((int)n, r)) p.data[(size_t)row * S + sidx] = v;      /* (lane r holds row r's length) */
-            if (FUSE_MS) { ch++; if (ch == C) ch = 0u; }
+        } else if (t >= 1u) {
+            const uint32_t to = t - 1u, s0 = to * 64u + i4;
+            int32_t (*tl)[65] = tile[to % 3u];
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint32_t r = 4u * (uint32_t)k + rq;
+                const int32_t *w = &tl[r][i4];
+                lnn_v4i v = { w[0], w[1], w[2], w[3] };
+                if (FUSE_MS) {                                    /* row0 is a multiple of C: channels 0 and 1 of a frame are neighbouring rows of this block */
+                    const uint32_t ch = r & (C - 1u);
+                    if (ch < 2u) {
+                        const int32_t *o = &tl[r ^ 1u][i4];       /* (C >= 2: rows r and r ^ 1 are the frame's channels 0 and 1) */
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t m_ = (uint32_t)(ch ? o[j] : v[j]), sd = (uint32_t)(ch ? v[j] : o[j]);
+                            const uint32_t l = m_ - (uint32_t)((int32_t)sd >> 1);
+                            v[j] = (int32_t)(ch ? sd + l : l);
+                        }
+                    }
+                }
+                const uint32_t nr = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((r & 63u) * 4u), (int)n);      /* row r's length: lane r holds it */
+                if (r < nv) {
+                    int32_t *gp = blk + r * S + s0;
+                    if (s0 + 3u < nr) *(lnn_v4i *)gp = v;
+                    else { if (s0 < nr) gp[0] = v[0]; if (s0 + 1u < nr) gp[1] = v[1]; if (s0 + 2u < nr) gp[2] = v[2]; }
+                }
+            }
         }
         __syncthreads();
     }
