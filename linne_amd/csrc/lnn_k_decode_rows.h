@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
     __shared__ __attribute__((aligned(16))) int8_t zeros[256];               /* what the A operand's other K groups read */
     __shared__ __attribute__((aligned(16))) int32_t stg_in[2][4][64], stg_out[4][64];
     __shared__ __attribute__((aligned(16))) int8_t cst[4][SR_CST];           /* a row's coefficients while its registers are built */
+    __shared__ int8_t call[4][16];                                           /* NCH = 0: the layer's coefficients of each row (P <= 16 of them) */
     const uint32_t lane = threadIdx.x, i = lane & 15u, q = lane >> 4, S = p.S;
     const uint32_t nrows = p.F * p.C;
     uint32_t cf = 4u * blockIdx.x + q;
@@ -69,6 +70,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
     const uint32_t nchunk = (nmax + 63u) / 64u;
     for (uint32_t k = lane; k < 256u; k += 64u) { zeros[k] = 0; }
     for (uint32_t k = lane; k < 4u * SR_CST / 4u; k += 64u) ((uint32_t *)&cst[0][0])[k] = 0u;
+    if (!NCH) call[q][i] = (i < P && units) ? (int8_t)crec[i] : (int8_t)0;
     if (NCH) for (uint32_t k = lane; k < 4096u / 4u; k += 64u) ((uint32_t *)&ring[0][0][0])[k] = 0u;
     /* the A operand of lane l: row l & 15 = plane b of channel-frame qa, K group l >> 4: its own channel-frame's, or zeros */
     const int8_t *abase = (((lane & 15u) >> 2) == q) ? &ring[(lane & 15u) >> 2][lane & 3u][0] : &zeros[0];
@@ -138,6 +140,21 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             const bool same_unit = ((uint32_t)(bu >> (16u * q)) & 0xFFFFu) == 0u;
             const bool all_pred = (rb == 0xFFFFu) && same_unit, all_pass = (rb == 0u);
             gen = !(all_pred || all_pass);
+            if (!NCH) {
+                /* layers of <= 16 taps (a unit of np < 16 samples' start is a mixed block every time): the registers are built per
+                 * LANE from the layer's whole coefficient vector (unit u's at u np) -- every tap of a predicting lane lies in its own
+                 * unit (d <= np <= its place in the unit), so mixed rows run the steady code too */
+                gen = false;
+                const uint32_t cb0 = unit * np + np - i;         /* tap of distance d of my unit: call[cb0 + i - d] */
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int32_t da = (int32_t)i - j; const uint32_t db = 16u + i - (uint32_t)j;
+                    const bool va = pred && da >= 1 && (uint32_t)da <= np, vb = pred && db <= np;
+                    ccA[j] = va ? (int32_t)call[q][va ? cb0 + (uint32_t)j : 0u] : 0;
+                    ccB[j] = vb ? (int32_t)call[q][vb ? cb0 + (uint32_t)j - 16u : 0u] : 0;
+                }
+                half_l = pred ? half : 0u;
+            } else
             {   /* the coefficient registers of every row for the state it is in now (rows that keep theirs get the same values
                  * again); a mixed row: zeros, no state */
                 const bool bpred = pred && !gen;
@@ -180,15 +197,24 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             const uint32_t c = m >> 2, k = m & 3u;
             if (k == 0u && c + 1u < nchunk) { *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][4u * i] = pre; if (c + 2u < nchunk) pre = fetch(c + 2u); }
             const int32_t res = stg_in[c & 1u][q][16u * k + i];
-            const uint32_t mnext = window(m + 1u);              /* issued now, needed a block later */
             const uint32_t acc0 = half_l + mcur + nxt;
             uint32_t acc = acc0;
             nxt = 0;
-            /* speculation as in k_synth_pipe: every output of the block fits 24 bits -- one full-rate multiply-add per sum */
+            /* speculation as in k_synth_pipe: every output of the block fits 24 bits -- one full-rate multiply-add per sum.  The
+             * NEXT block's matrix-unit part rides between the steps, a chunk every two of them: each MFMA waits for the one before
+             * it (one accumulator), and a wave that issued the seven back to back stood still for their latencies */
+            lnn_v4i acc4 = { 0, 0, 0, 0 }, wa = { 0, 0, 0, 0 };
+            if (NCH) wa = *(const lnn_v4i *)(abase + ((16u * m - 16u) & 255u));
 #define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
                 acc += (uint32_t)__mul24(ccA[J], sv); asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nxt) : "v"(ccB[J]), "v"(sv)); }     /* (a multiply-add per tap: the compiler's tree of products and three-operand adds is half as many again) */
-            SR_STEPS(0)
+#define SR_WIN(CC_) if ((CC_) < NCH) { const lnn_v4i a_ = wa; \
+                if ((CC_) + 1 < NCH) wa = *(const lnn_v4i *)(abase + ((16u * m - 16u - 16u * (uint32_t)((CC_) + 1)) & 255u)); \
+                acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_, tz[(CC_) < NCH ? (CC_) : 0], acc4, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
+            SR_STEP(0, 0) SR_STEP(1, 0) SR_WIN(0) SR_STEP(2, 0) SR_STEP(3, 0) SR_WIN(1) SR_STEP(4, 0) SR_STEP(5, 0) SR_WIN(2) SR_STEP(6, 0) SR_STEP(7, 0) SR_WIN(3)
+            SR_STEP(8, 0) SR_STEP(9, 0) SR_WIN(4) SR_STEP(10, 0) SR_STEP(11, 0) SR_WIN(5) SR_STEP(12, 0) SR_STEP(13, 0) SR_WIN(6) SR_STEP(14, 0) SR_STEP(15, 0)
+#undef SR_WIN
 #undef SR_STEP
+            const uint32_t mnext = (uint32_t)acc4[0] + ((uint32_t)acc4[1] << 8) + ((uint32_t)acc4[2] << 16) + ((uint32_t)acc4[3] << 24);
             int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
             const bool fits = gen || (((int32_t)((uint32_t)yout << 8) >> 8) == yout);
             if (!__all(fits)) {
