@@ -746,7 +746,7 @@ def worker(args):
             avg_ms = kern_ms[dom] / launches
             # timed spans of one kind per chunk of frames: per-layer kernels have one span per layer they serve
             per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2),
-                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big}.get(dom, 1)
+                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big, 33: nlayers, 34: 1}.get(dom, 1)
             cf_per_launch = F * nch * args.steps / (launches / per_chunk)
             achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
             per_cf = (pmc.get(KERNEL_KINDS[dom]) or {}).get("hbm_bytes_per_channel_frame_per_launch")
@@ -763,10 +763,15 @@ def worker(args):
             roofline["whole_step_traffic_over_algorithmic"] = whole["encode_hbm_bytes_per_channel_frame"] / ALGO_BYTES_PER_CF
         roofline_decode = roof(DECODE_KINDS)
         if roofline_decode:
-            roofline_decode["note"] = ("algorithmic bytes = 82552 B per channel-frame (residual in, PCM out, parameters); the synthesis is one dependent "
-                                       "recurrence per channel-frame: latency bound")
+            roofline_decode["note"] = ("algorithmic bytes = 82552 B per channel-frame (residual in, PCM out, parameters) per launch: a layer of the cascade "
+                                       "streams the channel-frame in and out once; k_synth_rows is bound by the vector unit's issue rate (a dependent "
+                                       "recurrence per channel-frame, four channel-frames per wave), not by HBM")
             if whole.get("decode_hbm_bytes_per_channel_frame"):
                 roofline_decode["whole_step_traffic_per_channel_frame"] = whole["decode_hbm_bytes_per_channel_frame"]
+            # the whole decode step against the same peak: the cascade's layers are launches of their own (each streams the
+            # channel-frame in and out once), so the step moves the algorithmic bytes once in nlayers + 1 passes
+            roofline_decode["whole_step_achieved"] = ALGO_BYTES_PER_CF * F * nch / (dec_s / args.steps) / 1e9
+            roofline_decode["whole_step_frac"] = roofline_decode["whole_step_achieved"] / HBM_PEAK_GBS
         cf_per_s = enc_fps * nch / world        # per GPU
         valu = {"executed_tflops": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12, "reference_equiv_tflops": 2 * MAC_PER_CF_REFERENCE * cf_per_s / 1e12,
                 "peak_fma_tflops": FP64_PEAK_TFLOPS, "frac_of_unfused_peak": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / (FP64_PEAK_TFLOPS / 2),

@@ -988,7 +988,10 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
          * above all -- take the pipelined latency form (k_synth_pipe: a wave per stage of the cascade, 16-sample blocks) when the
          * frame fits its LDS image; k_synthesize is its fallback for longer frames */
         const bool pipe_fits = SP_LDS_BYTES(p.S) <= LEV_LDS_BUDGET;
-        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < 6144u ? 3 : 0);
+        /* (tools/decode_crossover.py: the pipelined form costs 0.85 ms per 1024 channel-frames, the throughput form 1.7 ms up to ~4000 and
+         * 0.17 per 1024 beyond: they cross at 2048; the lanes form the throughput form falls back to, 5.1 ms whatever the batch: at 6144) */
+        const bool rows_fit = (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u;
+        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < (rows_fit ? 2048u : 6144u) ? 3 : 0);
         const bool use_pipe = (form == 3) && pipe_fits, use_wave = (form == 1) || (form == 3 && !pipe_fits);
         /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows, 34 = k_deemph_lr */
         if (use_pipe) { const int sp_ = span_begin(ctx, 32, ctx->stream); hipLaunchKernelGGL(k_synth_pipe, dim3(CF), dim3(64 * (hs.L + 1)), SP_LDS_BYTES(p.S), ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
@@ -998,7 +1001,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
             /* k_synth_rows (four channel-frames per wave, the old taps on the matrix unit) takes the layers without de-emphasis whose
              * order is a preset's, when the samples can travel as 16-byte groups (LINNE_AMD_DECODE_KERNEL=lanes: none) */
             const int nch = hs.P[l] <= 16u ? 0 : (hs.P[l] == 32u ? 1 : (hs.P[l] == 64u ? 3 : (hs.P[l] == 128u ? 7 : -1)));
-            if (nch >= 0 && form != 2 && (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u) {
+            if (nch >= 0 && form != 2 && rows_fit) {
                 const int sp_ = span_begin(ctx, 33, ctx->stream);
                 const dim3 grows((CF + 3) / 4);
                 switch (nch) {
