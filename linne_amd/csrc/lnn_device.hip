@@ -1013,8 +1013,8 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 span_end(ctx, sp_, ctx->stream);
                 if (de) {       /* the de-emphasis behind layer 0 (lanes = channel-frames), MS -> LR on its way out when a block of 64 rows holds whole frames */
                     const int sd_ = span_begin(ctx, 34, ctx->stream);
-                    if (p.ms && p.C >= 2u && p.C <= 64u && (p.C & (p.C - 1u)) == 0u) { hipLaunchKernelGGL((k_deemph_lr<true>), dim3(gsmall), dim3(256), 0, ctx->stream, p); ms_done = true; }
-                    else hipLaunchKernelGGL((k_deemph_lr<false>), dim3(gsmall), dim3(256), 0, ctx->stream, p);
+                    if (p.ms && p.C >= 2u && p.C <= 64u && (p.C & (p.C - 1u)) == 0u) { hipLaunchKernelGGL((k_deemph_lr<true>), dim3(gsmall), dim3(64 * (2 + DL_STORERS)), 0, ctx->stream, p); ms_done = true; }
+                    else hipLaunchKernelGGL((k_deemph_lr<false>), dim3(gsmall), dim3(64 * (2 + DL_STORERS)), 0, ctx->stream, p);
                     span_end(ctx, sd_, ctx->stream);
                 }
                 continue;

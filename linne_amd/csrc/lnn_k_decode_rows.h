@@ -282,12 +282,13 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
  * recurrence per channel-frame, with lanes = channel-frames, and MS -> LR (linne_utility.c:135-147) on the way out when the frames
  * of a block of 64 rows are whole (FUSE_MS: C a power of two <= 64; k_ms_to_lr otherwise).  Tiles of 64 rows x 64 samples go through
  * LDS; a load or store instruction moves 16 bytes per lane = 256 bytes of four rows (16 instructions per tile and direction).
- * A wave alone on its SIMD issues an instruction every ~9 cycles, so a pass costs what ONE wave executes per tile: the block is four
+ * A wave alone on its SIMD issues an instruction every ~9 cycles, so a pass costs what ONE wave executes per tile: the block is six
  * waves with a role each -- wave 0 requests tile t + 2 and writes tile t + 1 into LDS, wave 1 runs the recurrences over tile t (the
- * only serial part: 64 steps of eight instructions), waves 2 and 3 turn tile t - 1 into left / right and store it, half the rows
+ * only serial part: 64 steps of eight instructions), waves 2 .. 5 turn tile t - 1 into left / right and store it, a quarter of the rows
  * each -- three tile buffers, a barrier per tile. */
 template <bool FUSE_MS>
-__global__ __launch_bounds__(256) void k_deemph_lr(DecPlan p)
+#define DL_STORERS 4       /* waves that store (2 + DL_STORERS waves per block) */
+__global__ __launch_bounds__(64 * (2 + DL_STORERS)) void k_deemph_lr(DecPlan p)
 {
     __shared__ int32_t tile[3][64][65];                           /* [tile mod 3][row][sample]: bank = row + sample, no conflicts either way */
     const uint32_t lane = threadIdx.x & 63u, row0 = blockIdx.x * 64u, S = p.S, C = p.C;
@@ -340,12 +341,12 @@ __global__ __launch_bounds__(256) void k_deemph_lr(DecPlan p)
                     tl[lane][s] = y;
                 }
             }
-        } else if (t >= 1u) {                                      /* (two waves: eight of the sixteen row groups each) */
+        } else if (t >= 1u) {                                      /* (DL_STORERS waves: their share of the sixteen row groups each) */
             const uint32_t to = t - 1u, s0 = to * 64u + i4;
             int32_t (*tl)[65] = tile[to % 3u];
 #pragma unroll
-            for (int kk = 0; kk < 8; kk++) {
-                const uint32_t r = 4u * ((uint32_t)kk + 8u * (role - 2u)) + rq;
+            for (int kk = 0; kk < 16 / DL_STORERS; kk++) {
+                const uint32_t r = 4u * ((uint32_t)kk + (uint32_t)(16 / DL_STORERS) * (role - 2u)) + rq;
                 const int32_t *w = &tl[r][i4];
                 lnn_v4i v = { w[0], w[1], w[2], w[3] };
                 if (FUSE_MS) {                                    /* row0 is a multiple of C: channels 0 and 1 of a frame are neighbouring rows of this block */
