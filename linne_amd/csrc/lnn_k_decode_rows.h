@@ -282,12 +282,12 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
  * recurrence per channel-frame, with lanes = channel-frames, and MS -> LR (linne_utility.c:135-147) on the way out when the frames
  * of a block of 64 rows are whole (FUSE_MS: C a power of two <= 64; k_ms_to_lr otherwise).  Tiles of 64 rows x 64 samples go through
  * LDS; a load or store instruction moves 16 bytes per lane = 256 bytes of four rows (16 instructions per tile and direction).
- * A wave alone on its SIMD issues an instruction every ~9 cycles, so a pass costs what ONE wave executes per tile: the block is six
+ * A wave alone on its SIMD issues an instruction every ~9 cycles, so a pass costs what ONE wave executes per tile: the block is four
  * waves with a role each -- wave 0 requests tile t + 2 and writes tile t + 1 into LDS, wave 1 runs the recurrences over tile t (the
- * only serial part: 64 steps of eight instructions), waves 2 .. 5 turn tile t - 1 into left / right and store it, a quarter of the rows
+ * only serial part: 64 steps of eight instructions), waves 2 and 3 turn tile t - 1 into left / right and store it, half the rows
  * each -- three tile buffers, a barrier per tile. */
 template <bool FUSE_MS>
-#define DL_STORERS 4       /* waves that store (2 + DL_STORERS waves per block) */
+#define DL_STORERS 2       /* waves that store (2 + DL_STORERS waves per block) */
 __global__ __launch_bounds__(64 * (2 + DL_STORERS)) void k_deemph_lr(DecPlan p)
 {
     __shared__ int32_t tile[3][64][65];                           /* [tile mod 3][row][sample]: bank = row + sample, no conflicts either way */
