@@ -973,7 +973,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
     DecPlan p; memset(&p, 0, sizeof(p));
     p.C = shape->num_channels; p.S = shape->num_samples_per_block; p.L = hs.L; p.ms = shape->ch_process_method; p.F = num_frames;
     for (uint32_t l = 0; l < hs.L; l++) { p.P[l] = hs.P[l]; p.coef_off[l] = hs.coef_off[l]; }
-    p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp; p.dbg = ctx->knob.dbg_maxtr;
+    p.data = d_data; p.prm = d_params; p.nsmp = ctx->d_nsmp;
     ctx->nspans = 0;
     bool ms_done = false;
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }

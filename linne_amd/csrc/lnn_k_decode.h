@@ -10,7 +10,6 @@ struct DecPlan {
     uint32_t C, S, L, ms, F;
     uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];
     int32_t *data; const int32_t *prm; const uint32_t *nsmp;
-    uint32_t dbg;
 };
 
 /* wrap-around sum of one int per lane over the 64-lane wavefront (associative, so a DPP tree is exact) */
