@@ -310,6 +310,34 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
         assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f}"
 
 
+@pytest.mark.parametrize("kernel", ["rows", "lanes", "pipe"])
+@pytest.mark.parametrize("nch,bits,block,preset,F", [(2, 16, 2048, 7, 37), (3, 24, 1024, 4, 23), (1, 16, 4096, 5, 70), (8, 16, 1024, 7, 9)])
+def test_decode_forms_with_frames_of_many_lengths_in_one_batch(ctx, monkeypatch, kernel, nch, bits, block, preset, F):
+    """a batch as many tracks back to back make it: frames of a dozen lengths in any order (so the four channel-frames of a
+    k_synth_rows wave, the 64 rows of a k_deemph_lr / k_synth_small block and the rows of its last, partial block end in
+    different places, unit boundaries fall inside the 16-sample blocks, and the shortest frames are shorter than a layer's
+    order); the decode must restore every frame's own samples and leave what lies behind them alone"""
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", kernel)
+    rng = np.random.default_rng(99 + F)
+    ms = nch >= 2
+    frames = music_frames(F, nch, block, bits, seed=5 + nch)
+    pool = np.concatenate([[block, 1, 129, block - 3, 17, block // 2 + 1], rng.integers(1, block + 1, size=6)])     # (an encode call takes up to 16 distinct lengths)
+    ns = rng.choice(pool, size=F).astype(np.uint32)
+    ns[:6] = pool[:6]
+    for f in range(F):
+        frames[f, :, int(ns[f]):] = 0
+    shape = ctx.shape(nch, bits, block, preset, ms)
+    res, prm, st = ctx.encode_frames_host(shape, frames, ns)
+    marked = res.copy()
+    for f in range(F):
+        marked[f, :, int(ns[f]):] = -123456                      # what lies behind a frame's end is nobody's data: it must stay
+    dec = ctx.decode_frames_host(shape, marked, prm, ns)
+    for f in range(F):
+        n = int(ns[f])
+        assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f} (n = {n})"
+        assert np.all(dec[f, :, n:] == -123456), f"frame {f}: samples behind its end were written"
+
+
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("LINNE_FUZZ_SEEDS", "16"))))
 def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, seed):
     """randomised sweep over what the API accepts: channels, bit depth, preset, block size (even or odd), MS on/off, stream length
