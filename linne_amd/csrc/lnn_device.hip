@@ -85,7 +85,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -276,6 +276,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
+    ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", 1);
     { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : (strcmp(e, "rows") == 0 ? 4 : 2))); }
     ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
 }
@@ -1005,7 +1006,12 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 const int sp_ = span_begin(ctx, 33, ctx->stream);
                 const dim3 grows((CF + 3) / 4);
                 switch (nch) {
-                case 0: hipLaunchKernelGGL((k_synth_rows<0>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
+                case 0:     /* (LINNE_AMD_DECODE_ROWS8=0: the four-channel-frame form for these layers too) */
+                        if (!ctx->knob.rows8) { if (hs.P[l] <= 4u) hipLaunchKernelGGL((k_synth_rows<0, 4>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_rows<0>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); }
+                        else if (hs.P[l] <= 4u) hipLaunchKernelGGL((k_synth_rows8<4>), dim3((CF + 7) / 8), dim3(64), 0, ctx->stream, p, (uint32_t)l);
+                        else if (hs.P[l] <= 8u) hipLaunchKernelGGL((k_synth_rows8<8>), dim3((CF + 7) / 8), dim3(64), 0, ctx->stream, p, (uint32_t)l);
+                        else hipLaunchKernelGGL((k_synth_rows8<16>), dim3((CF + 7) / 8), dim3(64), 0, ctx->stream, p, (uint32_t)l);
+                        break;
                 case 1: hipLaunchKernelGGL((k_synth_rows<1>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
                 case 3: hipLaunchKernelGGL((k_synth_rows<3>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;
                 default: hipLaunchKernelGGL((k_synth_rows<7>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); break;

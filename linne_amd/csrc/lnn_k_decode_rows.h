@@ -41,12 +41,14 @@ __device__ __forceinline__ uint32_t row_sum_all(uint32_t v)      /* wrap-around 
 
 #define SR_PAD 160u      /* zeros in front of the staged coefficients: distances up to 128 + 16 + 15 beyond np */
 #define SR_CST 320u      /* SR_PAD + 128 coefficients + 16 zeros (distances <= 0), rounded */
-template <int NCH>      /* 16-sample chunks of older history on the matrix unit: 0 for layers of <= 16 taps, 1 for 32, 3 for 64, 7 for 128 */
+template <int NCH, int PB = 16>      /* NCH: 16-sample chunks of older history on the matrix unit: 0 for layers of <= 16 taps, 1 for 32, 3 for 64, 7
+                                       * for 128.  PB: the layer's order if it is below 16, else 16: output j of a block reaches the next block's sums
+                                       * only from distance 16 + i - j <= PB, i.e. j >= 16 - PB -- the other steps leave that multiply-add out */
 __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p, uint32_t layer)
 {
     __shared__ __attribute__((aligned(16))) int8_t ring[4][4][256];          /* [channel-frame][digit plane][sample mod 256] */
     __shared__ __attribute__((aligned(16))) int8_t zeros[256];               /* what the A operand's other K groups read */
-    __shared__ __attribute__((aligned(16))) int32_t stg_in[2][4][64], stg_out[4][64];
+    __shared__ __attribute__((aligned(16))) int32_t stg_in[2][4][80], stg_out[4][80];    /* (rows 16 words apart modulo the 64 banks: the four rows' reads of a block do not collide) */
     __shared__ __attribute__((aligned(16))) int8_t cst[4][SR_CST];           /* a row's coefficients while its registers are built */
     __shared__ int8_t call[4][16];                                           /* NCH = 0: the layer's coefficients of each row (P <= 16 of them) */
     const uint32_t lane = threadIdx.x, i = lane & 15u, q = lane >> 4, S = p.S;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             /* what the previous block adds to this one's sums, and the matrix-unit part, with the registers as they are now
              * (rows that kept their state get the values they had: the sums are associative) */
             nxt = 0;
-#define SR_STEP(J, MUL_) { const int32_t sv = row_bcast<J>(yprev); nxt += sp_mul8(ccB[J], sv & 0xFFFF, sv >> 16); }
+#define SR_STEP(J, MUL_) if ((J) >= 16 - PB) { const int32_t sv = row_bcast<J>(yprev); nxt += sp_mul8(ccB[J], sv & 0xFFFF, sv >> 16); }
             SR_STEPS(0)
 #undef SR_STEP
             mcur = window(m);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             lnn_v4i acc4 = { 0, 0, 0, 0 }, wa = { 0, 0, 0, 0 };
             if (NCH) wa = *(const lnn_v4i *)(abase + ((16u * m - 16u) & 255u));
 #define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
-                acc += (uint32_t)__mul24(ccA[J], sv); asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nxt) : "v"(ccB[J]), "v"(sv)); }     /* (a multiply-add per tap: the compiler's tree of products and three-operand adds is half as many again) */
+                acc += (uint32_t)__mul24(ccA[J], sv); if ((J) >= 16 - PB) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nxt) : "v"(ccB[J]), "v"(sv)); }     /* (a multiply-add per tap: the compiler's tree of products and three-operand adds is half as many again) */
 #define SR_WIN(CC_) if ((CC_) < NCH) { const lnn_v4i a_ = wa; \
                 if ((CC_) + 1 < NCH) wa = *(const lnn_v4i *)(abase + ((16u * m - 16u - 16u * (uint32_t)((CC_) + 1)) & 255u)); \
                 acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_, tz[(CC_) < NCH ? (CC_) : 0], acc4, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             if (!__all(fits)) {
                 acc = acc0; nxt = 0;
 #define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
-                const int32_t sl = sv & 0xFFFF, shh = sv >> 16; acc += sp_mul8(ccA[J], sl, shh); nxt += sp_mul8(ccB[J], sl, shh); }
+                const int32_t sl = sv & 0xFFFF, shh = sv >> 16; acc += sp_mul8(ccA[J], sl, shh); if ((J) >= 16 - PB) nxt += sp_mul8(ccB[J], sl, shh); }
                 SR_STEPS(0)
 #undef SR_STEP
                 yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
@@ -277,6 +279,148 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
         } while (m < nblk && __all(m < m_event));
     }
 }
+
+/* k_synth_rows8<PB>: k_synth_rows for the layers of <= 16 taps with EIGHT channel-frames per wave, one per half of a DPP row, in
+ * blocks of 8 outputs (lane i of a half = sample 8 m + i): a step's five to seven instructions -- shift, subtract, TWO broadcasts
+ * (row_newbcast:j into the whole row, row_newbcast:8+j over its upper half: bank mask 0xc), the multiply-add into this block's sum,
+ * the ones into the next block's (distances 8 + i - j) and, for orders above 8, the block after that (16 + i - j) -- serve eight
+ * channel-frames, not four.  No matrix unit, no generic routine: every lane's coefficient registers are built from its own (unit,
+ * predicting or not), as in k_synth_rows<0>.  PB = 4 / 8 / 16 bounds the layer's order: taps that cannot exist are left out. */
+template <int J> __device__ __forceinline__ int32_t half_bcast(int32_t v)
+{
+    const int32_t lo = __builtin_amdgcn_update_dpp(0, v, 0x150 + J, 0xf, 0xf, true);         /* lane J of the row -> all of it */
+    return __builtin_amdgcn_update_dpp(lo, v, 0x150 + 8 + J, 0xf, 0xc, false);               /* lane 8 + J -> lanes 8 .. 15 */
+}
+#define SR8_STEPS SR8_STEP(0) SR8_STEP(1) SR8_STEP(2) SR8_STEP(3) SR8_STEP(4) SR8_STEP(5) SR8_STEP(6) SR8_STEP(7)
+template <int PB>
+__global__ __launch_bounds__(64, 4) void k_synth_rows8(DecPlan p, uint32_t layer)
+{
+    constexpr bool FAR = PB > 8;                                   /* taps beyond distance 8 + i: the block before the previous one */
+    constexpr int JB = (PB >= 8) ? 0 : 8 - PB;                    /* first step whose output reaches the next block (8 + i - j <= PB) */
+    __shared__ __attribute__((aligned(16))) int32_t stg_in[2][8][72], stg_out[8][72];    /* (rows 8 words apart modulo the 64 banks) */
+    __shared__ int8_t call[8][16];                                 /* the layer's coefficients of each channel-frame (unit u's at u np) */
+    const uint32_t lane = threadIdx.x, i = lane & 7u, q = lane >> 3, S = p.S;
+    const uint32_t nrows = p.F * p.C;
+    uint32_t cf = 8u * blockIdx.x + q;
+    const bool have = cf < nrows;
+    if (!have) cf = nrows - 1u;
+    const uint32_t n = have ? p.nsmp[cf / p.C] : 0u;
+    const int32_t *rec = p.prm + (size_t)cf * LINNE_AMD_PARAM_WORDS;
+    int32_t *g = p.data + (size_t)cf * S;
+    const uint32_t P = p.P[layer];
+    const uint32_t units = (uint32_t)rec[LINNE_AMD_PRM_UNITS + layer], rs = (uint32_t)rec[LINNE_AMD_PRM_RSHIFT + layer];
+    const uint32_t np = units ? P / units : 0u, ns = units ? n / units : 0u;
+    const bool skip = (units == 0 || np == 0 || ns < np);          /* linne_decoder.c: such a layer leaves the data unchanged */
+    const uint32_t half = 1u << ((rs - 1u) & 31u), sh_ = rs & 31u;
+    const int32_t *crec = rec + LINNE_AMD_PRM_COEF + p.coef_off[layer];
+    uint32_t nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t other = (uint32_t)__shfl_xor((int)nmax, o); nmax = other > nmax ? other : nmax; }
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
+    const uint32_t nchunk = (nmax + 63u) / 64u, nblk = (nmax + 7u) / 8u;
+    call[q][i] = (i < P && units) ? (int8_t)crec[i] : (int8_t)0;
+    call[q][i + 8u] = (i + 8u < P && units) ? (int8_t)crec[i + 8u] : (int8_t)0;
+
+    uint32_t unit = 0, m_event = 0u, half_l = 0u;
+    bool pred = false;
+    int32_t ccA[8], ccB[8], ccC[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { ccA[j] = 0; ccB[j] = 0; ccC[j] = 0; }
+    int32_t yprev = 0, yprev2 = 0;
+    uint32_t accB = 0, accC = 0, ncp = 0;                          /* what the previous block / the one before it add to this block; what the previous block adds to the next */
+
+    /* 64-sample chunks, 32 bytes per lane: chunk c + 1 is requested while chunk c is worked on */
+    auto fetch = [&](uint32_t c, lnn_v4i &v0, lnn_v4i &v1) {
+        const uint32_t s0 = 64u * c + 8u * i;
+        v0 = lnn_v4i{ 0, 0, 0, 0 }; v1 = lnn_v4i{ 0, 0, 0, 0 };
+        if (s0 + 3u < S) v0 = *(const lnn_v4i *)(g + s0);           /* (S is a multiple of 4: a group of four is whole or absent) */
+        if (s0 + 7u < S) v1 = *(const lnn_v4i *)(g + s0 + 4u);
+    };
+    lnn_v4i pre0 = { 0, 0, 0, 0 }, pre1 = { 0, 0, 0, 0 };
+    if (nchunk) { fetch(0, pre0, pre1); *(lnn_v4i *)&stg_in[0][q][8u * i] = pre0; *(lnn_v4i *)&stg_in[0][q][8u * i + 4u] = pre1; }
+    if (nchunk > 1u) fetch(1, pre0, pre1);
+
+    uint32_t m = 0;
+#pragma unroll 1
+    while (m < nblk) {
+        {   /* a lane's class changes here: every lane's class in this block, for how many blocks it keeps it, its registers */
+            const uint32_t t = 8u * m + i;
+            unit = skip ? units : t / (ns ? ns : 1u);
+            uint32_t ahead = 0xFFFFFFFFu;                          /* behind the last unit (or a skipped layer): copied to the end */
+            pred = false;
+            if (unit < units) {
+                const uint32_t tl = t - unit * ns;
+                pred = tl >= np;
+                ahead = ((pred ? ns : np) - tl + 7u) / 8u;
+            }
+            m_event = (ahead == 0xFFFFFFFFu) ? ahead : m + ahead;
+            const uint32_t cb0 = unit * np + np - i;               /* tap of distance d of my unit: call[cb0 + i - d]; all of them lie in the unit (d <= np <= my place in it) */
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int32_t da = (int32_t)i - j; const uint32_t db = 8u + i - (uint32_t)j, dc = 16u + i - (uint32_t)j;
+                const bool va = pred && da >= 1 && (uint32_t)da <= np, vb = pred && db <= np, vc = FAR && pred && dc <= np;
+                ccA[j] = va ? (int32_t)call[q][va ? cb0 + (uint32_t)j : 0u] : 0;
+                ccB[j] = vb ? (int32_t)call[q][vb ? cb0 + (uint32_t)j - 8u : 0u] : 0;
+                ccC[j] = vc ? (int32_t)call[q][vc ? cb0 + (uint32_t)j - 16u : 0u] : 0;
+            }
+            half_l = pred ? half : 0u;
+            /* what the blocks before add, with the registers as they are now (lanes that kept their class get the values they had) */
+            accB = 0; accC = 0; ncp = 0;
+#define SR8_STEP(J) { const int32_t sv = half_bcast<J>(yprev); const int32_t sl = sv & 0xFFFF, shh = sv >> 16; \
+                if ((J) >= JB) accB += sp_mul8(ccB[J], sl, shh); if (FAR) ncp += sp_mul8(ccC[J], sl, shh); \
+                if (FAR) { const int32_t s2 = half_bcast<J>(yprev2); accC += sp_mul8(ccC[J], s2 & 0xFFFF, s2 >> 16); } }
+            SR8_STEPS
+#undef SR8_STEP
+        }
+#pragma unroll 1
+        do {
+            const uint32_t c = m >> 3, k = m & 7u;
+            if (k == 0u && c + 1u < nchunk) {
+                *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][8u * i] = pre0; *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][8u * i + 4u] = pre1;
+                if (c + 2u < nchunk) fetch(c + 2u, pre0, pre1);
+            }
+            const int32_t res = stg_in[c & 1u][q][8u * k + i];
+            const uint32_t acc0 = half_l + accB + accC;
+            uint32_t acc = acc0, nb = 0, nc = 0;
+            /* speculation as in k_synth_rows: every output of the block fits 24 bits */
+#define SR8_STEP(J) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = half_bcast<J>(y); \
+                acc += (uint32_t)__mul24(ccA[J], sv); \
+                if ((J) >= JB) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nb) : "v"(ccB[J]), "v"(sv)); \
+                if (FAR) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nc) : "v"(ccC[J]), "v"(sv)); }
+            SR8_STEPS
+#undef SR8_STEP
+            int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+            const bool fits = (((int32_t)((uint32_t)yout << 8) >> 8) == yout);
+            if (!__all(fits)) {
+                acc = acc0; nb = 0; nc = 0;
+#define SR8_STEP(J) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = half_bcast<J>(y); \
+                const int32_t sl = sv & 0xFFFF, shh = sv >> 16; acc += sp_mul8(ccA[J], sl, shh); \
+                if ((J) >= JB) nb += sp_mul8(ccB[J], sl, shh); if (FAR) nc += sp_mul8(ccC[J], sl, shh); }
+                SR8_STEPS
+#undef SR8_STEP
+                yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
+            }
+            stg_out[q][8u * k + i] = yout;
+            yprev2 = yprev; yprev = yout;
+            accB = nb; accC = ncp; ncp = nc;
+            m++;
+            if (k == 7u || m == nblk) {
+                /* the chunk's outputs: 32 bytes per lane; nothing behind a frame's end is written */
+                const uint32_t s0 = 64u * c + 8u * i;
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t sh0 = s0 + 4u * (uint32_t)h;
+                    const lnn_v4i v = *(const lnn_v4i *)&stg_out[q][8u * i + 4u * (uint32_t)h];
+                    if (have) {
+                        if (sh0 + 3u < n) *(lnn_v4i *)(g + sh0) = v;
+                        else { if (sh0 < n) g[sh0] = v[0]; if (sh0 + 1u < n) g[sh0 + 1u] = v[1]; if (sh0 + 2u < n) g[sh0 + 2u] = v[2]; }
+                    }
+                }
+            }
+        } while (m < nblk && __all(m < m_event));
+    }
+}
+#undef SR8_STEPS
 
 /* k_deemph_lr: what follows layer 0 when k_synth_rows took it -- the two-stage de-emphasis (linne_utility.c:215-241), a scalar
  * recurrence per channel-frame, with lanes = channel-frames, and MS -> LR (linne_utility.c:135-147) on the way out when the frames
