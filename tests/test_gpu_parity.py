@@ -289,13 +289,16 @@ def test_own_cli_matches_the_reference_cli(tmp_path):
         assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4"])
 @pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
 def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
     """DecodeFramesDevice picks its kernels by batch size (one wave per channel-frame for small batches; lanes =
     channel-frames / four lanes per channel-frame for large ones, whose int32 dot products run in FP64).  Both forms must
-    restore the input exactly and agree with the oracle's synthesis, on every preset family, ragged tails included."""
-    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", kernel)
+    restore the input exactly and agree with the oracle's synthesis, on every preset family, ragged tails included.
+    (`rows4`: the throughput form with four channel-frames per wave for the short layers too; `rows` takes eight there.)"""
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel == "rows4" else kernel)
+    if kernel == "rows4":
+        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "0")
     ms = nch >= 2
     F = 5
     frames = music_frames(F, nch, block, bits, seed=77 + nch + preset)
@@ -310,14 +313,16 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
         assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f}"
 
 
-@pytest.mark.parametrize("kernel", ["rows", "lanes", "pipe"])
+@pytest.mark.parametrize("kernel", ["rows", "rows4", "lanes", "pipe"])
 @pytest.mark.parametrize("nch,bits,block,preset,F", [(2, 16, 2048, 7, 37), (3, 24, 1024, 4, 23), (1, 16, 4096, 5, 70), (8, 16, 1024, 7, 9)])
 def test_decode_forms_with_frames_of_many_lengths_in_one_batch(ctx, monkeypatch, kernel, nch, bits, block, preset, F):
     """a batch as many tracks back to back make it: frames of a dozen lengths in any order (so the four channel-frames of a
     k_synth_rows wave, the 64 rows of a k_deemph_lr / k_synth_small block and the rows of its last, partial block end in
     different places, unit boundaries fall inside the 16-sample blocks, and the shortest frames are shorter than a layer's
     order); the decode must restore every frame's own samples and leave what lies behind them alone"""
-    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", kernel)
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel == "rows4" else kernel)
+    if kernel == "rows4":
+        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "0")
     rng = np.random.default_rng(99 + F)
     ms = nch >= 2
     frames = music_frames(F, nch, block, bits, seed=5 + nch)

@@ -99,7 +99,7 @@ def kinds_that_ran(c, kinds):
 def test_large_batch_picks_the_lanes_kernels_by_itself(oracle, big):
     """3200 stereo frames + tail in ONE chunk: k_autocorr_hist<128,0/1>, k_autocorr_sub, autocorr_rows, k_fwd_loss,
     k_synth_small/big are what the batch-size rules select; nothing is forced"""
-    for v in ("LINNE_AMD_HIST", "LINNE_AMD_FWD_LOSS", "LINNE_AMD_ROWS16", "LINNE_AMD_L0_PRODUCTS", "LINNE_AMD_DECODE_KERNEL", "LINNE_AMD_SORT"):
+    for v in ("LINNE_AMD_HIST", "LINNE_AMD_FWD_LOSS", "LINNE_AMD_ROWS16", "LINNE_AMD_L0_PRODUCTS", "LINNE_AMD_DECODE_KERNEL", "LINNE_AMD_DECODE_ROWS8", "LINNE_AMD_SORT"):
         assert v not in os.environ
     c = linne_amd.Context(0, scratch_bytes=8 << 30, use_torch_stream=False)
     try:
