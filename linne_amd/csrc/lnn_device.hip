@@ -276,7 +276,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
-    ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", 1);
+    ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", -1);
     { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : (strcmp(e, "rows") == 0 ? 4 : 2))); }
     ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
 }
@@ -989,10 +989,10 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
          * above all -- take the pipelined latency form (k_synth_pipe: a wave per stage of the cascade, 16-sample blocks) when the
          * frame fits its LDS image; k_synthesize is its fallback for longer frames */
         const bool pipe_fits = SP_LDS_BYTES(p.S) <= LEV_LDS_BUDGET;
-        /* (tools/decode_crossover.py: the pipelined form costs 0.85 ms per 1024 channel-frames, the throughput form 1.7 ms up to ~4000 and
-         * 0.17 per 1024 beyond: they cross at 2048; the lanes form the throughput form falls back to, 5.1 ms whatever the batch: at 6144) */
+        /* (tools/decode_crossover.py: the pipelined form costs 0.85 ms per 1024 channel-frames, the throughput form 1.25 ms up to ~4000 and
+         * 0.12 per 1024 beyond: they cross at 1536; the lanes form the throughput form falls back to, 5.1 ms whatever the batch: at 6144) */
         const bool rows_fit = (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u;
-        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < (rows_fit ? 2048u : 6144u) ? 3 : 0);
+        const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < (rows_fit ? 1536u : 6144u) ? 3 : 0);
         const bool use_pipe = (form == 3) && pipe_fits, use_wave = (form == 1) || (form == 3 && !pipe_fits);
         /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows, 34 = k_deemph_lr */
         if (use_pipe) { const int sp_ = span_begin(ctx, 32, ctx->stream); hipLaunchKernelGGL(k_synth_pipe, dim3(CF), dim3(64 * (hs.L + 1)), SP_LDS_BYTES(p.S), ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
@@ -1006,8 +1006,8 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 const int sp_ = span_begin(ctx, 33, ctx->stream);
                 const dim3 grows((CF + 3) / 4);
                 switch (nch) {
-                case 0:     /* (LINNE_AMD_DECODE_ROWS8=0: the four-channel-frame form for these layers too) */
-                        if (!ctx->knob.rows8) { if (hs.P[l] <= 4u) hipLaunchKernelGGL((k_synth_rows<0, 4>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_rows<0>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); }
+                case 0:     /* (LINNE_AMD_DECODE_ROWS8=0 / 1: the four- / eight-channel-frame form whatever the batch) */
+                        if (!(ctx->knob.rows8 < 0 ? CF >= 20480u : ctx->knob.rows8 != 0)) {     /* (eight per wave are twice the blocks per wave: they pay once the four-per-wave form fills the SIMDs, tools/decode_crossover.py) */ if (hs.P[l] <= 4u) hipLaunchKernelGGL((k_synth_rows<0, 4>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); else hipLaunchKernelGGL((k_synth_rows<0>), grows, dim3(64), 0, ctx->stream, p, (uint32_t)l); }
                         else if (hs.P[l] <= 4u) hipLaunchKernelGGL((k_synth_rows8<4>), dim3((CF + 7) / 8), dim3(64), 0, ctx->stream, p, (uint32_t)l);
                         else if (hs.P[l] <= 8u) hipLaunchKernelGGL((k_synth_rows8<8>), dim3((CF + 7) / 8), dim3(64), 0, ctx->stream, p, (uint32_t)l);
                         else hipLaunchKernelGGL((k_synth_rows8<16>), dim3((CF + 7) / 8), dim3(64), 0, ctx->stream, p, (uint32_t)l);
