@@ -65,7 +65,7 @@ KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocor
                 11: "k_synthesize (one wave per channel-frame, all layers)", 12: "k_ms_to_lr",
                 30: "k_synth_big<P> (synthesis of the long layer)", 31: "k_synth_small<P> (synthesis of the short layers, de-emphasis)",
                 32: "k_synth_pipe (a wave per stage of the cascade, 16-sample blocks: the latency form)",
-                33: "k_synth_rows<NCH> (four channel-frames per wave, the old taps on the matrix unit: the throughput form)",
+                33: "k_synth_rows<NCH> / k_synth_rows8<PB> (four / eight channel-frames per wave, the old taps on the matrix unit: the throughput form)",
                 34: "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out)"}
 
 

@@ -11,7 +11,7 @@ KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the s
         ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_fwd_loss", "k_fwd_loss<P> (last layer: forward pass + ordered loss)"),
         ("k_fir2<1, true", "k_fir2<1,true,*> (forward of layer 0, jobs with several units)"),
         ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"), ("k_quantize", "k_finalize"), ("k_fir_cascade", "k_finalize"),
-        ("k_synth_rows", "k_synth_rows<NCH> (four channel-frames per wave, the old taps on the matrix unit: the throughput form)"), ("k_deemph_lr", "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out)"),
+        ("k_synth_rows", "k_synth_rows<NCH> / k_synth_rows8<PB> (four / eight channel-frames per wave, the old taps on the matrix unit: the throughput form)"), ("k_deemph_lr", "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out)"),
         ("k_synth_big", "k_synth_big<P> (synthesis of the long layer)"), ("k_synth_small", "k_synth_small<P> (synthesis of the short layers, de-emphasis)"),
         ("k_synthesize", "k_synthesize (one wave per channel-frame, all layers)"), ("k_ms_to_lr", "k_ms_to_lr"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan"), ("k_rice_emit", "k_rice_emit")]
 def load(path, counter):
