@@ -264,8 +264,8 @@ int LINNEAmd_Synchronize(struct LINNEAmdContext *ctx);
  * replace 3 for the frames they take), 24 Rice scan + emission, 25 the long layer's search in one window pass (k_search_long;
  * replaces 5 for the frames it takes), 26 the real final pass of -a N, 27 the -l trainer, 28 Rice decoding, 30 / 31 the synthesis of
  * the long layer (k_synth_big) / of the short layers and the de-emphasis (k_synth_small); 11 is then the one-launch form
- * (k_synthesize), 32 the pipelined latency form (k_synth_pipe: small batches), 33 the throughput form of a layer (k_synth_rows: four
- * channel-frames per wave, what large batches take), 34 the de-emphasis behind it (k_deemph_lr; it includes MS->LR when whole frames
+ * (k_synthesize), 32 the pipelined latency form (k_synth_pipe: small batches), 33 the throughput form of a layer (k_synth_rows / k_synth_rows8: four
+ * or eight channel-frames per wave, what large batches take), 34 the de-emphasis behind it (k_deemph_lr; it includes MS->LR when whole frames
  * lie in a block of 64 rows: no kind 12 then). */
 double LINNEAmd_GetLastTimingMs(struct LINNEAmdContext *ctx, int which);
 int LINNEAmd_GetLastTimingLaunches(struct LINNEAmdContext *ctx, int which);

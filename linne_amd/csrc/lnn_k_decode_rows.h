@@ -1,5 +1,6 @@
-/* lnn_k_decode_rows.h -- k_synth_rows: the THROUGHPUT form of a synthesis layer (linne_lpc_synthesize.c:8-83), four channel-frames
- * per wave, one per 16-lane DPP row.
+/* lnn_k_decode_rows.h -- the THROUGHPUT form of the synthesis: k_synth_rows (a layer, linne_lpc_synthesize.c:8-83, four channel-frames
+ * per wave, one per 16-lane DPP row), k_synth_rows8 (the layers of <= 16 taps, eight per wave) and k_deemph_lr (de-emphasis + MS -> LR
+ * behind layer 0).
  * Part of the single translation unit lnn_device.hip (included there behind lnn_k_decode.h); not a stand-alone header.
  *
  * The lanes = channel-frames kernels (k_synth_small / k_synth_big) are few, long waves: a pass costs one wave's 10 240-step
@@ -18,9 +19,12 @@
  * Blocks are aligned to the frame (sample 16 m + i), not to the unit: a lane is `pred` (its sample is predicted from its unit's
  * coefficients) or not (the unit's first np samples, what lies behind the last unit, a layer linne_decoder.c skips), and a row's
  * coefficient registers are built for ONE state -- all 16 lanes predicting in unit u, or none (zeros: the steady code then copies).
- * A block in which a row's lanes disagree (a unit's boundary inside it, orders below 16) takes the generic routine for that row:
- * tap by tap over the row's lanes from the previous outputs (registers for d <= 16, the digit ring beyond), a DPP row sum per
- * sample.  Frames of any length and unit count take this kernel; the steady code is what a frame spends its time in.
+ * A block in which a row's lanes disagree (a unit's boundary inside it) takes the generic routine for that row: tap by tap over the
+ * row's lanes from the previous outputs (registers for d <= 16, the digit ring beyond), a DPP row sum per sample.  The layers of <= 16
+ * taps, where a unit of fewer than 16 samples makes every unit's first block such a block, build the registers per LANE instead and
+ * have no generic rows.  An outer loop iteration starts at a block in which some lane's class changes (every lane knows the next
+ * such block of its own: m_event) and writes the registers -- there and nowhere else, so the inner loop keeps them in place.
+ * Frames of any length and unit count take this kernel; the steady code is what a frame spends its time in.
  * The samples travel in 64-sample chunks: one 16-byte load and store per lane and chunk, staged through LDS. */
 #ifndef LNN_K_DECODE_ROWS_H_INCLUDED
 #define LNN_K_DECODE_ROWS_H_INCLUDED
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
 #undef SR_STEP
                 yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
             }
-            if (__any(gen)) {
+            if (NCH && __any(gen)) {                             /* (the layers of <= 16 taps have no mixed rows: registers per lane) */
                 /* the generic routine, sample by sample: the row's lanes share the taps (lane k: distances k + 1, k + 17, ...) */
                 int32_t ycur = 0;
                 const uint32_t rowbase = 16u * q;
