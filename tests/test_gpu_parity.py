@@ -289,6 +289,14 @@ def test_own_cli_matches_the_reference_cli(tmp_path):
         assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
 
 
+def _force_decode_form(monkeypatch, kernel):
+    """LINNE_AMD_DECODE_KERNEL for a test; `rows` / `rows4`: the throughput form with EIGHT / FOUR channel-frames per wave in the layers of
+    <= 16 taps (the batch-size rule would pick four for batches as small as a test's)"""
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel in ("rows", "rows4") else kernel)
+    if kernel in ("rows", "rows4"):
+        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "1" if kernel == "rows" else "0")
+
+
 @pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4"])
 @pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
 def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
@@ -296,9 +304,7 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
     channel-frames / four lanes per channel-frame for large ones, whose int32 dot products run in FP64).  Both forms must
     restore the input exactly and agree with the oracle's synthesis, on every preset family, ragged tails included.
     (`rows4`: the throughput form with four channel-frames per wave for the short layers too; `rows` takes eight there.)"""
-    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel == "rows4" else kernel)
-    if kernel == "rows4":
-        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "0")
+    _force_decode_form(monkeypatch, kernel)
     ms = nch >= 2
     F = 5
     frames = music_frames(F, nch, block, bits, seed=77 + nch + preset)
@@ -320,9 +326,7 @@ def test_decode_forms_with_frames_of_many_lengths_in_one_batch(ctx, monkeypatch,
     k_synth_rows wave, the 64 rows of a k_deemph_lr / k_synth_small block and the rows of its last, partial block end in
     different places, unit boundaries fall inside the 16-sample blocks, and the shortest frames are shorter than a layer's
     order); the decode must restore every frame's own samples and leave what lies behind them alone"""
-    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel == "rows4" else kernel)
-    if kernel == "rows4":
-        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "0")
+    _force_decode_form(monkeypatch, kernel)
     rng = np.random.default_rng(99 + F)
     ms = nch >= 2
     frames = music_frames(F, nch, block, bits, seed=5 + nch)
@@ -356,7 +360,7 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     if seed % 3 == 2:
         monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "lanes")   # (the default for these short streams is the pipelined latency form)
     if seed % 3 == 1:
-        monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows")    # four channel-frames per wave (the batch form of every layer but the de-emphasised one)
+        _force_decode_form(monkeypatch, "rows" if seed % 2 else "rows4")     # the batch form of the synthesis: eight / four channel-frames per wave in the short layers
     if seed % 4 == 3:
         monkeypatch.setenv("LINNE_AMD_PREP_GENERAL", "1")
     rng = np.random.default_rng(1000 + seed)
@@ -389,11 +393,11 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     assert ret == 0 and np.array_equal(dec, x)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4"])
 def test_corrupt_streams_do_not_hang_or_fault(product, oracle, monkeypatch, kernel):
     """with the CRC check off a damaged payload reaches the parser and the GPU with arbitrary parameters (unit counts,
     shifts, coefficients, residuals): decoding must come back with a result code (and the device must stay usable)"""
-    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", kernel)
+    _force_decode_form(monkeypatch, kernel)
     rng = np.random.default_rng(4242)
     x = music(2, 6 * 2048 + 100, 16, seed=8)
     good = oracle.encode_whole(x, 16, 44100, 2048, 7, True)
