@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t row_sum_all(uint32_t v)      /* wrap-around 
 template <int NCH, int PB = 16>      /* NCH: 16-sample chunks of older history on the matrix unit: 0 for layers of <= 16 taps, 1 for 32, 3 for 64, 7
                                        * for 128.  PB: the layer's order if it is below 16, else 16: output j of a block reaches the next block's sums
                                        * only from distance 16 + i - j <= PB, i.e. j >= 16 - PB -- the other steps leave that multiply-add out */
-__global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p, uint32_t layer)
+__global__ __launch_bounds__(64, 4) void k_synth_rows(DecPlan p, uint32_t layer)
 {
     __shared__ __attribute__((aligned(16))) int8_t ring[4][4][256];          /* [channel-frame][digit plane][sample mod 256] */
     __shared__ __attribute__((aligned(16))) int8_t zeros[256];               /* what the A operand's other K groups read */
@@ -91,17 +91,17 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
 #pragma unroll
     for (int c = 0; c < (NCH ? NCH : 1); c++) tz[c] = lnn_v4i{ 0, 0, 0, 0 };
     int32_t yprev = 0;
-    uint32_t nxt = 0, mcur = 0;
+    uint32_t nxt = 0;                                              /* layers of <= 16 taps: what the previous block adds (NCH > 0: the matrix unit's, with the old taps) */
+    lnn_v4i wacc = { 0, 0, 0, 0 }, tzp = { 0, 0, 0, 0 };           /* NCH > 0: the digit planes of this block's matrix-unit sums so far (chunks 0 .. NCH-1); the Toeplitz slice of the PREVIOUS block's taps (distances 16 + i - e) */
 
-    auto window = [&](uint32_t m) -> uint32_t {                 /* matrix-unit part of block m's sums: the 16 NCH samples that end 16 before it */
-        if (!NCH) return 0u;
+    auto window = [&](uint32_t m) -> lnn_v4i {                  /* matrix-unit part of block m's sums without the block before it: the 16 NCH samples that end 16 before it (digit planes) */
         lnn_v4i acc4 = { 0, 0, 0, 0 };
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
             const lnn_v4i a = *(const lnn_v4i *)(abase + ((16u * m - 32u - 16u * (uint32_t)c) & 255u));
             acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, tz[c], acc4, 0, 0, 0);
         }
-        return (uint32_t)acc4[0] + ((uint32_t)acc4[1] << 8) + ((uint32_t)acc4[2] << 16) + ((uint32_t)acc4[3] << 24);
+        return acc4;
     };
 
     /* 64-sample chunks: chunk c + 1 is requested while chunk c is worked on */
@@ -176,7 +176,13 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
                 }
                 const int8_t *cb = &cst[q][0] + (bpred ? SR_PAD + np - i : SR_PAD - 17u);      /* (no state: zeros whatever the distance) */
 #pragma unroll
-                for (int j = 0; j < 16; j++) { ccA[j] = cb[j]; ccB[j] = cb[j - 16]; }         /* distances i - j and 16 + i - j */
+                for (int j = 0; j < 16; j++) ccA[j] = cb[j];                                   /* distances i - j */
+                {   /* distances 16 + i - e: the block before, element e -- as a slice for the matrix unit like the older ones */
+                    uint32_t w[4] = { 0u, 0u, 0u, 0u };
+#pragma unroll
+                    for (int e = 0; e < 16; e++) w[e >> 2] |= ((uint32_t)cb[e - 16] & 0xFFu) << (8 * (e & 3));
+                    tzp = lnn_v4i{ (int)w[0], (int)w[1], (int)w[2], (int)w[3] };
+                }
                 __builtin_amdgcn_sched_barrier(0);          /* (a group of reads at a time: the registers are the steady code's) */
 #pragma unroll
                 for (int cc = 0; cc < NCH; cc++) {
@@ -192,27 +198,36 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             if (gen) m_event = m + 1u;                      /* a mixed row has no state: the next block builds */
             /* what the previous block adds to this one's sums, and the matrix-unit part, with the registers as they are now
              * (rows that kept their state get the values they had: the sums are associative) */
-            nxt = 0;
+            if (!NCH) {
+                nxt = 0;
 #define SR_STEP(J, MUL_) if ((J) >= 16 - PB) { const int32_t sv = row_bcast<J>(yprev); nxt += sp_mul8(ccB[J], sv & 0xFFFF, sv >> 16); }
-            SR_STEPS(0)
+                SR_STEPS(0)
 #undef SR_STEP
-            mcur = window(m);
+            } else wacc = window(m);
         }
 #pragma unroll 1
         do {
             const uint32_t c = m >> 2, k = m & 3u;
             if (k == 0u && c + 1u < nchunk) { *(lnn_v4i *)&stg_in[(c + 1u) & 1u][q][4u * i] = pre; if (c + 2u < nchunk) pre = fetch(c + 2u); }
             const int32_t res = stg_in[c & 1u][q][16u * k + i];
-            const uint32_t acc0 = half_l + mcur + nxt;
+            /* NCH > 0: the block before this one joins the sums on the matrix unit too (its digits are in the ring since it ended; the same 16
+             * bytes are chunk 0 of the NEXT block's window): the steps carry no multiply-add for it */
+            lnn_v4i wa = { 0, 0, 0, 0 };
+            uint32_t mpart = 0;
+            if (NCH) {
+                wa = *(const lnn_v4i *)(abase + ((16u * m - 16u) & 255u));
+                wacc = __builtin_amdgcn_mfma_i32_16x16x64_i8(wa, tzp, wacc, 0, 0, 0);
+                mpart = (uint32_t)wacc[0] + ((uint32_t)wacc[1] << 8) + ((uint32_t)wacc[2] << 16) + ((uint32_t)wacc[3] << 24);
+            }
+            const uint32_t acc0 = half_l + mpart + nxt;
             uint32_t acc = acc0;
             nxt = 0;
             /* speculation as in k_synth_pipe: every output of the block fits 24 bits -- one full-rate multiply-add per sum.  The
              * NEXT block's matrix-unit part rides between the steps, a chunk every two of them: each MFMA waits for the one before
              * it (one accumulator), and a wave that issued the seven back to back stood still for their latencies */
-            lnn_v4i acc4 = { 0, 0, 0, 0 }, wa = { 0, 0, 0, 0 };
-            if (NCH) wa = *(const lnn_v4i *)(abase + ((16u * m - 16u) & 255u));
+            lnn_v4i acc4 = { 0, 0, 0, 0 };
 #define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
-                acc += (uint32_t)__mul24(ccA[J], sv); if ((J) >= 16 - PB) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nxt) : "v"(ccB[J]), "v"(sv)); }     /* (a multiply-add per tap: the compiler's tree of products and three-operand adds is half as many again) */
+                acc += (uint32_t)__mul24(ccA[J], sv); if (!NCH && (J) >= 16 - PB) asm("v_mad_i32_i24 %0, %1, %2, %0" : "+v"(nxt) : "v"(ccB[J]), "v"(sv)); }     /* (a multiply-add per tap: the compiler's tree of products and three-operand adds is half as many again) */
 #define SR_WIN(CC_) if ((CC_) < NCH) { const lnn_v4i a_ = wa; \
                 if ((CC_) + 1 < NCH) wa = *(const lnn_v4i *)(abase + ((16u * m - 16u - 16u * (uint32_t)((CC_) + 1)) & 255u)); \
                 acc4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a_, tz[(CC_) < NCH ? (CC_) : 0], acc4, 0, 0, 0); __builtin_amdgcn_sched_barrier(0); }
@@ -220,13 +235,12 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
             SR_STEP(8, 0) SR_STEP(9, 0) SR_WIN(4) SR_STEP(10, 0) SR_STEP(11, 0) SR_WIN(5) SR_STEP(12, 0) SR_STEP(13, 0) SR_WIN(6) SR_STEP(14, 0) SR_STEP(15, 0)
 #undef SR_WIN
 #undef SR_STEP
-            const uint32_t mnext = (uint32_t)acc4[0] + ((uint32_t)acc4[1] << 8) + ((uint32_t)acc4[2] << 16) + ((uint32_t)acc4[3] << 24);
             int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
             const bool fits = gen || (((int32_t)((uint32_t)yout << 8) >> 8) == yout);
             if (!__all(fits)) {
                 acc = acc0; nxt = 0;
 #define SR_STEP(J, MUL_) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); const int32_t sv = row_bcast<J>(y); \
-                const int32_t sl = sv & 0xFFFF, shh = sv >> 16; acc += sp_mul8(ccA[J], sl, shh); if ((J) >= 16 - PB) nxt += sp_mul8(ccB[J], sl, shh); }
+                const int32_t sl = sv & 0xFFFF, shh = sv >> 16; acc += sp_mul8(ccA[J], sl, shh); if (!NCH && (J) >= 16 - PB) nxt += sp_mul8(ccB[J], sl, shh); }
                 SR_STEPS(0)
 #undef SR_STEP
                 yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
@@ -269,7 +283,7 @@ __global__ __launch_bounds__(64, (NCH >= 1 ? 3 : 4)) void k_synth_rows(DecPlan p
                 ring[q][0][ix] = (int8_t)dg; ring[q][1][ix] = (int8_t)(dg >> 8); ring[q][2][ix] = (int8_t)(dg >> 16); ring[q][3][ix] = (int8_t)(dg >> 24);
             }
             yprev = yout;
-            mcur = mnext;
+            wacc = acc4;
             m++;
             if (k == 3u || m == nblk) {
                 /* the chunk's outputs: 16 bytes per lane; nothing behind a frame's end is written */
