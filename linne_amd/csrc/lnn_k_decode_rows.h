@@ -45,12 +45,13 @@ __device__ __forceinline__ uint32_t row_sum_all(uint32_t v)      /* wrap-around 
 
 #define SR_PAD 160u      /* zeros in front of the staged coefficients: distances up to 128 + 16 + 15 beyond np */
 #define SR_CST 320u      /* SR_PAD + 128 coefficients + 16 zeros (distances <= 0), rounded */
+#define SR_RINGP 272      /* bytes from a digit plane to the next (256 used) */
 template <int NCH, int PB = 16>      /* NCH: 16-sample chunks of older history on the matrix unit: 0 for layers of <= 16 taps, 1 for 32, 3 for 64, 7
                                        * for 128.  PB: the layer's order if it is below 16, else 16: output j of a block reaches the next block's sums
                                        * only from distance 16 + i - j <= PB, i.e. j >= 16 - PB -- the other steps leave that multiply-add out */
 __global__ __launch_bounds__(64, 4) void k_synth_rows(DecPlan p, uint32_t layer)
 {
-    __shared__ __attribute__((aligned(16))) int8_t ring[4][4][256];          /* [channel-frame][digit plane][sample mod 256] */
+    __shared__ __attribute__((aligned(16))) int8_t ring[4][4][SR_RINGP];     /* [channel-frame][digit plane][sample mod 256]; planes 272 bytes apart = 4 banks: the 16 planes' reads of a chunk (one lane each) and the rows' digit stores do not collide */
     __shared__ __attribute__((aligned(16))) int8_t zeros[256];               /* what the A operand's other K groups read */
     __shared__ __attribute__((aligned(16))) int32_t stg_in[2][4][80], stg_out[4][80];    /* (rows 16 words apart modulo the 64 banks: the four rows' reads of a block do not collide) */
     __shared__ __attribute__((aligned(16))) int8_t cst[4][SR_CST];           /* a row's coefficients while its registers are built */
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(64, 4) void k_synth_rows(DecPlan p, uint32_t layer)
     for (uint32_t k = lane; k < 256u; k += 64u) { zeros[k] = 0; }
     for (uint32_t k = lane; k < 4u * SR_CST / 4u; k += 64u) ((uint32_t *)&cst[0][0])[k] = 0u;
     if (!NCH) call[q][i] = (i < P && units) ? (int8_t)crec[i] : (int8_t)0;
-    if (NCH) for (uint32_t k = lane; k < 4096u / 4u; k += 64u) ((uint32_t *)&ring[0][0][0])[k] = 0u;
+    if (NCH) for (uint32_t k = lane; k < 16u * SR_RINGP / 4u; k += 64u) ((uint32_t *)&ring[0][0][0])[k] = 0u;
     /* the A operand of lane l: row l & 15 = plane b of channel-frame qa, K group l >> 4: its own channel-frame's, or zeros */
     const int8_t *abase = (((lane & 15u) >> 2) == q) ? &ring[(lane & 15u) >> 2][lane & 3u][0] : &zeros[0];
 
@@ -537,5 +538,6 @@ __global__ __launch_bounds__(64 * (2 + DL_STORERS)) void k_deemph_lr(DecPlan p)
 #undef SR_STEPS
 #undef SR_PAD
 #undef SR_CST
+#undef SR_RINGP
 
 #endif
