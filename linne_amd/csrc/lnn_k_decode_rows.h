@@ -10,7 +10,8 @@
  *   d <= i            the block's own outputs: lane i holds output i's sum; when y_j is final every later lane of the ROW adds its
  *                     tap times y_j -- the broadcast is a DPP row_newbcast, so the four rows run their own recurrences in the same
  *                     instructions (shift, subtract, broadcast, two 24-bit multiply-adds per step and four channel-frames);
- *   i < d <= i + 16   the previous block's outputs: added in the same steps into the NEXT block's sums (second coefficient set);
+ *   i < d <= i + 16   the previous block's outputs: layers of <= 16 taps add them in the same steps into the NEXT block's sums (second
+ *                     coefficient set); longer layers leave them to the matrix unit with the older ones (one more MFMA at the block's start);
  *   d > i + 16        older samples (layers of more than 16 taps): v_mfma_i32_16x16x64_i8 with K = 4 channel-frames x 16 samples --
  *                     A = the outputs' signed base-256 digit planes (row 4 q + b = plane b of channel-frame q, non-zero only in
  *                     that channel-frame's K group), B = each channel-frame's Toeplitz slice of its 8-bit coefficients (held by
