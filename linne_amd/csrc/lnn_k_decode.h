@@ -393,7 +393,8 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
  * same range).  Frames too long for the LDS image stay with k_synthesize. */
 typedef int lnn_v4i __attribute__((ext_vector_type(4)));
 #define SP_RING 256u
-struct SpShared { uint32_t prog[LNN_MAXL + 1]; uint32_t pad[4]; int8_t ring[LNN_MAXL][4][SP_RING]; };
+#define SP_RINGP 272u                   /* bytes from a digit plane to the next: the four planes' 16-byte reads of a window (one lane each) hit different banks */
+struct SpShared { uint32_t prog[LNN_MAXL + 1]; uint32_t pad[4]; int8_t ring[LNN_MAXL][4][SP_RINGP]; };
 
 __device__ __forceinline__ uint32_t sp_load_prog(const uint32_t *q) { return __hip_atomic_load(q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void sp_publish(uint32_t *q, uint32_t v) { __hip_atomic_store(q, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
@@ -407,7 +408,7 @@ __device__ __forceinline__ uint32_t sp_mul8(int32_t c, int32_t sl, int32_t sh) {
 __device__ __forceinline__ uint32_t sp_digits(int32_t v) { return ((uint32_t)v + 0x00808080u) ^ 0x00808080u; }
 
 template <int KS>       /* 64-sample steps of history summed on the matrix unit: 0 for layers of <= 16 taps, 1 up to 80, 2 up to 144 */
-__device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout, int8_t (*ring)[SP_RING], const int32_t *coef,
+__device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout, int8_t (*ring)[SP_RINGP], const int32_t *coef,
         uint32_t P, uint32_t units, uint32_t rs, uint32_t n, uint32_t lane)
 {
     const uint32_t np = units ? P / units : 0u, ns = units ? n / units : 0u;
