@@ -710,6 +710,8 @@ def worker(args):
     ok = bool(torch.equal(work, frames))
     while len(dec_bufs) < min(args.steps, DECODE_COPIES):
         dec_bufs.append(torch.empty_like(work))
+    for i in range(1, len(dec_bufs)):            # every copy decoded once before the timed region (a fresh allocation's first pass pays for its pages)
+        decode_step(i)
     for b in dec_bufs:
         b.copy_(res)
     barrier()
