@@ -1,7 +1,8 @@
 """GPU parity at the batch sizes the launch rules pick BY THEMSELVES (-m gpu).
 
 EncodeFramesDevice chooses its kernel forms by batch size (lnn_device.hip: k_autocorr_hist / k_autocorr_sub from 12 288
-jobs, k_fwd_loss from 24 576 jobs; DecodeFramesDevice: k_synth_small / k_synth_big from 6 144 channel-frames), cuts a call
+jobs, k_fwd_loss from 24 576 jobs; DecodeFramesDevice: k_synth_rows + k_deemph_lr from 1 536 channel-frames, k_synth_rows8 for the
+short layers from 20 480), cuts a call
 into equal chunks when the scratch arena is small, and can rotate chunks over two streams.  The tests in
 test_gpu_parity.py reach those forms by forcing them onto a few frames; here the batch is big enough that nothing is
 forced: many full 64-row blocks per class run, a ragged tail, several chunks, two streams, and the many-tracks shape of
@@ -322,3 +323,41 @@ def test_whole_stream_api_over_several_devices(product, oracle, monkeypatch, dev
     assert mine == oracle.encode_whole(x, 16, 44100, block, 7, True)
     ret, dec = product.decode_whole(mine)
     assert ret == 0 and np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("preset,nch,bits", [(0, 2, 16), (2, 1, 16), (4, 2, 24), (5, 8, 16), (7, 2, 16)])
+def test_decode_throughput_forms_at_the_batch_sizes_that_pick_them(preset, nch, bits):
+    """DecodeFramesDevice with nothing forced on batches of > 20 480 channel-frames (short blocks keep them cheap): k_synth_rows for
+    the long layer of every preset family (32 / 64 / 128 taps), k_synth_rows8 for the layers of <= 16 taps, k_deemph_lr with and without
+    the fused MS -> LR (1, 2 and 8 channels), several rounds of waves per SIMD, frames of a dozen lengths in the batch.  decode(encode(x))
+    must be x, and what lies behind a frame's end must stay."""
+    for v in ("LINNE_AMD_DECODE_KERNEL", "LINNE_AMD_DECODE_ROWS8"):
+        assert v not in os.environ
+    block = 1024
+    F = 20480 // nch + 77
+    base = np.stack([music(nch, block, bits, seed=100 * preset + k) for k in range(64)])             # [64][nch][block]
+    frames = np.ascontiguousarray(np.tile(base, ((F + 63) // 64, 1, 1))[:F])
+    rng = np.random.default_rng(5 + preset)
+    ns = np.full(F, block, dtype=np.uint32)
+    pool = np.array([1, 17, 130, 500, 777, block - 3, block // 2 + 1], dtype=np.uint32)
+    where = rng.choice(F, size=200, replace=False)
+    ns[where] = rng.choice(pool, size=200)
+    ns[-1] = 777
+    for f in np.flatnonzero(ns < block):
+        frames[f, :, int(ns[f]):] = 0
+    c = linne_amd.Context(0)
+    try:
+        shape = c.shape(nch, bits, block, preset, nch >= 2)
+        res, prm, st = c.encode_frames_host(shape, frames, ns)
+        marked = res.copy()
+        for f in np.flatnonzero(ns < block):
+            marked[f, :, int(ns[f]):] = -123456
+        dec = c.decode_frames_host(shape, marked, prm, ns)
+    finally:
+        c.close()
+    full = ns == block
+    assert np.array_equal(dec[full], frames[full])
+    for f in np.flatnonzero(~full):
+        n = int(ns[f])
+        assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f} (n = {n})"
+        assert np.all(dec[f, :, n:] == -123456), f"frame {f}: samples behind its end were written"
