@@ -811,6 +811,10 @@ def worker(args):
             "encode_sample_parity": None, "encode_sample_parity_detail": None,
             "encode_channel_frames_per_s": enc_fps * nch,
             "kernel_ms_per_step": breakdown,
+            "kernel_ms_note": ("summed HIP-event time of each kernel kind per step.  A batch of this size runs as two halves on two compute streams "
+                               "(LINNE_AMD_STREAMS, default 2 when each half keeps the large-batch kernel forms): a kernel's time includes what the other "
+                               "half's kernels took of the GPU beside it, so the encode kinds add up to about twice ms_per_step"
+                               if os.environ.get("LINNE_AMD_STREAMS", "2") != "1" else "summed HIP-event time of each kernel kind per step (one compute stream)"),
             "roofline": roofline, "roofline_decode": roofline_decode, "valu_f64": valu, "cpu_baseline": None, "cpu_baseline_decode": None,
             "block_at_a_time": None, "end_to_end_api": None, "transports": None,
             "transports_note": "value = the hot path with every rank's shard resident in its own HBM (contract: inputs resident when the timed "

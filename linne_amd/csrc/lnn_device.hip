@@ -58,7 +58,7 @@ struct LINNEAmdContext {
     uint32_t *d_ucount;
     /* frame groups of one call rotate over these streams so that the latency-bound phases of one group (short
      * layers, Levinson, ordered sums) overlap the throughput-bound phases of another */
-    hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub;
+    hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub, nsub_forced /* LINNE_AMD_STREAMS was given */;
     hipStream_t side; hipEvent_t side_done; int has_side;     /* block-type statistics run beside the analysis */
     hipEvent_t fork_ev, join_ev;        /* side stream: the general autocorrelation kernel for the few frames the lanes = jobs kernels do not take */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_map;   /* class index per sorted row, then the sorted row's frame (same buffer) */ uint32_t *d_nsmp; uint64_t nsmp_cap;
@@ -142,12 +142,13 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
     if ((e = hipMalloc((void **)&ctx->d_ucount, 4 * sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
     {
         const char *env = getenv("LINNE_AMD_STREAMS");
-        int ns = env ? atoi(env) : 1;
+        int ns = env ? atoi(env) : 2;                /* (two by default since round 3: see the rule at the chunk loop) */
+        ctx->nsub_forced = env != NULL;
         if (ns < 1) ns = 1;
         if (ns > LNN_MAXSUB) ns = LNN_MAXSUB;
         /* One stream of a process maps onto one of a few hardware queues (four by default); streams that share a queue run in
-         * order whatever their events say.  A context therefore creates as few streams as it needs: with one compute stream
-         * (the default) the analysis runs on the context's own stream, and sub-streams exist only for LINNE_AMD_STREAMS >= 2. */
+         * order whatever their events say.  A context therefore creates as few streams as it needs: two compute sub-streams
+         * (LINNE_AMD_STREAMS=1: none -- the analysis then always runs on the context's own stream, as small batches do anyway). */
         ctx->nsub = 0;
         for (int i = 0; i < ns && ns >= 2; i++) {
             if (hipStreamCreateWithFlags(&ctx->sub[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ctx->sub_done[i], hipEventDisableTiming) != hipSuccess) break;
@@ -643,6 +644,11 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     /* frame groups ("chunks") rotate over nsub streams, each with its own slice of the arena */
     uint32_t nsub = ctx->nsub > 0 ? (uint32_t)ctx->nsub : 1u;
     while (nsub > 1 && ((ctx->arena_bytes - 65536) / nsub < per_frame * 2 || num_frames < nsub * 512u)) nsub--;
+    /* By default a call is cut in two only if each half still fills the chip and keeps every large-batch kernel form (the rules below
+     * go by the jobs of a chunk: k_fwd_loss from 24 576): the halves' latency-bound kernels (Levinson-Durbin, the short layers' search,
+     * the selections) then run beside the other half's vector-unit-bound ones -- 83.1 -> 80.1 ms per step on the 60-minute batch
+     * (tools/streams_ab.sh).  Smaller batches keep one stream and the context's own (no fork / join around a block-at-a-time call). */
+    if (!ctx->nsub_forced) while (nsub > 1 && (uint64_t)(num_frames / nsub) * C * hs.R < 32768u) nsub--;
     const uint64_t part_bytes = ((ctx->arena_bytes - 65536) / nsub) & ~(uint64_t)255;
     uint64_t chunk = part_bytes / per_frame;
     if (chunk == 0) chunk = 1;
@@ -661,7 +667,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount, 0, sizeof(uint32_t), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount + 2, 0x7F, 2 * sizeof(uint32_t), ctx->stream));      /* min margin: a huge double (0x7F7F...) */
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
-    const bool use_sub = ctx->nsub > 0;
+    const bool use_sub = ctx->nsub > 0 && (nsub > 1 || ctx->nsub_forced);
     if (use_sub || ctx->has_side) HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (use_sub) for (uint32_t i = 0; i < nsub; i++) HIPCHK(ctx, hipStreamWaitEvent(ctx->sub[i], ctx->ev_start, 0));
     {   /* statistics of every frame of the call: one launch beside the analysis */
