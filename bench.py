@@ -758,6 +758,12 @@ def worker(args):
             if not cand:
                 return None
             dom = max(cand, key=lambda k: kern_ms[k])
+            # With two compute streams (the default for a batch of this size) a kernel's HIP-event time includes what the other half's
+            # kernels took of the GPU beside it, and the latency-bound kernels stretch most: the largest SUM is then not the kernel that
+            # does the most work.  The long layer's search is the dominant kernel by exclusive time (profiles/r03b_kernel_stats_one_stream.csv,
+            # LINNE_AMD_STREAMS=1: 24.6 of 83 ms): it is the roofline's kernel whenever it ran.
+            if 25 in cand and 25 in kinds:
+                dom = 25
             launches = max(1, kern_launches[dom])
             avg_ms = kern_ms[dom] / launches
             # timed spans of one kind per chunk of frames: per-layer kernels have one span per layer they serve
