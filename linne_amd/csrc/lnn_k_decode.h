@@ -490,13 +490,14 @@ __device__ void sp_layer_stage(int32_t *buf, const uint32_t *pin, uint32_t *pout
              * again with the multiplication split in halves (exact modulo 2^32 for any value). */
             /* (a lone wave issues an instruction every ~9 cycles whatever its dependences, so a step costs what it counts in
              * instructions: shift, subtract, v_readlane, two multiply-adds and the three wait states the scalar result needs) */
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
-                const int32_t sv = __builtin_amdgcn_readlane(y, j);
-                acc += (uint32_t)__mul24(ccA[j], sv);
-                nxt += (uint32_t)__mul24(ccB[j], sv);
-            }
+            /* (round 3: y_j reaches the lanes through a DPP row_newbcast -- lanes 0 .. 15 are the block -- not through v_readlane: no
+             * trip through a scalar register and its wait states) */
+#define SP_STEP(J) { const int32_t y = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_)); \
+                const int32_t sv = __builtin_amdgcn_update_dpp(0, y, 0x150 + (J), 0xf, 0xf, true); \
+                acc += (uint32_t)__mul24(ccA[J], sv); nxt += (uint32_t)__mul24(ccB[J], sv); }
+            SP_STEP(0) SP_STEP(1) SP_STEP(2) SP_STEP(3) SP_STEP(4) SP_STEP(5) SP_STEP(6) SP_STEP(7)
+            SP_STEP(8) SP_STEP(9) SP_STEP(10) SP_STEP(11) SP_STEP(12) SP_STEP(13) SP_STEP(14) SP_STEP(15)
+#undef SP_STEP
             /* lane i's sum has not changed since step i (ccA[j] = 0 for j >= i): its output, whatever the step */
             int32_t yout = (int32_t)((uint32_t)res - (uint32_t)((int32_t)acc >> sh_));
             const bool fits = (lane >= 16u) || (((int32_t)((uint32_t)yout << 8) >> 8) == yout);
