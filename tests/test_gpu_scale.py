@@ -361,3 +361,31 @@ def test_decode_throughput_forms_at_the_batch_sizes_that_pick_them(preset, nch, 
         n = int(ns[f])
         assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f} (n = {n})"
         assert np.all(dec[f, :, n:] == -123456), f"frame {f}: samples behind its end were written"
+
+
+def test_the_default_two_streams_give_the_one_stream_result(monkeypatch):
+    """a call whose halves keep the large-batch kernel forms (>= 32 768 jobs each) is cut in two over two compute streams by default
+    (lnn_device.hip, the rule at the chunk loop); residual, parameters and statistics must be those of LINNE_AMD_STREAMS=1, bit for bit
+    (short blocks keep the batch cheap: 8 320 stereo frames of 1024 samples, a dozen frame lengths among them)"""
+    assert "LINNE_AMD_STREAMS" not in os.environ
+    nch, bits, block, preset, F = 2, 16, 1024, 7, 8320
+    base = np.stack([music(nch, block, bits, seed=900 + k) for k in range(64)])
+    frames = np.ascontiguousarray(np.tile(base, ((F + 63) // 64, 1, 1))[:F])
+    rng = np.random.default_rng(77)
+    ns = np.full(F, block, dtype=np.uint32)
+    where = rng.choice(F, size=300, replace=False)
+    ns[where] = rng.choice(np.array([130, 500, 777, block - 3, block // 2 + 1], dtype=np.uint32), size=300)
+    for f in np.flatnonzero(ns < block):
+        frames[f, :, int(ns[f]):] = 0
+    out = []
+    for streams in (None, "1"):
+        if streams:
+            monkeypatch.setenv("LINNE_AMD_STREAMS", streams)
+        c = linne_amd.Context(0)
+        try:
+            shape = c.shape(nch, bits, block, preset, True)
+            out.append(c.encode_frames_host(shape, frames, ns))
+        finally:
+            c.close()
+    for a, b, what in zip(out[0], out[1], ("residual", "parameters", "statistics")):
+        assert np.array_equal(a, b), what
