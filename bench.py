@@ -113,9 +113,9 @@ def frames_from_track(track, block):
     return frames, nsm
 
 
-def host_cores():
+def host_cores(world=1):
     """CPU threads this process may really use: affinity, capped by the cgroup CPU quota and BENCH_CPU_CORES
-    (a one-GPU box grants 16 of the host's cores)"""
+    (a one-GPU box grants 16 of the host's cores; with N ranks rank 0 may use the N ranks' share while they wait)"""
     n = len(os.sched_getaffinity(0))
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -123,7 +123,7 @@ def host_cores():
             n = min(n, max(1, int(float(q) / float(per))))
     except Exception:
         pass
-    n = min(n, int(os.environ.get("BENCH_CPU_CORES", "16")))
+    n = min(n, int(os.environ.get("BENCH_CPU_CORES", str(16 * max(1, world)))))
     return max(1, n)
 
 
@@ -203,7 +203,7 @@ def _run_threads(work, n):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(frames_host, bits, rate, block, preset, ms, budget_frames_per_thread):
+def cpu_baseline(frames_host, bits, rate, block, preset, ms, budget_frames_per_thread, cores=None):
     """reference CPU encoder (EncodeBlock incl. its entropy stage, libs/linne_encoder/src/linne_encoder.c:594-752) on the first
     frames of the workload, one handle per thread over disjoint frames; then the reference CPU DECODER (DecodeBlock,
     libs/linne_decoder/src/linne_decoder.c:564-668) over the blocks the encoder just wrote, again one handle per thread.
@@ -211,7 +211,7 @@ def cpu_baseline(frames_host, bits, rate, block, preset, ms, budget_frames_per_t
     import ctypes as C
     from linne_amd.api import LinneApi, _RefDecoderConfig, _RefHeader
     Oracle, REF_SO, EncodeParameter, reference_available = _checkers()
-    cores = host_cores()
+    cores = cores or host_cores()
     F, nch, _ = frames_host.shape
     per = min(budget_frames_per_thread, max(1, F // cores))
     total = per * cores
@@ -439,11 +439,13 @@ def leg_exchange(dist, group, ctx, shape, frames, nsm, res_ref, prm_ref, steps, 
     Ftot = F * world
     nsm_all = np.tile(nsm, world)
     backend = dist.get_backend(group)
+    rccl_ranks = None
     if backend == "nccl":           # the whole-group communicator comes up here, inside this leg's deadline
         t = torch.ones(1, device=dev)
         dist.all_reduce(t, group=group)
         torch.cuda.synchronize()
-        assert int(t.item()) == world
+        rccl_ranks = int(t.item())      # what RCCL itself counted: an all-reduce of ones over the communicator
+        assert rccl_ranks == world
     ex = ChunkExchange(dist, Ftot, chunk_frames, [((nch, S), torch.int32)],
                        [((nch, S), torch.int32), ((nch, linne_amd.PARAM_WORDS), torch.int32), ((nch, linne_amd.STAT_WORDS), torch.float64)], dev, root=0, group=group)
     if rank == 0:
@@ -469,7 +471,7 @@ def leg_exchange(dist, group, ctx, shape, frames, nsm, res_ref, prm_ref, steps, 
     dt = red(time.perf_counter() - t0)
     moved = (ex.bytes_per_frame_out + ex.bytes_per_frame_back) * Ftot * (world - 1) / max(1, world)
     via = "RCCL ncclSend / ncclRecv over xGMI, device memory to device memory" if backend == "nccl" else f"{backend} with every transfer staged through host copies (a REHEARSAL of the schedule, not an RCCL measurement)"
-    return {"frames_per_s": Ftot * steps / dt, "ms_per_step": dt / steps * 1e3, "ranks": world, "backend": backend, "staged_through_host": bool(ex.stage_through_host),
+    return {"frames_per_s": Ftot * steps / dt, "ms_per_step": dt / steps * 1e3, "ranks": world, "rccl_ranks": rccl_ranks, "backend": backend, "staged_through_host": bool(ex.stage_through_host),
             "chunk_frames": chunk_frames, "chunks_per_step": len(ex.chunks), "root_link_gb_per_s": moved * steps / dt / 1e9, "results_equal_resident_path": same,
             "what": f"rank 0's HBM -> scatter of int32 [chunk][C][S] -> encode hot path on every rank -> gather of residual+params+stats to rank 0; pipelined; {via}"}
 
@@ -477,7 +479,8 @@ def leg_exchange(dist, group, ctx, shape, frames, nsm, res_ref, prm_ref, steps, 
 class Guard:
     """The one JSON line and the deadlines of the optional legs.  run(name, seconds, fn) returns fn()'s record, {"error": ...} if
     it raised; if it has not returned after `seconds`, a watchdog thread records the timeout, prints the line (rank 0) and ends
-    the process -- the legs behind a hung one are not run, the headline in front of it is never lost."""
+    the process with a non-zero code (3, or 2 if a parity check had failed before) -- the legs behind a hung one are not run, the
+    headline in front of it is never lost, and the run still counts as failed: a hang is a finding, not a result."""
 
     def __init__(self, rank):
         self.rank, self.line, self.lock, self.printed, self.exit_code = rank, None, threading.Lock(), False, 0
@@ -504,9 +507,9 @@ class Guard:
                     self.line[name] = rec
                 self.line.setdefault("legs_timed_out", []).append(name)
             self.emit()
-            sys.stderr.write(f"bench.py rank {self.rank}: leg {name} hung; exiting\n")
+            sys.stderr.write(f"bench.py rank {self.rank}: leg {name} hung; exiting with a failure code\n")
             sys.stderr.flush()
-            os._exit(self.exit_code)
+            os._exit(self.exit_code or 3)       # the line is out, but a leg that hung (on the GPU, on a link) is a FAILURE of the run
 
         threading.Thread(target=watch, daemon=True).start()
         try:
@@ -704,6 +707,31 @@ def worker(args):
     enc_s = red_max(time.perf_counter() - t0)
     ctx.enable_timing(False)
 
+    # One more step, UNTIMED, on ONE compute stream: with the default two streams a kernel's HIP-event span includes what the other
+    # half's kernels took of the GPU beside it, so the spans of the timed steps overlap and add up to ~2x the step.  This step's
+    # spans are exclusive -- the figures a `LINNE_AMD_STREAMS=1 rocprofv3 --kernel-trace --stats` summary of the same workload
+    # gives per kernel (profiles/r0N_kernel_stats_one_stream.csv) -- and they pick and price the roofline's kernel.
+    excl_ms = {k: 0.0 for k in KERNEL_KINDS}
+    excl_launches = {k: 0 for k in KERNEL_KINDS}
+    streams_env = os.environ.get("LINNE_AMD_STREAMS")
+    os.environ["LINNE_AMD_STREAMS"] = "1"            # (read per call by the library)
+    try:
+        ctx.enable_timing(True)
+        encode_step()
+        torch.cuda.synchronize()
+        for k in ENCODE_KINDS:
+            m = ctx.last_ms(k)
+            if m > 0:
+                excl_ms[k] = m
+                excl_launches[k] = ctx.last_launches(k)
+        ctx.enable_timing(False)
+    finally:
+        if streams_env is None:
+            del os.environ["LINNE_AMD_STREAMS"]
+        else:
+            os.environ["LINNE_AMD_STREAMS"] = streams_env
+    barrier()
+
     # decode: warm-up, then K timed steps
     decode_step()
     barrier()
@@ -751,39 +779,40 @@ def worker(args):
             except Exception:
                 pmc = {}
 
-        def roof(kinds, exclude=()):
-            """dominant kernel of `kinds` by summed HIP-event time: algorithmic bytes of the channel-frames one launch processes /
-            its average duration, against the HBM peak (DESIGN.md "Measurement")"""
-            cand = [k for k in kinds if k not in exclude and kern_ms[k] > 0]
+        def roof(kinds, ms, launches_of, nsteps, exclude=()):
+            """dominant kernel of `kinds` by summed HIP-event time over `nsteps` steps whose spans do not overlap: algorithmic bytes of
+            the channel-frames one launch processes / its average duration, against the HBM peak (DESIGN.md "Measurement")"""
+            cand = [k for k in kinds if k not in exclude and ms[k] > 0]
             if not cand:
                 return None
-            dom = max(cand, key=lambda k: kern_ms[k])
-            # With two compute streams (the default for a batch of this size) a kernel's HIP-event time includes what the other half's
-            # kernels took of the GPU beside it, and the latency-bound kernels stretch most: the largest SUM is then not the kernel that
-            # does the most work.  The long layer's search is the dominant kernel by exclusive time (profiles/r03b_kernel_stats_one_stream.csv,
-            # LINNE_AMD_STREAMS=1: 24.6 of 83 ms): it is the roofline's kernel whenever it ran.
-            if 25 in cand and 25 in kinds:
-                dom = 25
-            launches = max(1, kern_launches[dom])
-            avg_ms = kern_ms[dom] / launches
+            dom = max(cand, key=lambda k: ms[k])
+            launches = max(1, launches_of[dom])
+            avg_ms = ms[dom] / launches
             # timed spans of one kind per chunk of frames: per-layer kernels have one span per layer they serve
             per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2),
-                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big, 33: nlayers, 34: 1}.get(dom, 1)
-            cf_per_launch = F * nch * args.steps / (launches / per_chunk)
+                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big, 33: nlayers, 34: 1, 35: 1}.get(dom, 1)
+            cf_per_launch = F * nch * nsteps / (launches / per_chunk)
             achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
             per_cf = (pmc.get(KERNEL_KINDS[dom]) or {}).get("hbm_bytes_per_channel_frame_per_launch")
             return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "traffic": per_cf * cf_per_launch if per_cf else None, "traffic_source": pmc_src if per_cf else None,
                     "kernel": KERNEL_KINDS[dom], "avg_launch_ms": avg_ms, "launches": launches, "channel_frames_per_launch": cf_per_launch}
 
-        roofline = roof(ENCODE_KINDS, exclude=(13,))            # k_stats (13) runs beside the analysis
+        # encode: priced on the exclusive spans of the extra one-stream step (see above); k_stats (13) runs beside the analysis
+        roofline = roof(ENCODE_KINDS, excl_ms, excl_launches, 1, exclude=(13,))
         if roofline:
-            roofline["note"] = "algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64"
+            roofline["measured_on"] = ("one extra untimed encode step of the same batch with LINNE_AMD_STREAMS=1 (exclusive per-kernel HIP-event spans on the "
+                                       "launch stream); agrees with the rocprofv3 --kernel-trace --stats summary of the same workload on one stream "
+                                       "(profiles/r04_kernel_stats_one_stream.csv), and with twice the half-batch launches of the two-stream summary")
+            roofline["exclusive_kernel_ms"] = {KERNEL_KINDS[k]: round(excl_ms[k], 3) for k in ENCODE_KINDS if excl_ms[k] > 0}
+            roofline["exclusive_step_ms"] = round(sum(excl_ms[k] for k in ENCODE_KINDS if k != 13), 3)
+            roofline["note"] = ("algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64 "
+                                "(which rests on a CONSTANT multiply-add count per channel-frame, not on a counter)")
         whole = (pmc.get("_whole_step") or {})
         if roofline and whole.get("encode_hbm_bytes_per_channel_frame"):
             roofline["whole_step_traffic_per_channel_frame"] = whole["encode_hbm_bytes_per_channel_frame"]
             roofline["whole_step_traffic_over_algorithmic"] = whole["encode_hbm_bytes_per_channel_frame"] / ALGO_BYTES_PER_CF
-        roofline_decode = roof(DECODE_KINDS)
+        roofline_decode = roof(DECODE_KINDS, kern_ms, kern_launches, args.steps)
         if roofline_decode:
             roofline_decode["note"] = ("algorithmic bytes = 82552 B per channel-frame (residual in, PCM out, parameters) per launch: a layer of the cascade "
                                        "streams the channel-frame in and out once; k_synth_rows is bound by the vector unit's issue rate (a dependent "
@@ -822,7 +851,7 @@ def worker(args):
                                "half's kernels took of the GPU beside it, so the encode kinds add up to about twice ms_per_step"
                                if os.environ.get("LINNE_AMD_STREAMS", "2") != "1" else "summed HIP-event time of each kernel kind per step (one compute stream)"),
             "roofline": roofline, "roofline_decode": roofline_decode, "valu_f64": valu, "cpu_baseline": None, "cpu_baseline_decode": None,
-            "block_at_a_time": None, "end_to_end_api": None, "transports": None,
+            "block_at_a_time": None, "end_to_end_api": None, "transports": None, "rccl_ranks": None, "n1_reference": None, "value_over_n1": None,
             "transports_note": "value = the hot path with every rank's shard resident in its own HBM (contract: inputs resident when the timed "
                                "region starts); transports = the same work with the data starting elsewhere: in pinned host memory of each rank "
                                "(direct_h2d) or in rank 0's HBM (rccl_scatter_gather, N > 1), transfers inside the timed region",
@@ -846,19 +875,25 @@ def worker(args):
         if not everyone.get("ok"):
             guard.exit_code = 2
 
-    # ---- legs on rank 0 at N = 1: the CPU baselines, the block-at-a-time API, the end-to-end API
-    if rank == 0 and world == 1:
+    # ---- legs on rank 0: the CPU baselines at EVERY N (north_star: the reference's CPU path timed on the box's own host cores in the
+    # same run as the 1 / 2 / 4 / 8 GPU figures; the other ranks wait at the barrier below, their GPUs idle -- nothing is timed then),
+    # the block-at-a-time API and the end-to-end API at N = 1
+    if rank == 0:
         ref_blocks = None
         host_frames = None
-        if not args.no_cpu_baseline or not args.no_block_at_a_time:
-            nf = min(F - 1, max(64, host_cores() * args.cpu_frames_per_thread))
+        cores = host_cores(world)
+        if not args.no_cpu_baseline or (world == 1 and not args.no_block_at_a_time):
+            nf = min(F - 1, max(64, cores * args.cpu_frames_per_thread))
             host_frames = frames[:nf].cpu().numpy()
         if not args.no_cpu_baseline:
-            out = guard.run("cpu_baseline", 2 * L, lambda: cpu_baseline(host_frames, bits, rate, block, args.preset, ms, args.cpu_frames_per_thread))
+            out = guard.run("cpu_baseline", 2 * L, lambda: cpu_baseline(host_frames, bits, rate, block, args.preset, ms, args.cpu_frames_per_thread, cores))
             if isinstance(out, dict):
                 line["cpu_baseline"] = out
             else:
                 line["cpu_baseline"], line["cpu_baseline_decode"], ref_blocks = out
+    if world > 1 and not args.no_cpu_baseline:
+        guard.run("cpu_baseline_wait", 2 * L + 30, lambda: dist.barrier() or {})
+    if rank == 0 and world == 1:
         if not args.no_block_at_a_time:
             bat = guard.run("block_at_a_time", L, lambda: block_at_a_time(host_frames, bits, rate, block, args.preset, ms, ref_blocks))
             cpu, cpud = line.get("cpu_baseline") or {}, line.get("cpu_baseline_decode") or {}
@@ -886,6 +921,30 @@ def worker(args):
         def put(name):
             return lambda rec: transports.__setitem__(name, rec)
 
+        n1 = None
+        if world > 1:
+            # the N = 1 figures of the SAME legs, measured by rank 0 alone while the other ranks wait (their GPUs idle): what
+            # `over_n1` below divides by, so the line itself says how the paths that move data scale from 1 to N GPUs
+            def alone():
+                sync = torch.cuda.synchronize
+                for _ in range(max(1, args.warmup)):
+                    encode_step()
+                sync()
+                t1 = time.perf_counter()
+                for _ in range(tsteps):
+                    encode_step()
+                sync()
+                resident = F * tsteps / (time.perf_counter() - t1)
+                d = leg_direct_h2d(ctx, shape, frames, nsm, res, tsteps, chunk, sync, 1, lambda v: v)
+                return {"resident_frames_per_s": resident, "direct_h2d_frames_per_s": d.get("frames_per_s"), "steps": tsteps,
+                        "what": "rank 0 alone (the other ranks wait, their GPUs idle): the resident hot path and the direct_h2d leg at N = 1, same shard, same chunking"}
+            if rank == 0:
+                n1 = guard.run("n1_reference", L, alone)
+                line["n1_reference"] = n1
+                if n1.get("resident_frames_per_s"):
+                    line["value_over_n1"] = line["value"] / n1["resident_frames_per_s"]
+            guard.run("n1_reference_wait", L + 30, lambda: dist.barrier() or {})
+
         transports["direct_h2d"] = guard.run("transports.direct_h2d", L, lambda: leg_direct_h2d(ctx, shape, frames, nsm, res, tsteps, chunk, barrier, world, red_max),
                                              on_timeout=put("direct_h2d"))
         if world > 1:
@@ -901,6 +960,16 @@ def worker(args):
             if not agreed.get("ok") and "error" not in rec:
                 rec = {"error": "another rank failed or timed out in this leg", "this_rank": rec}
             transports[name] = rec
+            if rank == 0:
+                line["rccl_ranks"] = rec.get("rccl_ranks") if isinstance(rec, dict) else None
+        if rank == 0 and n1 and "error" not in n1:
+            for name, rec in transports.items():
+                if isinstance(rec, dict) and rec.get("frames_per_s"):
+                    base = n1.get("direct_h2d_frames_per_s") if name == "direct_h2d" else n1.get("resident_frames_per_s")
+                    if base:
+                        rec["over_n1"] = rec["frames_per_s"] / base
+                        rec["over_n1_base"] = ("n1_reference.direct_h2d_frames_per_s" if name == "direct_h2d" else
+                                               "n1_reference.resident_frames_per_s (with one rank the scatter / gather has nobody to talk to: the leg IS the resident path)")
         torch.cuda.empty_cache()
 
     if rank == 0:

@@ -37,6 +37,15 @@ struct DevClass {
 #define LNN_MAXRUN LNN_MAXCLS
 struct RowRuns { uint32_t n; uint32_t mixed; uint32_t row_begin[LNN_MAXRUN + 1]; uint32_t blk_begin[LNN_MAXRUN + 1]; };   /* mixed: the one-run fallback */
 
+/* timing experiments (never in a release build): LNN_DBG_IS(p, v) is a compile-time false unless the library was built with
+ * make EXPERIMENTS=1 */
+#ifdef LNN_TIMING_EXPERIMENTS
+#define LNN_DBG_IS(p, v) ((p).dbg_maxtr == (v))
+#define LNN_DBG_MAXTR(p) ((p).dbg_maxtr)
+#else
+#define LNN_DBG_IS(p, v) false
+#define LNN_DBG_MAXTR(p) 0u
+#endif
 struct Plan {
     uint32_t C, S, bits, L, R, ms, F, J;
     uint32_t hist;                      /* the long layer's lags come from k_autocorr_hist / k_autocorr_sub where they take the frame (LINNE_AMD_HIST, default 1) */
@@ -65,7 +74,7 @@ struct Plan {
     uint8_t *uncertain;                 /* [J] the order-free sums could not certify the argmin       */
     uint32_t *ucount;                   /* running count of such (job, layer) pairs of the call       */
     unsigned long long *min_margin;     /* bits of the smallest certified relative gap of the call (k_select)        */
-    uint32_t dbg_maxtr;                 /* TIMING EXPERIMENTS ONLY (LINNE_AMD_DBG_MAXTR): the long layer's search evaluates only the first trials; results are wrong */
+    uint32_t dbg_maxtr;                 /* builds with LNN_TIMING_EXPERIMENTS only (make EXPERIMENTS=1; LINNE_AMD_DBG_MAXTR): switches parts of kernels off to time the rest -- results are wrong; a release build compiles every use out (LNN_DBG_IS) */
     uint32_t force_exact;               /* LINNE_AMD_EXACT: flag every search as uncertain              */
     double *lparams;                    /* [J][MAXL][MAXP]             */
     uint32_t *lunits;                   /* [J][MAXL]                   */

@@ -85,7 +85,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -279,7 +279,16 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
     ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", -1);
     { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : (strcmp(e, "rows") == 0 ? 4 : 2))); }
+    /* LINNE_AMD_STREAMS per call: a call may use fewer compute sub-streams than the context created (bench.py times one step on
+     * one stream so that its per-kernel spans do not overlap); it cannot use more */
+    ctx->knob.streams = env_int("LINNE_AMD_STREAMS", 0);
+    if (ctx->knob.streams < 0) ctx->knob.streams = 0;
+#ifdef LNN_TIMING_EXPERIMENTS       /* builds for timing experiments only (make EXPERIMENTS=1): with these set the results are WRONG */
     ctx->knob.dbg_maxtr = (uint32_t)env_int("LINNE_AMD_DBG_MAXTR", 0);
+    ctx->knob.nostats = env_int("LINNE_AMD_DBG_NOSTATS", 0);
+#else
+    ctx->knob.dbg_maxtr = 0; ctx->knob.nostats = 0;
+#endif
 }
 /* span bookkeeping: span_begin/span_end bracket one kernel launch with events when timing is on */
 static int span_begin(LINNEAmdContext *ctx, int kind, hipStream_t st)
@@ -643,12 +652,14 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     }
     /* frame groups ("chunks") rotate over nsub streams, each with its own slice of the arena */
     uint32_t nsub = ctx->nsub > 0 ? (uint32_t)ctx->nsub : 1u;
+    const bool streams_forced = ctx->nsub_forced || ctx->knob.streams > 0;
+    if (ctx->knob.streams > 0 && (uint32_t)ctx->knob.streams < nsub) nsub = (uint32_t)ctx->knob.streams;
     while (nsub > 1 && ((ctx->arena_bytes - 65536) / nsub < per_frame * 2 || num_frames < nsub * 512u)) nsub--;
     /* By default a call is cut in two only if each half still fills the chip and keeps every large-batch kernel form (the rules below
      * go by the jobs of a chunk: k_fwd_loss from 24 576): the halves' latency-bound kernels (Levinson-Durbin, the short layers' search,
      * the selections) then run beside the other half's vector-unit-bound ones -- 83.1 -> 80.1 ms per step on the 60-minute batch
      * (tools/streams_ab.sh).  Smaller batches keep one stream and the context's own (no fork / join around a block-at-a-time call). */
-    if (!ctx->nsub_forced) while (nsub > 1 && (uint64_t)(num_frames / nsub) * C * hs.R < 32768u) nsub--;
+    if (!streams_forced) while (nsub > 1 && (uint64_t)(num_frames / nsub) * C * hs.R < 32768u) nsub--;
     const uint64_t part_bytes = ((ctx->arena_bytes - 65536) / nsub) & ~(uint64_t)255;
     uint64_t chunk = part_bytes / per_frame;
     if (chunk == 0) chunk = 1;
@@ -667,7 +678,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount, 0, sizeof(uint32_t), ctx->stream));
     HIPCHK(ctx, hipMemsetAsync(ctx->d_ucount + 2, 0x7F, 2 * sizeof(uint32_t), ctx->stream));      /* min margin: a huge double (0x7F7F...) */
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->ev[0], ctx->stream)); }
-    const bool use_sub = ctx->nsub > 0 && (nsub > 1 || ctx->nsub_forced);
+    const bool use_sub = ctx->nsub > 0 && (nsub > 1 || (streams_forced && ctx->knob.streams != 1));
     if (use_sub || ctx->has_side) HIPCHK(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (use_sub) for (uint32_t i = 0; i < nsub; i++) HIPCHK(ctx, hipStreamWaitEvent(ctx->sub[i], ctx->ev_start, 0));
     {   /* statistics of every frame of the call: one launch beside the analysis */
@@ -678,7 +689,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         ps.pcm = d_pcm; ps.pcm16 = pcm16; ps.stats = d_stats; ps.cls_of_frame = ctx->d_clsidx; ps.frame_map = ctx->d_map; ps.cls = ctx->d_cls; ps.sintab = ctx->d_sin;
         hipStream_t ss = ctx->stream;
         if (ctx->has_side) { ss = ctx->side; HIPCHK(ctx, hipStreamWaitEvent(ss, ctx->ev_start, 0)); }
-        if (!env_int("LINNE_AMD_DBG_NOSTATS", 0)) {      /* TIMING EXPERIMENTS ONLY: without the statistics the block types are wrong */
+        if (!ctx->knob.nostats) {      /* (always, except in a build for timing experiments: without the statistics the block types are wrong) */
         const int sp_ = span_begin(ctx, 13, ss);
         /* batches: lanes = channel-frames (k_stats_rows); a few channel-frames: a block each (k_stats finishes one block sooner).  LINNE_AMD_STATS_ROWS forces either */
         const bool rows_form = ctx->knob.stats_rows >= 0 ? (ctx->knob.stats_rows != 0) : ((uint64_t)num_frames * C >= 1024u);
@@ -691,6 +702,9 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         span_end(ctx, sp_, ss); }
         if (ss != ctx->stream) HIPCHK(ctx, hipEventRecord(ctx->side_done, ss));
     }
+    /* the chunks are enqueued inside one function so that EVERY way out of the loop -- a failing HIP call, a failing layer pass --
+     * comes by the join below: with sub-streams forked off, the caller may only reuse its buffers once they have drained */
+    auto enqueue_chunks = [&]() -> int {
     uint32_t chunk_index = 0;
     for (uint32_t f0 = 0; f0 < num_frames; f0 += (uint32_t)chunk, chunk_index++) {
         const uint32_t slot = chunk_index % nsub;
@@ -955,6 +969,14 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
             { const int sp2_ = span_begin(ctx, 10, st); hipLaunchKernelGGL(k_quantize, dim3((uint32_t)CF), dim3(64), 0, st, q); hipLaunchKernelGGL(k_fir_cascade, dim3((uint32_t)CF, CF >= 1024u ? 1u : (S + FIN_TILE - 1) / FIN_TILE), dim3(FIN_THREADS), 0, st, q); span_end(ctx, sp2_, st); }
         }
         HIPCHK(ctx, hipGetLastError());
+    }
+    return LNN_OK;
+    };
+    const int loop_ret = enqueue_chunks();
+    if (loop_ret != LNN_OK) {       /* what was forked is waited for before the error goes back (the callers synchronise ctx->stream only) */
+        if (use_sub) for (uint32_t i = 0; i < nsub; i++) (void)hipStreamSynchronize(ctx->sub[i]);
+        if (ctx->has_side) (void)hipStreamSynchronize(ctx->side);
+        return loop_ret;
     }
     if (ctx->has_side) HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_done, 0));
     if (use_sub) {

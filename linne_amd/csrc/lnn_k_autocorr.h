@@ -822,9 +822,9 @@ __global__ __launch_bounds__(NTH) void k_autocorr_prod(Plan p, uint32_t layer, u
                         for (int t = 0; t < NT; t++) { dst[t][i] = px[m] * pw[m][t]; drem[t][i] = prem[m][t]; }     /* (0.0 * 0.0 beyond the frame's end) */
                     }
                 }
-                if (k + 1u < nchunks && p.dbg_maxtr != 103u) prefetch(k + 1u);
+                if (k + 1u < nchunks && !LNN_DBG_IS(p, 103u)) prefetch(k + 1u);
             }
-            if (k >= 1u && k - 1u < nchunks && p.dbg_maxtr != 102u) {                      /* the pairs of chunk k - 1: both samples inside the same unit, else +0.0 (no effect on the bits) */
+            if (k >= 1u && k - 1u < nchunks && !LNN_DBG_IS(p, 102u)) {                      /* the pairs of chunk k - 1: both samples inside the same unit, else +0.0 (no effect on the bits) */
                 const double (*src)[CHUNK + P] = sv[(k - 1u) & 1u];
                 const uint32_t (*rem)[CHUNK + P] = srem[(k - 1u) & 1u];
                 double (*dst)[CHUNK + 2] = sprod[(k - 1u) & 1u];
@@ -846,7 +846,7 @@ __global__ __launch_bounds__(NTH) void k_autocorr_prod(Plan p, uint32_t layer, u
                     }
                 }
             }
-        } else if (k >= 2u && tid < (uint32_t)NCH && p.dbg_maxtr != 101u) {                /* add up chunk k - 2 */
+        } else if (k >= 2u && tid < (uint32_t)NCH && !LNN_DBG_IS(p, 101u)) {                /* add up chunk k - 2 */
             const uint32_t base = (k - 2u) * CHUNK;
             const uint32_t cnt = (na - base < (uint32_t)CHUNK) ? (na - base) : (uint32_t)CHUNK;
             const double *q = sprod[k & 1u][tid];

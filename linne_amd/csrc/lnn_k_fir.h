@@ -68,7 +68,7 @@ __global__ __launch_bounds__(FIR_THREADS, (MODE == 0) ? 3 : 4) void k_fir2(Plan 
     const double *x = p.sig + ((size_t)job * 2 + cur) * p.S;
     const int32_t *xi = p.xint + (size_t)(job / p.R) * p.S;          /* layer 0 reads the pre-emphasised int32 channel (linne_encoder.c:661-663) */
     uint32_t ntr = (MODE != 1) ? c.ntrials[layer] : 1u;
-    if (MODE == 2 && p.dbg_maxtr && ntr > p.dbg_maxtr) ntr = p.dbg_maxtr;
+    if (MODE == 2 && LNN_DBG_MAXTR(p) && ntr > LNN_DBG_MAXTR(p)) ntr = LNN_DBG_MAXTR(p);
     if (MODE == 0 && tid < LNN_MAXT) chain[tid] = 0.0;
     {
         const double *hsrc = (MODE != 1) ? (p.tcoef + (size_t)job * LNN_MAXT * LNN_MAXP) : (p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP);

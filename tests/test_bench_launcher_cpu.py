@@ -1,5 +1,7 @@
 """bench.py's own launcher and its line guard (no GPU needed): `python bench.py --gpus N` starts N ranks itself, a mismatch
-between --gpus and the launcher's WORLD_SIZE fails loudly, and a leg that hangs costs that leg -- never the line."""
+between --gpus and the launcher's WORLD_SIZE fails loudly, and a leg that hangs costs that leg -- never the line -- while the
+process still ends with a failure code.  (The N > 1 line itself -- cpu_baseline, n1_reference, over_n1 -- is checked on the GPU box by
+tests/test_gpu_scale.py::test_bench_two_rank_rehearsal_line_is_complete.)"""
 import json
 import os
 import subprocess
@@ -49,7 +51,7 @@ def test_gpus_must_match_the_launchers_world_size():
     assert r.returncode != 0 and "--gpus 8" in r.stderr
 
 
-def test_a_hung_leg_costs_the_leg_not_the_line():
+def test_a_hung_leg_costs_the_leg_not_the_line_and_fails_the_run():
     code = textwrap.dedent(f"""
         import sys, time
         sys.path.insert(0, {ROOT!r})
@@ -62,9 +64,24 @@ def test_a_hung_leg_costs_the_leg_not_the_line():
         print("not reached")
     """)
     r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=60)
-    assert r.returncode == 0, r.stderr
+    assert r.returncode == 3, r.stderr         # the line is printed, and a hang is still a failure of the run
     lines = r.stdout.strip().splitlines()
     assert len(lines) == 1
     line = json.loads(lines[0])
     assert line["value"] == 1.0 and line["a"] == {"fine": True} and "ZeroDivisionError" in line["b"]["error"]
     assert "timed out" in line["transports"]["rccl"]["error"] and line["legs_timed_out"] == ["transports.rccl"]
+
+
+def test_a_parity_failure_before_a_hang_keeps_its_own_exit_code():
+    code = textwrap.dedent(f"""
+        import sys, time
+        sys.path.insert(0, {ROOT!r})
+        import bench
+        g = bench.Guard(0)
+        g.line = {{"value": 1.0}}
+        g.exit_code = 2
+        g.run("x", 0.3, lambda: time.sleep(60))
+    """)
+    r = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2, r.stderr
+    assert json.loads(r.stdout.strip().splitlines()[-1])["legs_timed_out"] == ["x"]

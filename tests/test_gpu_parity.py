@@ -289,6 +289,23 @@ def test_own_cli_matches_the_reference_cli(tmp_path):
         assert (back / (name + ".wav")).read_bytes() == open(r, "rb").read(), name
 
 
+def _params_from_tap(tap, preset, nch):
+    """the oracle's per-channel parameters as a [C][PARAM_WORDS] record of include/linne_amd.h (pre-emphasis prev x2, coef x2,
+    units, shifts, then the layers' coefficients in filter order)"""
+    rec = np.zeros((nch, linne_amd.PARAM_WORDS), dtype=np.int32)
+    for ch in range(nch):
+        t = tap.ch[ch]
+        rec[ch, 0:2] = list(t.preem_prev); rec[ch, 2:4] = list(t.preem_coef)
+        L = linne_amd.PRESET_LAYERS[preset]
+        rec[ch, 4:4 + len(L)] = list(t.num_units)[:len(L)]
+        rec[ch, 7:7 + len(L)] = list(t.rshift)[:len(L)]
+        off = 10
+        for l, P in enumerate(L):
+            rec[ch, off:off + P] = list(t.coef[l][:P])
+            off += P
+    return rec
+
+
 def _force_decode_form(monkeypatch, kernel):
     """LINNE_AMD_DECODE_KERNEL for a test; `rows` / `rows4`: the throughput form with EIGHT / FOUR channel-frames per wave in the layers of
     <= 16 taps (the batch-size rule would pick four for batches as small as a test's)"""
@@ -300,9 +317,11 @@ def _force_decode_form(monkeypatch, kernel):
 @pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4"])
 @pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
 def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
-    """DecodeFramesDevice picks its kernels by batch size (one wave per channel-frame for small batches; lanes =
-    channel-frames / four lanes per channel-frame for large ones, whose int32 dot products run in FP64).  Both forms must
-    restore the input exactly and agree with the oracle's synthesis, on every preset family, ragged tails included.
+    """DecodeFramesDevice picks its kernels by batch size (a wave per stage of the cascade for small batches; four / eight
+    channel-frames per wave, or lanes = channel-frames, for large ones).  Every form is fed what the ORACLE's encoder wrote
+    (its residual and parameters, not the product's) and must give the oracle's own synthesis of it
+    (oracle_decode_frame_hotpath: libs/linne_decoder/src/linne_decoder.c:503-522, linne_lpc_synthesize.c:8-83) -- which is the input --
+    on every preset family, ragged tails included; then the product's own encode output must decode to the input as well.
     (`rows4`: the throughput form with four channel-frames per wave for the short layers too; `rows` takes eight there.)"""
     _force_decode_form(monkeypatch, kernel)
     ms = nch >= 2
@@ -312,6 +331,22 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
     ns = np.full(F, block, dtype=np.uint32); ns[-1] = tail
     frames[-1, :, tail:] = 0
     shape = ctx.shape(nch, bits, block, preset, ms)
+    ores = np.zeros_like(frames)
+    oprm = np.zeros((F, nch, linne_amd.PARAM_WORDS), dtype=np.int32)
+    want = np.zeros_like(frames)
+    for f in range(F):
+        n = int(ns[f])
+        enc = oracle.encoder(nch, bits, 44100, block, preset, ms)
+        tap, r = enc.hotpath(frames[f][:, :n])
+        enc.close()
+        ores[f, :, :n] = r
+        oprm[f] = _params_from_tap(tap, preset, nch)
+        want[f, :, :n] = oracle.decode_hotpath([tap.ch[ch] for ch in range(nch)], r, bits, block, preset, ms)
+        assert np.array_equal(want[f, :, :n], frames[f, :, :n]), f"frame {f}: the oracle's own round trip"
+    dec = ctx.decode_frames_host(shape, ores, oprm, ns)
+    for f in range(F):
+        n = int(ns[f])
+        assert np.array_equal(dec[f, :, :n], want[f, :, :n]), f"frame {f}: HIP synthesis of the oracle's residual and parameters"
     res, prm, st = ctx.encode_frames_host(shape, frames, ns)
     dec = ctx.decode_frames_host(shape, res, prm, ns)
     for f in range(F):

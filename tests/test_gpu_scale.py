@@ -377,15 +377,82 @@ def test_the_default_two_streams_give_the_one_stream_result(monkeypatch):
     ns[where] = rng.choice(np.array([130, 500, 777, block - 3, block // 2 + 1], dtype=np.uint32), size=300)
     for f in np.flatnonzero(ns < block):
         frames[f, :, int(ns[f]):] = 0
-    out = []
+    out, chunks = [], []
     for streams in (None, "1"):
         if streams:
             monkeypatch.setenv("LINNE_AMD_STREAMS", streams)
         c = linne_amd.Context(0)
         try:
             shape = c.shape(nch, bits, block, preset, True)
+            c.enable_timing(True)
             out.append(c.encode_frames_host(shape, frames, ns))
+            chunks.append(c.last_launches(1))       # k_prep spans = chunks of the call
         finally:
             c.close()
+    assert chunks == [2, 1], f"the default call was not cut in two (chunks per call: {chunks})"
     for a, b, what in zip(out[0], out[1], ("residual", "parameters", "statistics")):
         assert np.array_equal(a, b), what
+
+
+def test_the_default_split_at_the_real_frame_size_against_the_oracle(oracle):
+    """What bench.py's timed batch runs, in small: 8 192 stereo frames of 10 240 samples at -m 7 (65 536 jobs) with NOTHING forced, an
+    arena that holds each half in one chunk (as bench.py's does).  The call must have been cut in two over the two compute streams
+    (the rule at the chunk loop of LINNEAmd_EncodeFramesDevice), every large-batch kernel form must have run, a sample of the output --
+    the first 64 frames, the last 64 with the ragged tail, 128 random ones from both halves -- must equal the oracle's bit for bit
+    (libs/linne_encoder/src/linne_encoder.c:594-752), and the whole batch must decode to the input."""
+    for v in ("LINNE_AMD_STREAMS", "LINNE_AMD_HIST", "LINNE_AMD_FWD_LOSS", "LINNE_AMD_SEARCH_LONG", "LINNE_AMD_DECODE_KERNEL"):
+        assert v not in os.environ
+    F = 8192
+    x = music(NCH, (F - 1) * BLOCK + TAIL, BITS, seed=404)
+    flat = np.zeros((NCH, F * BLOCK), dtype=np.int32)
+    flat[:, :x.shape[1]] = x
+    del x
+    frames = np.ascontiguousarray(flat.reshape(NCH, F, BLOCK).transpose(1, 0, 2))
+    del flat
+    ns = np.full(F, BLOCK, dtype=np.uint32)
+    ns[-1] = TAIL
+    c = linne_amd.Context(0, scratch_bytes=16 << 30)
+    try:
+        c.enable_timing(True)
+        res, prm, st = run_batch(c, frames, ns)
+        assert c.launches[1] == 2, f"chunks of the call: {c.launches[1]} (expected the two halves of the default split)"
+        assert kinds_that_ran(c, (20, 21, 22, 23)) == {20, 21, 22, 23}, c.launches
+        assert c.last_fallback_count() >= 0
+    finally:
+        c.close()
+    idx = sample_indices(F, seed=11)
+    assert any(f < F // 2 for f in idx[64:-64]) and any(f >= F // 2 for f in idx[64:-64])      # both halves sampled in the middle
+    compare_sample(oracle_taps(oracle, frames, ns, idx), ns, res, prm, st, "default split")
+
+
+def test_bench_two_rank_rehearsal_line_is_complete(tmp_path):
+    """`python bench.py --gpus 2` on the one-GPU box (both ranks on device 0, transfers over gloo: BENCH_BACKEND=gloo -- a rehearsal of
+    the N > 1 path, not an RCCL measurement).  The line an 8-GPU run would be judged by must be complete: the reference's CPU encoder
+    and decoder timed in the SAME run (north_star; libs/linne_encoder/src/linne_encoder.c:774-862, libs/linne_decoder/src/linne_decoder.c:564-668),
+    parity on every rank, the N = 1 figures of the transport legs and the ratios over them."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--minutes", "4", "--steps", "2", "--cpu-frames-per-thread", "8", "--scratch-gib", "8"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["scaling"] == "weak"
+    assert line["encode_sample_parity"] is True and line["decode_bit_exact"] is True
+    cpu, cpud = line["cpu_baseline"], line["cpu_baseline_decode"]
+    assert cpu and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["kind"] in ("reference", "port")
+    if cpu["kind"] == "reference":
+        assert cpud and cpud["value"] > 0 and cpud["bit_exact"] is True
+    assert line["hot_path_resident_over_cpu_encodeblock"] > 1
+    n1 = line["n1_reference"]
+    assert n1["resident_frames_per_s"] > 0 and n1["direct_h2d_frames_per_s"] > 0 and line["value_over_n1"] > 0
+    tr = line["transports"]
+    assert tr["direct_h2d"]["over_n1"] > 0 and tr["direct_h2d"]["results_equal_resident_path"] is True
+    ex = tr["gloo_scatter_gather_rehearsal"]
+    assert ex["over_n1"] > 0 and ex["results_equal_resident_path"] is True and ex["ranks"] == 2
+    assert line["rccl_ranks"] is None                 # gloo moved the bytes: nothing may claim RCCL counted ranks
+    assert "legs_timed_out" not in line
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["exclusive_step_ms"] > 0
