@@ -713,6 +713,7 @@ def worker(args):
     # gives per kernel (profiles/r0N_kernel_stats_one_stream.csv) -- and they pick and price the roofline's kernel.
     excl_ms = {k: 0.0 for k in KERNEL_KINDS}
     excl_launches = {k: 0 for k in KERNEL_KINDS}
+    excl_step_ms = None
     streams_env = os.environ.get("LINNE_AMD_STREAMS")
     os.environ["LINNE_AMD_STREAMS"] = "1"            # (read per call by the library)
     try:
@@ -724,6 +725,7 @@ def worker(args):
             if m > 0:
                 excl_ms[k] = m
                 excl_launches[k] = ctx.last_launches(k)
+        excl_step_ms = ctx.last_ms(0)            # the whole call, first event to last, on the context's stream
         ctx.enable_timing(False)
     finally:
         if streams_env is None:
@@ -805,7 +807,9 @@ def worker(args):
                                        "launch stream); agrees with the rocprofv3 --kernel-trace --stats summary of the same workload on one stream "
                                        "(profiles/r04_kernel_stats_one_stream.csv), and with twice the half-batch launches of the two-stream summary")
             roofline["exclusive_kernel_ms"] = {KERNEL_KINDS[k]: round(excl_ms[k], 3) for k in ENCODE_KINDS if excl_ms[k] > 0}
-            roofline["exclusive_step_ms"] = round(sum(excl_ms[k] for k in ENCODE_KINDS if k != 13), 3)
+            roofline["one_stream_step_ms"] = round(excl_step_ms, 3) if excl_step_ms and excl_step_ms > 0 else None
+            roofline["exclusive_kernel_ms_note"] = ("k_stats and, for a ragged tail, k_autocorr2 run on the side stream BESIDE the kernels of the main one: "
+                                                    "their spans are not part of the sum that makes one_stream_step_ms")
             roofline["note"] = ("algorithmic bytes = 82552 B per channel-frame; the kernel is FP64-VALU/latency bound, see valu_f64 "
                                 "(which rests on a CONSTANT multiply-add count per channel-frame, not on a counter)")
         whole = (pmc.get("_whole_step") or {})

@@ -547,6 +547,13 @@ static void layer_forward(struct Layer *L, double *data, uint32_t n)
         }
     }
 }
+/* TEST / MEASUREMENT TAP (tools/search_margins.py): when set, every unit-count search appends one record per trial --
+ * { num_params, nunits, mean loss, largest L1 norm of a unit's coefficients, max |input| } -- so that the margins between the
+ * trials (what a certificate of the argmin has to beat) can be read off without touching the arithmetic */
+static __thread double *g_trial_tap = NULL;
+static __thread uint32_t g_trial_tap_cap = 0, g_trial_tap_n = 0;
+void oracle_set_trial_tap(double *buf, uint32_t cap_records) { g_trial_tap = buf; g_trial_tap_cap = cap_records; g_trial_tap_n = 0; }
+uint32_t oracle_trial_tap_count(void) { return g_trial_tap_n; }
 /* linne_network.c:268-347 */
 static uint32_t layer_search_units(struct Layer *L, struct Lpc *c, const double *input, uint32_t n, uint32_t max_units, double reg)
 {
@@ -578,6 +585,13 @@ static uint32_t layer_search_units(struct Layer *L, struct Lpc *c, const double 
             }
         }
         mean_loss /= n;
+        if (g_trial_tap && g_trial_tap_n < g_trial_tap_cap) {
+            double *rec = g_trial_tap + 5 * (size_t)g_trial_tap_n++, hmax = 0.0, xmax = 0.0;
+            uint32_t k;
+            for (unit = 0; unit < nunits; unit++) { double a = 0.0; for (k = 0; k < np; k++) a += fabs(L->params[unit * np + k]); if (a > hmax) hmax = a; }
+            for (k = 0; k < n; k++) if (fabs(input[k]) > xmax) xmax = fabs(input[k]);
+            rec[0] = L->num_params; rec[1] = nunits; rec[2] = mean_loss; rec[3] = hmax; rec[4] = xmax;
+        }
         if (mean_loss < min_loss) { min_loss = mean_loss; best = nunits; }
     }
     return best;

@@ -114,6 +114,9 @@ uint32_t oracle_huffman_code(uint32_t sym, uint32_t *code);
 
 /* multi-threaded throughput helper for bench.py's cpu_baseline leg ("port"): encodes num_frames frames
  * (planar [frame][ch][block]) with num_threads handles over disjoint frames; returns seconds. */
+/* measurement tap (tools/search_margins.py): records of 5 doubles per trial of every unit-count search of THIS thread from now on */
+void oracle_set_trial_tap(double *buf, uint32_t cap_records);
+uint32_t oracle_trial_tap_count(void);
 double oracle_bench_encode(const struct OracleEncodeParameter *param, const int32_t *frames, uint32_t num_frames,
         uint32_t num_threads, uint64_t *total_bytes);
 

@@ -455,4 +455,4 @@ def test_bench_two_rank_rehearsal_line_is_complete(tmp_path):
     assert ex["over_n1"] > 0 and ex["results_equal_resident_path"] is True and ex["ranks"] == 2
     assert line["rccl_ranks"] is None                 # gloo moved the bytes: nothing may claim RCCL counted ranks
     assert "legs_timed_out" not in line
-    assert line["roofline"]["frac"] > 0 and line["roofline"]["exclusive_step_ms"] > 0
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["one_stream_step_ms"] > 0
