@@ -54,7 +54,7 @@ HBM_PEAK_GBS = 8000.0
 FP64_PEAK_TFLOPS = 78.6             # vector FMA peak; unfused mul+add tops out at half of it on paper
 FP64_UNFUSED_MEASURED_TFLOPS = 32.4 # what tools/ubench/dp_rate.hip sustains with separate multiply and add (profiles/r01_dp_rate.txt)
 ENCODE_KINDS = (1, 3, 4, 5, 6, 7, 8, 9, 10, 13, 14, 15, 16, 18, 19, 20, 21, 22, 23, 25)
-DECODE_KINDS = (11, 12, 30, 31, 32, 33, 34)
+DECODE_KINDS = (11, 12, 30, 31, 32, 33, 34, 35, 36)
 KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocorr2", 4: "k_levinson_lds",
                 5: "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)",
                 25: "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)",
@@ -65,8 +65,10 @@ KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocor
                 11: "k_synthesize (one wave per channel-frame, all layers)", 12: "k_ms_to_lr",
                 30: "k_synth_big<P> (synthesis of the long layer)", 31: "k_synth_small<P> (synthesis of the short layers, de-emphasis)",
                 32: "k_synth_pipe (a wave per stage of the cascade, 16-sample blocks: the latency form)",
-                33: "k_synth_rows<NCH> / k_synth_rows8<PB> (four / eight channel-frames per wave, the old taps on the matrix unit: the throughput form)",
-                34: "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out)"}
+                33: "k_synth_rows<NCH> (a long layer: four channel-frames per wave, the old taps on the matrix unit)",
+                36: "k_synth_rows8<PB> / k_synth_rows<0> (a short layer: eight / four channel-frames per wave)",
+                35: "k_synth_l0_de (layer 0 + de-emphasis + MS -> LR in one launch, tiles in LDS)",
+                34: "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out; LINNE_AMD_DECODE_FUSED=0)"}
 
 
 def synth_track(num_samples, nch, bits, seed, device, rate=44100.0, chunk=1 << 22):
@@ -792,7 +794,7 @@ def worker(args):
             avg_ms = ms[dom] / launches
             # timed spans of one kind per chunk of frames: per-layer kernels have one span per layer they serve
             per_chunk = {25: 1, 3: n_big, 14: nlayers - n_big, 4: nlayers, 5: max(1, nlayers - 2), 15: 1, 6: nlayers, 7: nlayers, 8: max(1, nlayers - 2),
-                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big, 33: nlayers, 34: 1, 35: 1}.get(dom, 1)
+                         16: 1, 21: n_big, 22: n_big, 23: n_big, 30: n_big, 31: nlayers - n_big, 33: n_big, 34: 1, 35: 1, 36: max(1, nlayers - n_big - 1)}.get(dom, 1)
             cf_per_launch = F * nch * nsteps / (launches / per_chunk)
             achieved = ALGO_BYTES_PER_CF * cf_per_launch / (avg_ms * 1e-3) / 1e9
             per_cf = (pmc.get(KERNEL_KINDS[dom]) or {}).get("hbm_bytes_per_channel_frame_per_launch")
@@ -818,15 +820,24 @@ def worker(args):
             roofline["whole_step_traffic_over_algorithmic"] = whole["encode_hbm_bytes_per_channel_frame"] / ALGO_BYTES_PER_CF
         roofline_decode = roof(DECODE_KINDS, kern_ms, kern_launches, args.steps)
         if roofline_decode:
-            roofline_decode["note"] = ("algorithmic bytes = 82552 B per channel-frame (residual in, PCM out, parameters) per launch: a layer of the cascade "
+            roofline_decode["note"] = ("algorithmic bytes = 82552 B per channel-frame (residual in, PCM out, parameters) per launch: a launch of the cascade "
                                        "streams the channel-frame in and out once; k_synth_rows is bound by the vector unit's issue rate (a dependent "
-                                       "recurrence per channel-frame, four channel-frames per wave), not by HBM")
+                                       "recurrence per channel-frame, four channel-frames per wave), not by HBM; frac is the DOMINANT launch's, "
+                                       "per_kernel lists every launch, whole_step_frac prices the step")
             if whole.get("decode_hbm_bytes_per_channel_frame"):
                 roofline_decode["whole_step_traffic_per_channel_frame"] = whole["decode_hbm_bytes_per_channel_frame"]
             # the whole decode step against the same peak: the cascade's layers are launches of their own (each streams the
             # channel-frame in and out once), so the step moves the algorithmic bytes once in nlayers + 1 passes
             roofline_decode["whole_step_achieved"] = ALGO_BYTES_PER_CF * F * nch / (dec_s / args.steps) / 1e9
             roofline_decode["whole_step_frac"] = roofline_decode["whole_step_achieved"] / HBM_PEAK_GBS
+            # every launch of the decode step by itself (the dominant one is `kernel` above): each streams the channel-frame in and out once
+            per = {}
+            for k in DECODE_KINDS:
+                if kern_launches[k] > 0 and kern_ms[k] > 0:
+                    avg = kern_ms[k] / kern_launches[k]
+                    per[KERNEL_KINDS[k]] = {"avg_launch_ms": round(avg, 4), "launches_per_step": kern_launches[k] / args.steps,
+                                            "frac": round(ALGO_BYTES_PER_CF * F * nch / (avg * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            roofline_decode["per_kernel"] = per
         cf_per_s = enc_fps * nch / world        # per GPU
         valu = {"executed_tflops": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12, "reference_equiv_tflops": 2 * MAC_PER_CF_REFERENCE * cf_per_s / 1e12,
                 "peak_fma_tflops": FP64_PEAK_TFLOPS, "frac_of_unfused_peak": 2 * MAC_PER_CF_EXECUTED * cf_per_s / 1e12 / (FP64_PEAK_TFLOPS / 2),

@@ -38,6 +38,7 @@
 #include "lnn_k_train.h"
 #include "lnn_k_decode.h"
 #include "lnn_k_decode_rows.h"
+#include "lnn_k_decode_fused.h"
 #include "lnn_k_finalize.h"
 #include "lnn_k_rice.h"
 
@@ -85,7 +86,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -278,6 +279,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
     ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", -1);
+    ctx->knob.decode_fused = env_int("LINNE_AMD_DECODE_FUSED", 1);
     { const char *e = getenv("LINNE_AMD_DECODE_KERNEL"); ctx->knob.decode_kernel = !e ? 0 : (strcmp(e, "wave") == 0 ? 1 : (strcmp(e, "pipe") == 0 ? 3 : (strcmp(e, "rows") == 0 ? 4 : 2))); }
     /* LINNE_AMD_STREAMS per call: a call may use fewer compute sub-streams than the context created (bench.py times one step on
      * one stream so that its per-kernel spans do not overlap); it cannot use more */
@@ -1022,7 +1024,7 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
         const bool rows_fit = (p.S & 3u) == 0u && ((uintptr_t)d_data & 15u) == 0u;
         const int form = ctx->knob.decode_kernel ? ctx->knob.decode_kernel : (CF < (rows_fit ? 1536u : 6144u) ? 3 : 0);
         const bool use_pipe = (form == 3) && pipe_fits, use_wave = (form == 1) || (form == 3 && !pipe_fits);
-        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows, 34 = k_deemph_lr */
+        /* timing kinds: 11 = k_synthesize (all layers in one launch), 30 = k_synth_big, 31 = k_synth_small, 32 = k_synth_pipe, 33 = k_synth_rows<NCH > 0> (a long layer), 36 = k_synth_rows<0> / k_synth_rows8 (a short layer), 34 = k_deemph_lr, 35 = k_synth_l0_de (layer 0 + de-emphasis + MS -> LR) */
         if (use_pipe) { const int sp_ = span_begin(ctx, 32, ctx->stream); hipLaunchKernelGGL(k_synth_pipe, dim3(CF), dim3(64 * (hs.L + 1)), SP_LDS_BYTES(p.S), ctx->stream, p); span_end(ctx, sp_, ctx->stream); }
         else if (use_wave) { const int sp_ = span_begin(ctx, 11, ctx->stream); hipLaunchKernelGGL(k_synthesize, dim3(CF), dim3(64), 0, ctx->stream, p, 0xFFFFFFFFu, 1u); span_end(ctx, sp_, ctx->stream); }
         else for (int32_t l = (int32_t)hs.L - 1; l >= 0; l--) {
@@ -1030,8 +1032,16 @@ extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const st
             /* k_synth_rows (four channel-frames per wave, the old taps on the matrix unit) takes the layers without de-emphasis whose
              * order is a preset's, when the samples can travel as 16-byte groups (LINNE_AMD_DECODE_KERNEL=lanes: none) */
             const int nch = hs.P[l] <= 16u ? 0 : (hs.P[l] == 32u ? 1 : (hs.P[l] == 64u ? 3 : (hs.P[l] == 128u ? 7 : -1)));
+            if (de && nch == 0 && form != 2 && rows_fit && hs.P[l] <= 4u && ctx->knob.decode_fused) {
+                /* the end of the cascade in ONE launch: layer 0, the de-emphasis and MS -> LR on tiles in LDS (lnn_k_decode_fused.h) */
+                const int sp_ = span_begin(ctx, 35, ctx->stream);
+                if (p.ms && p.C >= 2u && p.C <= 64u && (p.C & (p.C - 1u)) == 0u) { hipLaunchKernelGGL((k_synth_l0_de<true>), dim3(gsmall), dim3(64 * SF_WAVES), 0, ctx->stream, p); ms_done = true; }
+                else hipLaunchKernelGGL((k_synth_l0_de<false>), dim3(gsmall), dim3(64 * SF_WAVES), 0, ctx->stream, p);
+                span_end(ctx, sp_, ctx->stream);
+                continue;
+            }
             if (nch >= 0 && form != 2 && rows_fit) {
-                const int sp_ = span_begin(ctx, 33, ctx->stream);
+                const int sp_ = span_begin(ctx, nch > 0 ? 33 : 36, ctx->stream);
                 const dim3 grows((CF + 3) / 4);
                 switch (nch) {
                 case 0:     /* (LINNE_AMD_DECODE_ROWS8=0 / 1: the four- / eight-channel-frame form whatever the batch) */

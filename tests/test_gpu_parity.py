@@ -308,13 +308,16 @@ def _params_from_tap(tap, preset, nch):
 
 def _force_decode_form(monkeypatch, kernel):
     """LINNE_AMD_DECODE_KERNEL for a test; `rows` / `rows4`: the throughput form with EIGHT / FOUR channel-frames per wave in the layers of
-    <= 16 taps (the batch-size rule would pick four for batches as small as a test's)"""
-    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel in ("rows", "rows4") else kernel)
-    if kernel in ("rows", "rows4"):
-        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "1" if kernel == "rows" else "0")
+    <= 16 taps (the batch-size rule would pick four for batches as small as a test's), layer 0 + de-emphasis + MS -> LR in one launch
+    (k_synth_l0_de); `rows_nf`: the same with those three as launches of their own"""
+    monkeypatch.setenv("LINNE_AMD_DECODE_KERNEL", "rows" if kernel in ("rows", "rows4", "rows_nf") else kernel)
+    if kernel in ("rows", "rows4", "rows_nf"):
+        monkeypatch.setenv("LINNE_AMD_DECODE_ROWS8", "0" if kernel == "rows4" else "1")
+    if kernel == "rows_nf":         # layer 0, the de-emphasis and MS -> LR as launches of their own (k_synth_rows8 + k_deemph_lr) instead of k_synth_l0_de
+        monkeypatch.setenv("LINNE_AMD_DECODE_FUSED", "0")
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4", "rows_nf"])
 @pytest.mark.parametrize("nch,bits,block,preset,tail", [(2, 16, 10240, 7, 9280), (2, 16, 2048, 4, 777), (1, 16, 1024, 0, 130), (8, 24, 4096, 7, 4096), (3, 8, 1024, 2, 1000), (2, 16, 4096, 5, 3001)])
 def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block, preset, tail):
     """DecodeFramesDevice picks its kernels by batch size (a wave per stage of the cascade for small batches; four / eight
@@ -354,7 +357,7 @@ def test_decode_kernels_agree(ctx, oracle, monkeypatch, kernel, nch, bits, block
         assert np.array_equal(dec[f, :, :n], frames[f, :, :n]), f"frame {f}"
 
 
-@pytest.mark.parametrize("kernel", ["rows", "rows4", "lanes", "pipe"])
+@pytest.mark.parametrize("kernel", ["rows", "rows4", "rows_nf", "lanes", "pipe"])
 @pytest.mark.parametrize("nch,bits,block,preset,F", [(2, 16, 2048, 7, 37), (3, 24, 1024, 4, 23), (1, 16, 4096, 5, 70), (8, 16, 1024, 7, 9)])
 def test_decode_forms_with_frames_of_many_lengths_in_one_batch(ctx, monkeypatch, kernel, nch, bits, block, preset, F):
     """a batch as many tracks back to back make it: frames of a dozen lengths in any order (so the four channel-frames of a
@@ -428,7 +431,7 @@ def test_random_configurations_match_the_oracle(product, oracle, monkeypatch, se
     assert ret == 0 and np.array_equal(dec, x)
 
 
-@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4"])
+@pytest.mark.parametrize("kernel", ["wave", "lanes", "pipe", "rows", "rows4", "rows_nf"])
 def test_corrupt_streams_do_not_hang_or_fault(product, oracle, monkeypatch, kernel):
     """with the CRC check off a damaged payload reaches the parser and the GPU with arbitrary parameters (unit counts,
     shifts, coefficients, residuals): decoding must come back with a result code (and the device must stay usable)"""
