@@ -400,6 +400,13 @@ static int upload_lengths(LINNEAmdContext *ctx, const struct LINNEAmdShape *shap
     return LNN_OK;
 }
 
+/* The libm values of the path, behind names of their own so that a test can compare the box's libm with the committed
+ * values of the build container (tests/golden/libm_values.json): were they ever to differ, the test names the cause where the
+ * parity tests would only show hashes that do not match. */
+extern "C" double lnn_welch_divisor(uint32_t unit_samples) { return 4.0 * pow((double)(unit_samples - 1u), -2.0); }                        /* lpc.c:199 */
+extern "C" double lnn_sin_window(uint32_t s, uint32_t n) { return sin((3.1415926535897932384626433832795029 * s) / (n - 1)); }            /* lpc.c:192 */
+extern "C" double lnn_cholesky_pivot(double sum) { return pow(sum, -0.5); }                                                                /* lpc.c:421 */
+
 /* one length class: analysis length, the unit counts each layer may try, their Welch divisors (host libm, lpc.c:199) and
  * the offsets of its tables; returns LNN_INVALID_FORMAT for a length the device path does not take */
 static int make_class(LINNEAmdContext *ctx, const HostShape *hs, uint32_t S, uint32_t n, uint64_t *sin_total, uint64_t *wt_total, DevClass *out)
@@ -417,7 +424,7 @@ static int make_class(LINNEAmdContext *ctx, const HostShape *hs, uint32_t S, uin
         for (uint32_t u = 1; u <= maxu; u <<= 1) {
             if ((hs->P[l] % u) != 0 || (na % u) != 0) continue;      /* linne_network.c:291-294 */
             c.trial_u[l][nt] = u;
-            c.trial_div[l][nt] = 4.0 * pow((double)(na / u - 1u), -2.0);   /* lpc.c:199 */
+            c.trial_div[l][nt] = lnn_welch_divisor(na / u);               /* lpc.c:199 */
             c.wt_off[l][nt] = (uint32_t)*wt_total;
             { const uint32_t pu = hs->P[l] / u; *wt_total += na / u + (pu > 4 ? pu : 4); *wt_total = (*wt_total + 3u) & ~(uint64_t)3u; }   /* tables start 32-byte aligned */
             nt++;
@@ -491,7 +498,7 @@ static int build_classes(LINNEAmdContext *ctx, const struct LINNEAmdShape *shape
         for (uint32_t k = 0; k < ctx->sig_ncls; k++) {
             const DevClass &c = ctx->sig_cls[k];
             const uint32_t n = c.n;
-            for (uint32_t s = 0; s < n; s++) tab[c.sin_off + s] = sin((3.1415926535897932384626433832795029 * s) / (n - 1));   /* lpc.c:192 */
+            for (uint32_t s = 0; s < n; s++) tab[c.sin_off + s] = lnn_sin_window(s, n);   /* lpc.c:192 */
             /* Welch weights per trial over one padded unit (lpc.c:199-204): w[loc] = (div * h) * (n-1-h), h = min(loc, n-1-loc);
              * zero in the zero zone; the (never written) middle of an odd unit is handled on the device (Q1) */
             for (uint32_t l = 0; l < hs->L; l++)
@@ -798,7 +805,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                     hipLaunchKernelGGL(k_af_pivot, dim3((nprob + 63) / 64), dim3(64), 0, st, q, l, i);
                     HIPCHK(ctx, hipMemcpyAsync(ctx->af_h, q.af_pivot, sizeof(double) * (size_t)nprob, hipMemcpyDeviceToHost, st));
                     HIPCHK(ctx, hipStreamSynchronize(st));
-                    for (uint32_t k = 0; k < nprob; k++) { const double v = ctx->af_h[k]; ctx->af_h[k] = (v <= 0.0) ? -1.0 : pow(v, -0.5); }      /* lpc.c:418-421, host libm */
+                    for (uint32_t k = 0; k < nprob; k++) { const double v = ctx->af_h[k]; ctx->af_h[k] = (v <= 0.0) ? -1.0 : lnn_cholesky_pivot(v); }      /* lpc.c:418-421, host libm */
                     HIPCHK(ctx, hipMemcpyAsync(q.af_pivot, ctx->af_h, sizeof(double) * (size_t)nprob, hipMemcpyHostToDevice, st));
                     hipLaunchKernelGGL(k_af_column, dim3(nprob), dim3(128), 0, st, q, l, i);
                 }

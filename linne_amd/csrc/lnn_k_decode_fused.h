@@ -18,6 +18,11 @@
 #ifndef LNN_K_DECODE_FUSED_H_INCLUDED
 #define LNN_K_DECODE_FUSED_H_INCLUDED
 
+#if defined(SF_EXP) && SF_EXP == 3
+#define defined_SF_EXP3 true
+#else
+#define defined_SF_EXP3 false
+#endif
 #define SF_PROD 8                          /* producer waves (layer 0): eight channel-frames each */
 #define SF_WAVES (SF_PROD + 3)             /* + the de-emphasis wave + two waves that load and store */
 #define SF_STRIDE 65u                      /* words from a tile row to the next */
@@ -103,6 +108,9 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
 #pragma unroll 1
             do {
                 int32_t *const cell = trow + ((m >> 3) & 3u) * SF_TILE + 8u * (m & 7u);
+#if defined(SF_EXP) && SF_EXP == 2
+                m++; if ((m & 7u) == 0u) __syncthreads(); continue;
+#endif
                 const int32_t res = *cell;
                 const uint32_t acc0 = half_l + accB;
                 uint32_t acc = acc0, nb = 0;
@@ -140,8 +148,12 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
         const int32_t c0e = rec[LINNE_AMD_PRM_PCOEF + 0], c1e = rec[LINNE_AMD_PRM_PCOEF + 1];
         int32_t zp = rec[LINNE_AMD_PRM_PREV + 1], yp = rec[LINNE_AMD_PRM_PREV + 0];
         int32_t *const trow = &tile[0][0] + lane * SF_STRIDE;
+        /* the one serial piece of a tile -- 64 dependent steps -- sets the block's pace if it has to queue for issue slots behind the
+         * eight producer waves: it goes first */
+        __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (uint32_t t = 0; t < ntiles + 3u; t++) {
+#if !defined(SF_EXP) || SF_EXP != 1
             if (t >= 2u && t - 2u < ntiles) {
                 int32_t *tl = trow + ((t - 2u) & 3u) * SF_TILE;
 #pragma unroll 16
@@ -152,61 +164,68 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
                     tl[s] = y;
                 }
             }
+#endif
             __syncthreads();
         }
         return;
     }
     {
-        /* ---- load and store: wave 9 the block's channel-frames 0 .. 31, wave 10 the others; an instruction moves 16 bytes per lane =
-         * 64 samples of four channel-frames ---- */
+        /* ---- load and store: an instruction moves 16 bytes per lane = 64 samples of four channel-frames.  Instruction kk of wave
+         * 9 + h takes the block's channel-frames r = 8 (4 h + lane / 16) + kk: their tile rows rho = 8 kk + 4 h + lane / 16 lie 8 rows
+         * apart from one instruction to the next (constant offsets from one address register), a lane's four samples of the four
+         * rows hit 64 different banks, and a frame's channels 0 and 1 (r and r ^ 1) are the SAME lane's instructions kk and kk ^ 1:
+         * MS -> LR needs no second read ---- */
         const uint32_t h = wave - (uint32_t)SF_PROD - 1u, rq = lane >> 4, i4 = 4u * (lane & 15u);
+        const uint32_t rbase = 8u * (4u * h + rq);                 /* my rows: rbase + kk */
         int32_t *blk = p.data + (size_t)row0 * S;
+        int32_t *const tl0 = &tile[0][0] + (4u * h + rq) * SF_STRIDE + i4;      /* row kk of tile b: tl0[b SF_TILE + 8 kk SF_STRIDE] */
+        __builtin_amdgcn_s_setprio(2);                             /* (the next tile's loads should be on their way early) */
         lnn_v4i pre[8];
         auto issue = [&](uint32_t t) {
             const uint32_t s0 = t * 64u + i4;
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
-                const uint32_t r = 4u * (8u * h + (uint32_t)kk) + rq, rr = (r < nv) ? r : nv - 1u;
-                pre[kk] = (s0 < S) ? *(const lnn_v4i *)(blk + (rr * S + s0)) : lnn_v4i{ 0, 0, 0, 0 };      /* (S is a multiple of 4; a 32-bit offset from the block's uniform base: one address register per row) */
+                const uint32_t r = rbase + (uint32_t)kk, rr = (r < nv) ? r : nv - 1u;
+                pre[kk] = (s0 < S) ? *(const lnn_v4i *)(blk + (rr * S + s0)) : lnn_v4i{ 0, 0, 0, 0 };      /* (S is a multiple of 4; a 32-bit offset from the block's uniform base) */
             }
         };
         auto commit = [&](uint32_t t) {
-            int32_t *tb = &tile[t & 3u][0];
+            int32_t *tb = tl0 + (t & 3u) * SF_TILE;
 #pragma unroll
             for (int kk = 0; kk < 8; kk++) {
-                const uint32_t r = 4u * (8u * h + (uint32_t)kk) + rq;
-                int32_t *w = tb + sf_rho(r) * SF_STRIDE + i4;
+                int32_t *w = tb + 8u * (uint32_t)kk * SF_STRIDE;
                 w[0] = pre[kk][0]; w[1] = pre[kk][1]; w[2] = pre[kk][2]; w[3] = pre[kk][3];
             }
         };
+        /* FUSE_MS: channel of row rbase + kk (C is a power of two; row0 a multiple of 64 >= C) */
+        const bool ms_rows = FUSE_MS && ((rbase & (C - 1u) & ~7u) == 0u);       /* my rows hold channels 0 .. 7 of a frame (C <= 8: always) */
         if (ntiles) issue(0);
 #pragma unroll 1
         for (uint32_t t = 0; t < ntiles + 3u; t++) {
-            if (t >= 3u) {                                         /* tile t - 3 leaves */
+            if (t >= 3u && !(defined_SF_EXP3)) {                   /* tile t - 3 leaves */
                 const uint32_t to = t - 3u, s0 = to * 64u + i4;
-                const int32_t *tb = &tile[to & 3u][0];
+                const int32_t *tb = tl0 + (to & 3u) * SF_TILE;
 #pragma unroll
-                for (int kk = 0; kk < 8; kk++) {
-                    const uint32_t r = 4u * (8u * h + (uint32_t)kk) + rq;
-                    const int32_t *w = tb + sf_rho(r) * SF_STRIDE + i4;
-                    lnn_v4i v = { w[0], w[1], w[2], w[3] };
-                    if (FUSE_MS) {                                 /* row0 is a multiple of C: channels 0 and 1 of a frame are the rows r and r ^ 1 of this block */
-                        const uint32_t ch = r & (C - 1u);
-                        if (ch < 2u) {
-                            const int32_t *o = tb + sf_rho(r ^ 1u) * SF_STRIDE + i4;
+                for (int kp = 0; kp < 4; kp++) {                   /* rows 2 kp and 2 kp + 1 */
+                    const int32_t *wa = tb + 8u * (uint32_t)(2 * kp) * SF_STRIDE, *wb = wa + 8u * SF_STRIDE;
+                    lnn_v4i va = { wa[0], wa[1], wa[2], wa[3] }, vb = { wb[0], wb[1], wb[2], wb[3] };
+                    if (FUSE_MS && ms_rows && ((uint32_t)(2 * kp) & (C - 1u)) == 0u) {      /* (va, vb) = (mid, side) of a frame: linne_utility.c:135-147 */
 #pragma unroll
-                            for (int j = 0; j < 4; j++) {
-                                const uint32_t m_ = (uint32_t)(ch ? o[j] : v[j]), sd = (uint32_t)(ch ? v[j] : o[j]);
-                                const uint32_t l = m_ - (uint32_t)((int32_t)sd >> 1);
-                                v[j] = (int32_t)(ch ? sd + l : l);
-                            }
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t l = (uint32_t)va[j] - (uint32_t)(vb[j] >> 1);
+                            va[j] = (int32_t)l; vb[j] = (int32_t)((uint32_t)vb[j] + l);
                         }
                     }
-                    if (r < nv) {
-                        const uint32_t nr = nlen[r];
-                        int32_t *gp = blk + (r * S + s0);
-                        if (s0 + 3u < nr) *(lnn_v4i *)gp = v;
-                        else { if (s0 < nr) gp[0] = v[0]; if (s0 + 1u < nr) gp[1] = v[1]; if (s0 + 2u < nr) gp[2] = v[2]; }
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const uint32_t r = rbase + (uint32_t)(2 * kp + e);
+                        const lnn_v4i v = e ? vb : va;
+                        if (r < nv) {
+                            const uint32_t nr = nlen[r];
+                            int32_t *gp = blk + (r * S + s0);
+                            if (s0 + 3u < nr) *(lnn_v4i *)gp = v;
+                            else { if (s0 < nr) gp[0] = v[0]; if (s0 + 1u < nr) gp[1] = v[1]; if (s0 + 2u < nr) gp[2] = v[2]; }
+                        }
                     }
                 }
             }

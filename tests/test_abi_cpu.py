@@ -188,3 +188,37 @@ def test_decoder_contracts_and_host_only_blocks(api, oracle):
             assert L.LINNEDecoder_DecodeBlock(dec, bad.ctypes.data, bad.size, ptrs, 2, 2048, C.byref(dsz), C.byref(dn)) == CORRUPTION
             assert L.LINNEDecoder_DecodeBlock(dec, data[30:].ctypes.data, 100, ptrs, 2, 2048, C.byref(dsz), C.byref(dn)) == INSUFFICIENT_DATA
     L.LINNEDecoder_Destroy(dec)
+
+
+def libm_values_of_this_box():
+    """(what, key, the product's host value, this box's libm value through ctypes, the committed value of the build container)
+    for every entry of tests/golden/libm_values.json (lpc.c:192,199,421)"""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "libm_values.json")))
+    m = C.CDLL("libm.so.6")
+    m.pow.restype = C.c_double; m.pow.argtypes = [C.c_double, C.c_double]
+    m.sin.restype = C.c_double; m.sin.argtypes = [C.c_double]
+    lib = linne_amd.lib
+    lib.lnn_welch_divisor.restype = C.c_double; lib.lnn_welch_divisor.argtypes = [C.c_uint32]
+    lib.lnn_sin_window.restype = C.c_double; lib.lnn_sin_window.argtypes = [C.c_uint32, C.c_uint32]
+    lib.lnn_cholesky_pivot.restype = C.c_double; lib.lnn_cholesky_pivot.argtypes = [C.c_double]
+    for k, v in gold["welch_divisor"].items():
+        yield "Welch divisor 4 pow(n - 1, -2), n =", k, lib.lnn_welch_divisor(int(k)), 4.0 * m.pow(float(int(k) - 1), -2.0), float.fromhex(v)
+    for k, v in gold["sin_window"].items():
+        s, n = (int(t) for t in k.split("/"))
+        yield "SIN window sin(pi s / (n - 1)), s/n =", k, lib.lnn_sin_window(s, n), m.sin((3.1415926535897932384626433832795029 * s) / (n - 1)), float.fromhex(v)
+    for k, v in gold["cholesky_pivot"].items():
+        x = float.fromhex(k)
+        yield "Cholesky pivot pow(x, -0.5), x =", k, lib.lnn_cholesky_pivot(x), m.pow(x, -0.5), float.fromhex(v)
+
+
+def test_host_libm_values_are_the_build_containers():
+    """The path takes its transcendental values from the host's libm (lpc.c:192,199,421).  If this box's libm -- or the way the
+    library's host code was compiled -- gave other bits than the container the golden streams were made in, every stream hash would
+    differ and nothing would say why: this test names the value."""
+    n = 0
+    for what, key, product, box, committed in libm_values_of_this_box():
+        assert box.hex() == committed.hex(), f"this box's libm differs from the build container's: {what} {key}: {box.hex()} vs {committed.hex()}"
+        assert product.hex() == committed.hex(), f"liblinne_amd's host value differs: {what} {key}: {product.hex()} vs {committed.hex()}"
+        n += 1
+    assert n > 100

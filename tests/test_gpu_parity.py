@@ -975,3 +975,10 @@ def test_prep_and_statistics_forms_agree(ctx, product, oracle, monkeypatch, stat
                         music(2, 3 * block + 555, 16, seed=32)], axis=1)
     for preset in (7, 0):
         assert product.encode_whole(x, 16, 44100, block, preset, True) == oracle.encode_whole(x, 16, 44100, block, preset, True)
+
+
+def test_host_libm_values_on_the_gpu_box():
+    """SURVEY 7.5 item 6 on the box the parity tests run on: its libm, and the library's host code, give the committed Welch divisors,
+    SIN-window samples and Cholesky pivots bit for bit (tests/golden/libm_values.json) -- a mismatch here explains 162 differing hashes"""
+    from test_abi_cpu import test_host_libm_values_are_the_build_containers
+    test_host_libm_values_are_the_build_containers()
