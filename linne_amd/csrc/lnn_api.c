@@ -20,7 +20,8 @@
 #include <unistd.h>
 
 #define LNN_ALIGN 16u
-#define LNN_SLOTS 4u                    /* groups of frames in flight in EncodeWhole / DecodeWhole */
+#define LNN_ENC_SLOTS 4u               /* EncodeWhole rotates its groups over four slots per device (a slot is a GPU-sized group) */
+#define LNN_SLOTS 8u                    /* groups of frames in flight in EncodeWhole / DecodeWhole */
 #define ALIGN_UP(v) (((v) + (LNN_ALIGN - 1u)) & ~(uintptr_t)(LNN_ALIGN - 1u))
 
 
@@ -372,7 +373,7 @@ LINNEApiResult LINNEEncoder_EncodeWhole(struct LINNEEncoder *encoder, const int3
         gbase[g_] = pos;        /* = F */
     }
     /* group g goes to device g mod ndev, slot (g / ndev) mod nslots of that device: ndev * nslots groups in flight */
-    nslots = (ngroups + ndev - 1) / ndev; if (nslots > LNN_SLOTS) nslots = LNN_SLOTS;
+    nslots = (ngroups + ndev - 1) / ndev; if (nslots > LNN_ENC_SLOTS) nslots = LNN_ENC_SLOTS;
     window = ndev * nslots;
     if (F > 32) for (f = 0; f < ndev; f++) (void)LINNEAmd_ReserveScratch(gp->ctx[f], LINNEAmd_ScratchBytesPerFrame(&encoder->shape) * group + (1ull << 20));     /* a group = one launch chunk */
     if ((ret = want_slots(gp, &encoder->shape, group, nslots, 1)) != 0) {
@@ -604,6 +605,29 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
     }
     free(tmp);
 }
+/* int16 -> int32 into the caller's planes with streaming stores: the destination (1.27 GB per 60-minute stereo stream) is written
+ * once and not read here, so fetching its lines for ownership first would be half again the memory traffic of the scatter */
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void widen16_avx2(int32_t *dst, const int16_t *src, uint32_t n)
+{
+    uint32_t i = 0;
+    while (i < n && ((uintptr_t)(dst + i) & 31u)) { dst[i] = src[i]; i++; }
+    for (; i + 16u <= n; i += 16u) {
+        const __m256i a = _mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i *)(src + i)));
+        const __m256i b = _mm256_cvtepi16_epi32(_mm_loadu_si128((const __m128i *)(src + i + 8u)));
+        _mm256_stream_si256((__m256i *)(dst + i), a); _mm256_stream_si256((__m256i *)(dst + i + 8u), b);
+    }
+    for (; i < n; i++) dst[i] = src[i];
+    _mm_sfence();
+}
+static void widen16(int32_t *dst, const int16_t *src, uint32_t n)
+{
+    static int have = -1;
+    uint32_t i;
+    if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
+    if (have && n >= 64u) { widen16_avx2(dst, src, n); return; }
+    for (i = 0; i < n; i++) dst[i] = src[i];
+}
 static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
 {
     struct unpack_job *j = arg;
@@ -620,9 +644,7 @@ static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
                 for (s_ = 0; s_ < g->ns[f]; s_++) dst[s_] = (int32_t)((uint32_t)src[3u * s_] | ((uint32_t)src[3u * s_ + 1u] << 8)) | ((int32_t)(int8_t)src[3u * s_ + 2u] << 16);
             } else if (j->s16) {        /* the PCM came back as int16: widen on the way into the caller's planes */
                 const int16_t *src = j->s16 + ((size_t)g->cidx[f] * C + ch) * S;
-                int32_t *dst = j->buffer[ch] + g->prog[f];
-                uint32_t s_;
-                for (s_ = 0; s_ < g->ns[f]; s_++) dst[s_] = src[s_];
+                widen16(j->buffer[ch] + g->prog[f], src, g->ns[f]);
             } else memcpy(j->buffer[ch] + g->prog[f], j->sdata + ((size_t)g->cidx[f] * C + ch) * S, sizeof(int32_t) * g->ns[f]);
         }
     }
@@ -693,16 +715,23 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
         group = default_group((F + ndev - 1) / ndev, &decoder->shape, &decoder->layers, 0); if (group > F) group = F ? F : 1;
     }
     if (stream_mode) {
-        /* The device's Rice decoder and the synthesis are serial per block / per channel: a launch takes as long for 3 000 blocks as
-         * for 30 000 (9 + 11 ms), so the stream goes in FEW groups -- two per device, the second one's host parsing and Rice
-         * decoding beside the first one's synthesis (LINNE_AMD_DECODE_GROUPS) */
+        /* The device's Rice decoder is serial per block: a launch takes ~9 ms for 300 blocks as for 30 000 -- a LATENCY, not a cost:
+         * the groups' launches run side by side on the slots' own streams.  What bounds the call is the host's work (parsing 10 ms +
+         * widening the PCM into the caller's planes 10 ms per 60-minute stream on 16 threads) and the PCIe link (1.1 GB at 57 GB/s,
+         * both directions share it: tools/pcie_bw.py), so the stream goes in EIGHT groups per device (LINNE_AMD_DECODE_GROUPS), every
+         * one with a slot of its own: all are parsed and submitted back to back, and a group is scattered as soon as it is back while
+         * the later ones are still on the link or in the decoder */
         const char *eg = getenv("LINNE_AMD_DECODE_GROUPS");
         const uint32_t S_ = decoder->shape.num_samples_per_block, F_ = (uint32_t)(((uint64_t)hd->num_samples + S_ - 1) / S_);
-        const uint32_t ng = (eg && atoi(eg) > 0) ? (uint32_t)atoi(eg) : 2u;
+        const uint32_t ng = (eg && atoi(eg) > 0) ? (uint32_t)atoi(eg) : 8u;
         const uint64_t cap = (1ull << 30) / ((uint64_t)decoder->shape.num_channels * S_ * sizeof(int32_t)) + 1;
+        /* a group keeps the synthesis in its throughput form (from 1536 channel-frames on, lnn_device.hip) */
+        const uint32_t floor_ = (1536u + decoder->shape.num_channels - 1u) / decoder->shape.num_channels < 256u ? 256u : (1536u + decoder->shape.num_channels - 1u) / decoder->shape.num_channels;
         uint32_t g_ = (F_ + ng * ndev - 1) / (ng * ndev);
+        if (g_ < floor_) g_ = floor_;
         if (g_ > cap) g_ = (uint32_t)cap;
-        if (g_ > group && !getenv("LINNE_AMD_GROUP")) group = g_;
+        if (g_ > F_) g_ = F_ ? F_ : 1u;
+        if (!getenv("LINNE_AMD_GROUP")) group = g_;
         nslots = (((F_ + group - 1) / group) + ndev - 1) / ndev;          /* slots per device: as many as it will see groups */
         if (nslots < 1) nslots = 1;
         if (nslots > LNN_SLOTS) nslots = LNN_SLOTS;
@@ -713,7 +742,13 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;
     off = LINNE_HEADER_SIZE; produced = 0; consumed_groups = 0; progress = 0; scanning = 1; ret = LNN_OK;
     while (scanning || consumed_groups < produced) {
-        if (scanning && produced - consumed_groups < window && progress < hd->num_samples && off < data_size) {
+        const int can_produce = scanning && produced - consumed_groups < window && progress < hd->num_samples && off < data_size;
+        int oldest_back = 0;                /* the oldest group in flight is back already: its PCM goes out before more is parsed */
+        if (consumed_groups < produced) {
+            struct dgroup *og = &grp[consumed_groups % window];
+            oldest_back = !og->ncomp || LINNEAmd_SlotQuery(gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % nslots]) != 0;
+        }
+        if (can_produce && !oldest_back) {
             struct dgroup *g = &grp[produced % window];
             struct LINNEAmdSlot *sl;
             uint32_t scan_progress = progress, ncomp = 0;
@@ -778,7 +813,7 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
             produced++;
             continue;
         }
-        scanning = 0;
+        if (!can_produce) scanning = 0;     /* (armed again below once a slot is free, if the stream goes on) */
         if (consumed_groups < produced) {
             struct dgroup *g = &grp[consumed_groups % window];
             struct LINNEAmdSlot *sl = gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % nslots];

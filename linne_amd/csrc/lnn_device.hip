@@ -1456,6 +1456,16 @@ extern "C" int LINNEAmd_SlotWait(struct LINNEAmdSlot *s)
     return LNN_OK;
 }
 
+extern "C" int LINNEAmd_SlotQuery(struct LINNEAmdSlot *s)
+{
+    if (!s) return -1;
+    if (!s->pending) return 1;
+    const hipError_t e = hipEventQuery(s->ev_done);
+    if (e == hipSuccess) return 1;
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
+    return -1;                           /* (LINNEAmd_SlotWait reports it) */
+}
+
 extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t *num_samples, uint32_t num_frames)
 {
     if (!s || !s->for_encode) return LNN_INVALID_ARGUMENT;
