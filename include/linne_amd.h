@@ -210,9 +210,6 @@ uint32_t  LINNEAmd_SlotCapacity(const struct LINNEAmdSlot *slot);
 int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
 int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *slot, const uint32_t *num_samples, uint32_t num_frames);
 int LINNEAmd_SlotWait(struct LINNEAmdSlot *slot);
-/* without blocking: 1 = nothing of the slot's last submit is still on its way (LINNEAmd_SlotWait would return at once), 0 = it is,
- * negative = the query itself failed (LINNEAmd_SlotWait reports the error) */
-int LINNEAmd_SlotQuery(struct LINNEAmdSlot *slot);
 
 /* Several GPUs from ONE process (the "direct per-GPU H2D/D2H" transport).  The reference has nothing like
  * it: its caller loops over blocks in one thread (tools/linne_codec/linne_codec.c:133-161).  Frames are independent on this path

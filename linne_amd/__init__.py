@@ -45,7 +45,7 @@ AMD_SYMBOLS = [
     "LINNEAmd_MultiContext", "LINNEAmd_MultiGetLastError", "LINNEAmd_MultiEncodeFramesHost", "LINNEAmd_MultiDecodeFramesHost", "LINNEAmd_SlotCreate", "LINNEAmd_SlotDestroy", "LINNEAmd_SlotPcm", "LINNEAmd_SlotData", "LINNEAmd_SlotParams", "LINNEAmd_SlotStats",
     "LINNEAmd_SlotCapacity", "LINNEAmd_SlotRicePlan", "LINNEAmd_SlotCreateEx", "LINNEAmd_SlotFlags", "LINNEAmd_SlotPcm16", "LINNEAmd_SlotPacked", "LINNEAmd_SlotOffsets",
     "LINNEAmd_SlotFetchResidual", "LINNEAmd_SlotStream", "LINNEAmd_SlotStreamCapacity", "LINNEAmd_SlotBitPos", "LINNEAmd_SlotEndBits", "LINNEAmd_SlotPcm16Valid",
-    "LINNEAmd_SlotPcmWidth", "LINNEAmd_SlotDecodeStreamSubmit", "LINNEAmd_SlotFetchPcm32", "LINNEAmd_RiceDecodeDevice", "LINNEAmd_SlotBitEnd", "LINNEAmd_LastDecodeWholeMode", "LINNEAmd_RiceEmitDevice", "LINNEAmd_PackFramesEmitted", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait", "LINNEAmd_SlotQuery",
+    "LINNEAmd_SlotPcmWidth", "LINNEAmd_SlotDecodeStreamSubmit", "LINNEAmd_SlotFetchPcm32", "LINNEAmd_RiceDecodeDevice", "LINNEAmd_SlotBitEnd", "LINNEAmd_LastDecodeWholeMode", "LINNEAmd_RiceEmitDevice", "LINNEAmd_PackFramesEmitted", "LINNEAmd_RicePlanDevice", "LINNEAmd_PackFramesPlanned", "LINNEAmd_SlotEncodeSubmit", "LINNEAmd_SlotDecodeSubmit", "LINNEAmd_SlotWait",
 ]
 
 

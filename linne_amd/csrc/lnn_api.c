@@ -567,7 +567,7 @@ LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint
  * entropy-decoded, then scatter the PCM into the caller's planes ---- */
 struct dgroup {
     uint32_t nblk, ncomp; int streamed; uint64_t seg_first, seg_bytes;
-    uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn, *cons; int *rets;
+    uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn, *cons, *bsz /* the block's bytes by its size field (the scan) */; int *rets;
 };
 struct unpack_job {
     const struct LINNEDecoder *dec; const uint8_t *data; struct dgroup *g; int32_t *sdata, *sprm; int32_t **buffer;
@@ -586,6 +586,9 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
     for (f = first; f < first + count; f++) {
         if (g->cidx[f] != 0xFFFFFFFFu && j->sstream) {      /* stream mode: header, CRC and parameters here, the Rice code on the device */
             uint64_t rbit = 0;
+            /* the block's bytes go to the slot's pinned stream buffer by the thread that checks its CRC next: the second reader
+             * finds them in its cache (a pass of its own over the group cost a third of the parsing: 0.48 GB more from memory) */
+            memcpy(j->sstream + (g->offs[f] - j->seg_first), j->data + g->offs[f], g->bsz[f]);
             g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
                     &g->types[f], &g->ns[f], &g->cons[f], NULL, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS, &rbit);
             j->sbitpos[g->cidx[f]] = (g->offs[f] - j->seg_first) * 8u + rbit;
@@ -649,23 +652,17 @@ static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
         }
     }
 }
-static void copy_segment(void *arg, uint32_t first, uint32_t count)     /* the group's bytes -> the slot's pinned stream buffer, 1 MiB pieces */
-{
-    struct unpack_job *j = arg;
-    const uint64_t a = (uint64_t)first << 20, b0 = (uint64_t)(first + count) << 20, b = (b0 < j->seg_bytes) ? b0 : j->seg_bytes;
-    if (a < b) memcpy(j->sstream + a, j->data + j->seg_first + a, b - a);
-}
 static int dgroup_alloc(struct dgroup *g, uint32_t n)
 {
     memset(g, 0, sizeof(*g));
     g->offs = malloc(sizeof(*g->offs) * n); g->avail = malloc(sizeof(*g->avail) * n); g->room = malloc(sizeof(uint32_t) * n);
     g->types = malloc(sizeof(uint32_t) * n); g->ns = malloc(sizeof(uint32_t) * n); g->prog = malloc(sizeof(uint32_t) * n);
-    g->cidx = malloc(sizeof(uint32_t) * n); g->cn = malloc(sizeof(uint32_t) * n); g->rets = malloc(sizeof(int) * n); g->cons = malloc(sizeof(uint32_t) * n);
-    return (g->offs && g->avail && g->room && g->types && g->ns && g->prog && g->cidx && g->cn && g->rets && g->cons) ? 0 : -1;
+    g->cidx = malloc(sizeof(uint32_t) * n); g->cn = malloc(sizeof(uint32_t) * n); g->rets = malloc(sizeof(int) * n); g->cons = malloc(sizeof(uint32_t) * n); g->bsz = malloc(sizeof(uint32_t) * n);
+    return (g->offs && g->avail && g->room && g->types && g->ns && g->prog && g->cidx && g->cn && g->rets && g->cons && g->bsz) ? 0 : -1;
 }
 static void dgroup_free(struct dgroup *g)
 {
-    free(g->offs); free(g->avail); free(g->room); free(g->types); free(g->ns); free(g->prog); free(g->cidx); free(g->cn); free(g->rets); free(g->cons);
+    free(g->offs); free(g->avail); free(g->room); free(g->types); free(g->ns); free(g->prog); free(g->cidx); free(g->cn); free(g->rets); free(g->cons); free(g->bsz);
 }
 
 static __thread uint32_t g_last_decode_mode;
@@ -719,8 +716,8 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
          * the groups' launches run side by side on the slots' own streams.  What bounds the call is the host's work (parsing 10 ms +
          * widening the PCM into the caller's planes 10 ms per 60-minute stream on 16 threads) and the PCIe link (1.1 GB at 57 GB/s,
          * both directions share it: tools/pcie_bw.py), so the stream goes in EIGHT groups per device (LINNE_AMD_DECODE_GROUPS), every
-         * one with a slot of its own: all are parsed and submitted back to back, and a group is scattered as soon as it is back while
-         * the later ones are still on the link or in the decoder */
+         * one with a slot of its own: all are parsed and submitted back to back, then widened in order while the later ones are still
+         * on the link or in the decoder */
         const char *eg = getenv("LINNE_AMD_DECODE_GROUPS");
         const uint32_t S_ = decoder->shape.num_samples_per_block, F_ = (uint32_t)(((uint64_t)hd->num_samples + S_ - 1) / S_);
         const uint32_t ng = (eg && atoi(eg) > 0) ? (uint32_t)atoi(eg) : 8u;
@@ -742,13 +739,9 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
     uj.dec = decoder; uj.data = data; uj.buffer = buffer;
     off = LINNE_HEADER_SIZE; produced = 0; consumed_groups = 0; progress = 0; scanning = 1; ret = LNN_OK;
     while (scanning || consumed_groups < produced) {
-        const int can_produce = scanning && produced - consumed_groups < window && progress < hd->num_samples && off < data_size;
-        int oldest_back = 0;                /* the oldest group in flight is back already: its PCM goes out before more is parsed */
-        if (consumed_groups < produced) {
-            struct dgroup *og = &grp[consumed_groups % window];
-            oldest_back = !og->ncomp || LINNEAmd_SlotQuery(gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % nslots]) != 0;
-        }
-        if (can_produce && !oldest_back) {
+        /* parsing and submitting come first: what a group waits for longest is the device's Rice decoder (a latency of ~9 ms however
+         * small the group), so every group should be on its way before the host turns to widening the ones that are back */
+        if (scanning && produced - consumed_groups < window && progress < hd->num_samples && off < data_size) {
             struct dgroup *g = &grp[produced % window];
             struct LINNEAmdSlot *sl;
             uint32_t scan_progress = progress, ncomp = 0;
@@ -758,10 +751,11 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
                 const uint32_t k = g->nblk++;
                 uint32_t bsize;
                 g->offs[k] = off; g->avail[k] = rem; g->room[k] = buffer_num_samples - scan_progress; g->prog[k] = scan_progress;
-                g->cidx[k] = 0xFFFFFFFFu; g->types[k] = 0xFFFFFFFFu; g->ns[k] = 0;
+                g->cidx[k] = 0xFFFFFFFFu; g->types[k] = 0xFFFFFFFFu; g->ns[k] = 0; g->bsz[k] = 0;
                 if (rem < 11 || get_be16(data + off) != 0xFFFF) break;                  /* the parser reports the error */
                 bsize = get_be32(data + off + 2);
                 if ((uint64_t)bsize + 6 > rem) break;
+                g->bsz[k] = bsize + 6u;
                 if (data[off + 8] == LNN_BLOCK_COMPRESS) g->cidx[k] = ncomp++;
                 scan_progress += get_be16(data + off + 9);
                 off += (uint64_t)bsize + 6;
@@ -782,7 +776,6 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
                 g->seg_bytes = off - g->seg_first;                /* the scan above stopped at `off`: the group's bytes are [seg_first, off) */
                 if (g->seg_bytes > LINNEAmd_SlotStreamCapacity(sl)) { stream_mode = 0; g_last_decode_mode |= 2u; for (i = 0; i < LNN_MAX_DEVICES; i++) for (f = 0; f < LNN_SLOTS; f++) if (gp->slot[i][f]) (void)LINNEAmd_SlotWait(gp->slot[i][f]); goto setup; }
                 uj.sstream = LINNEAmd_SlotStream(sl); uj.sbitpos = LINNEAmd_SlotBitPos(sl); uj.sbitend = LINNEAmd_SlotBitEnd(sl); uj.seg_first = g->seg_first; uj.seg_bytes = g->seg_bytes;
-                lnn_parallel_for((uint32_t)((g->seg_bytes + 1048575u) >> 20), threads, copy_segment, &uj);
             }
             lnn_parallel_for(g->nblk, threads, unpack_blocks, &uj);
             t_parse += now_s() - t0;
@@ -813,7 +806,7 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
             produced++;
             continue;
         }
-        if (!can_produce) scanning = 0;     /* (armed again below once a slot is free, if the stream goes on) */
+        scanning = 0;                       /* (armed again below once a slot is free, if the stream goes on) */
         if (consumed_groups < produced) {
             struct dgroup *g = &grp[consumed_groups % window];
             struct LINNEAmdSlot *sl = gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % nslots];

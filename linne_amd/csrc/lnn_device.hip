@@ -113,8 +113,11 @@ extern "C" int lnn_preset_info(uint32_t preset, uint32_t *num_layers, uint32_t *
  * shared a queue, the H2D of group g + 1 sat behind the Rice emission of group g, which waits for the analysis of g: the
  * staging pipeline ran serially (measured: 28 ms per group instead of 23).  The runtime reads GPU_MAX_HW_QUEUES when it
  * initialises, i.e. at the first HIP call of the process; loading this library comes before that.  A value the user set is
- * left alone. */
-__attribute__((constructor)) static void lnn_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+ * left alone.  Round 4: 24, not 8 -- DecodeWhole keeps eight groups in flight, each slot with a stream of its own for its H2D and
+ * its Rice decoder (a 9 ms kernel of a few dozen waves) beside the synthesis and the copy-out stream; with 8 queues a slot's stream
+ * shared one with the copy-out stream and its Rice decoder started 3 ms late behind another group's D2H (timeline:
+ * profiles/r04_decode_timeline.txt; DecodeWhole of the 60-minute stream 55 ms with 8 queues, 42 with 16, 37 with 24). */
+__attribute__((constructor)) static void lnn_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
 
 extern "C" int LINNEAmd_GetDeviceCount(void)
 {
@@ -1454,16 +1457,6 @@ extern "C" int LINNEAmd_SlotWait(struct LINNEAmdSlot *s)
     HIPCHK(s->ctx, hipEventSynchronize(s->ev_done));
     s->pending = 0;
     return LNN_OK;
-}
-
-extern "C" int LINNEAmd_SlotQuery(struct LINNEAmdSlot *s)
-{
-    if (!s) return -1;
-    if (!s->pending) return 1;
-    const hipError_t e = hipEventQuery(s->ev_done);
-    if (e == hipSuccess) return 1;
-    if (e == hipErrorNotReady) { (void)hipGetLastError(); return 0; }
-    return -1;                           /* (LINNEAmd_SlotWait reports it) */
 }
 
 extern "C" int LINNEAmd_SlotEncodeSubmit(struct LINNEAmdSlot *s, const uint32_t *num_samples, uint32_t num_frames)
