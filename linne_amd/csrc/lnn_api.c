@@ -574,6 +574,7 @@ struct unpack_job {
     /* stream mode (the device decodes the Rice codes): the group's bytes go to the slot as they are, from seg_first on */
     uint8_t *sstream; uint64_t *sbitpos, *sbitend; uint64_t seg_first, seg_bytes; const int16_t *s16; uint32_t swidth;
 };
+static void copy_to_staging(uint8_t *dst, const uint8_t *src, size_t n);
 static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
 {
     struct unpack_job *j = arg;
@@ -588,7 +589,7 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
             uint64_t rbit = 0;
             /* the block's bytes go to the slot's pinned stream buffer by the thread that checks its CRC next: the second reader
              * finds them in its cache (a pass of its own over the group cost a third of the parsing: 0.48 GB more from memory) */
-            memcpy(j->sstream + (g->offs[f] - j->seg_first), j->data + g->offs[f], g->bsz[f]);
+            copy_to_staging(j->sstream + (g->offs[f] - j->seg_first), j->data + g->offs[f], g->bsz[f]);
             g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
                     &g->types[f], &g->ns[f], &g->cons[f], NULL, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS, &rbit);
             j->sbitpos[g->cidx[f]] = (g->offs[f] - j->seg_first) * 8u + rbit;
@@ -622,6 +623,26 @@ __attribute__((target("avx2"))) static void widen16_avx2(int32_t *dst, const int
     }
     for (; i < n; i++) dst[i] = src[i];
     _mm_sfence();
+}
+/* bytes into a pinned staging buffer that only the DMA engine will read: streaming stores, no read for ownership of the destination */
+__attribute__((target("avx2"))) static void copy_nt_avx2(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    size_t i = 0;
+    while (i < n && ((uintptr_t)(dst + i) & 31u)) { dst[i] = src[i]; i++; }
+    for (; i + 128u <= n; i += 128u) {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(src + i)), b = _mm256_loadu_si256((const __m256i *)(src + i + 32u));
+        const __m256i c = _mm256_loadu_si256((const __m256i *)(src + i + 64u)), d = _mm256_loadu_si256((const __m256i *)(src + i + 96u));
+        _mm256_stream_si256((__m256i *)(dst + i), a); _mm256_stream_si256((__m256i *)(dst + i + 32u), b);
+        _mm256_stream_si256((__m256i *)(dst + i + 64u), c); _mm256_stream_si256((__m256i *)(dst + i + 96u), d);
+    }
+    for (; i < n; i++) dst[i] = src[i];
+    _mm_sfence();
+}
+static void copy_to_staging(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    static int have = -1;
+    if (have < 0) have = __builtin_cpu_supports("avx2") ? 1 : 0;
+    if (have && n >= 4096u) copy_nt_avx2(dst, src, n); else memcpy(dst, src, n);
 }
 static void widen16(int32_t *dst, const int16_t *src, uint32_t n)
 {
