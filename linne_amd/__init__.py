@@ -140,6 +140,10 @@ class Context:
             raise LinneAmdError(f"LINNEAmd_ContextCreate(device={device}) failed: no usable HIP device "
                                 "(the prediction path has no CPU fallback)")
         self.device = int(device)
+        # With its own stream the library's kernels are NOT ordered behind what torch enqueued on torch's stream -- the fill kernel of a
+        # torch.zeros, a clone, a copy from the host: the binding then drains torch's stream before every call that touches tensors
+        # (_fence).  It went unnoticed while both streams happened to share a hardware queue; with the library's 24 queues they do not.
+        self._own_stream = not use_torch_stream
         if use_torch_stream:
             import torch
             s = torch.cuda.current_stream(self.device).cuda_stream
@@ -156,6 +160,12 @@ class Context:
     def _check(self, ret, what):
         if ret != 0:
             raise LinneAmdError(f"{what} -> {ret}: {lib.LINNEAmd_GetLastError(self.h).decode()}")
+
+    def _fence(self):
+        """own stream: everything torch has enqueued so far (allocations' fills, clones, H2D copies) is done before the library runs"""
+        if self._own_stream:
+            import torch
+            torch.cuda.current_stream(self.device).synchronize()
 
     @staticmethod
     def shape(nch, bits, block, preset, ms):
@@ -204,6 +214,7 @@ class Context:
         if num_samples is not None:
             ns = np.ascontiguousarray(num_samples, dtype=np.uint32)
             assert ns.shape == (F,)
+        self._fence()
         self._check(lib.LINNEAmd_EncodeFramesDevice(self.h, C.byref(shape), pcm.data_ptr(), ns.ctypes.data if ns is not None else None,
                                                     F, res.data_ptr(), prm.data_ptr(), st.data_ptr()), "EncodeFramesDevice")
         return res, prm, st
@@ -215,6 +226,7 @@ class Context:
         assert residual.dtype == torch.int32 and residual.is_cuda and residual.is_contiguous()
         plan = torch.zeros((F, Cn, RICE_PLAN_BYTES), dtype=torch.uint8, device=residual.device)
         ns = np.ascontiguousarray(num_samples, dtype=np.uint32) if num_samples is not None else None
+        self._fence()
         self._check(lib.LINNEAmd_RicePlanDevice(self.h, C.byref(shape), residual.data_ptr(), ns.ctypes.data if ns is not None else None,
                                                 F, plan.data_ptr()), "RicePlanDevice")
         return plan
@@ -227,6 +239,7 @@ class Context:
         cap = int(capacity_bytes if capacity_bytes is not None else F * Cn * (S * 4 + 64))
         packed = torch.zeros(cap, dtype=torch.uint8, device=residual.device)
         offsets = torch.zeros(F * Cn + 1, dtype=torch.int32, device=residual.device)
+        self._fence()
         self._check(lib.LINNEAmd_RiceEmitDevice(self.h, C.byref(shape), residual.data_ptr(), F, plan.data_ptr(), offsets.data_ptr(),
                                                 packed.data_ptr(), cap), "RiceEmitDevice")
         return packed, offsets
@@ -239,6 +252,7 @@ class Context:
         ns = None
         if num_samples is not None:
             ns = np.ascontiguousarray(num_samples, dtype=np.uint32)
+        self._fence()
         self._check(lib.LINNEAmd_DecodeFramesDevice(self.h, C.byref(shape), data.data_ptr(), ns.ctypes.data if ns is not None else None,
                                                     F, params.data_ptr()), "DecodeFramesDevice")
         return data

@@ -14,6 +14,23 @@
  * to lag J0+j -- the reference's products in the reference's order; the pairs that reach across a unit's end meet the zeros
  * (+0.0 added).  No per-wave window generator, no stream bookkeeping in the inner loop: 2 LPW multiply/adds and 2 LDS reads per
  * position and wave. */
+/* 16 bytes per lane from global memory straight into LDS: lane l's land at lds_wave_base + 16 l (global_load_lds_dwordx4, the LDS
+ * base in M0).  Inline assembly on purpose: through the builtin the compiler waits for the load (vmcnt) in front of the next LDS read
+ * of ANY array -- it cannot tell the landing zone from the ring the lags are read from -- and the prefetch is gone; here the one
+ * s_waitcnt sits where the data is needed (commit). */
+__device__ __forceinline__ void lds_dma16(const void *g, void *lds_wave_base)
+{
+    const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(base), "v"(g) : "memory", "m0");
+}
+template <int N> __device__ __forceinline__ void hist_wait_loads(double (&r)[N])
+{
+    static_assert(N == 9 || N == 11, "one operand list per lag count");
+    if constexpr (N == 9)
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]) : : "memory");
+    else
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]) : : "memory");
+}
 /* lags per wave (measured): order 128 -- 11 (12 waves, one block per CU); order 64 -- 9 (8 waves, two blocks per CU) */
 #define HIST_LPW(PT_) ((PT_) >= 128 ? 11 : 9)
 #define HIST_TILE(PT_) 16                                    /* positions per tile (a multiple of 16; 32 was measured: far slower for order 128) */
@@ -26,6 +43,7 @@ __global__ __launch_bounds__(64 * HIST_WAVES(P >> TT), ((P >> TT) >= 128) ? 3 : 
     static_assert(LPW <= 16, "a wave's lags come from a 16-deep register ring");
     static_assert(PT % T == 0 && D % T == 0, "tiles must not straddle a unit's end or the ring's end");
     __shared__ __attribute__((aligned(16))) double ring_lds[D + T][65];
+    __shared__ __attribute__((aligned(16))) lnn_d2 stage[NLD][64];      /* the tile on its way from memory: load instruction k's 64 x 16 bytes, as the lanes asked for them */
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const RowRuns &rr = p.runs[1];
     const uint32_t b = gridDim.x - 1u - blockIdx.x;
@@ -54,38 +72,54 @@ __global__ __launch_bounds__(64 * HIST_WAVES(P >> TT), ((P >> TT) >= 128) ? 3 : 
         uint32_t lr = row0 + (uint32_t)RPI * (k < (uint32_t)NLD ? k : 0u) + lrow; if (lr >= nrows) lr = nrows - 1;
         src[i] = p.sig + ((size_t)lr * 2 + cur) * p.S + lsmp;
     }
-    /* the tile being fetched: place in the padded stream */
-    uint32_t f_unit = 0, f_loc = 0;                          /* unit and place inside the padded unit of the NEXT tile to fetch */
-    lnn_d2 pre[NSLOT];
-    auto issue = [&]() {                                      /* fetch + window the tile at (f_unit, f_loc); zeros in the pad */
-#pragma unroll
-        for (int i = 0; i < NSLOT; i++) {
-            lnn_d2 v; v.x = 0.0; v.y = 0.0;
-            if (wave + (uint32_t)i * NW < (uint32_t)NLD && f_loc < n) {
-                const lnn_d2 x = *(const lnn_d2 *)(src[i] + (size_t)f_unit * n + f_loc);
-                const lnn_d2 w = *(const lnn_d2 *)(wt + f_loc + lsmp);
-                v.x = x.x * w.x; v.y = x.y * w.y;
-            }
-            pre[i] = v;
-        }
-        f_loc += T; if (f_loc == upl) { f_loc = 0; f_unit++; }
-    };
-    auto commit = [&](uint32_t slot0) {                       /* slot0: ring slot of the tile's first position (multiple of T) */
-#pragma unroll
-        for (int i = 0; i < NSLOT; i++) {
-            const uint32_t k = wave + (uint32_t)i * NW;
-            if (k < (uint32_t)NLD) {
-                const uint32_t r = (uint32_t)RPI * k + lrow;
-                ring_lds[slot0 + lsmp][r] = pre[i].x; ring_lds[slot0 + lsmp + 1][r] = pre[i].y;
-                if (slot0 == 0) { ring_lds[D + lsmp][r] = pre[i].x; ring_lds[D + lsmp + 1][r] = pre[i].y; }
-            }
-        }
-    };
     double r[LPW], q[LPW], hist[16];
 #pragma unroll
     for (int j = 0; j < LPW; j++) { r[j] = 0.0; q[j] = 0.0; }
 #pragma unroll
     for (int j = 0; j < 16; j++) hist[j] = 0.0;
+    /* the tile being fetched: place in the padded stream */
+    uint32_t f_unit = 0, f_loc = 0;                          /* unit and place inside the padded unit of the NEXT tile to fetch */
+    uint32_t p_loc = 0;                                       /* place of the tile that is on its way */
+    /* issue() only REQUESTS the tile's samples -- straight into LDS (global_load_lds_dwordx4: 16 bytes per lane to stage[k][lane],
+     * no register holds them on the way); they are windowed when commit() moves them into the ring, three quarters of a tile's work
+     * later.  (Round 4: the window multiply sat in issue() -- the wave then waited out every load on the spot, a trip to memory per
+     * tile with the whole block at the barrier behind it; kept in registers instead, the samples in flight pushed the order-64 kernel
+     * over its 128 registers and the compiler parked them in scratch, waiting for them just the same.)  The Welch weight of a sample is
+     * computed where it is needed, with the host table's own two multiplies (build_classes: w[loc] = div * (double)h *
+     * (double)(nu - 1 - h), h = min(loc, nu - 1 - loc): lpc.c:199-204) -- the same bits, and no second load to wait for. */
+    const double wdiv = c0.trial_div[layer][TT];
+    (void)wt;
+    auto issue = [&]() {                                      /* request the tile at (f_unit, f_loc); zeros in the pad */
+        p_loc = f_loc;
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NW;
+            if (k < (uint32_t)NLD && f_loc < n)
+                lds_dma16(src[i] + (size_t)f_unit * n + f_loc, &stage[k][0]);
+        }
+        f_loc += T; if (f_loc == upl) { f_loc = 0; f_unit++; }
+    };
+    auto welch = [&](uint32_t loc) -> double {               /* (loc < n: inside the unit) */
+        const uint32_t h = (loc < (n >> 1)) ? loc : (n - 1u - loc);
+        return wdiv * (double)h * (double)(n - 1u - h);
+    };
+    auto commit = [&](uint32_t slot0) {                       /* slot0: ring slot of the tile's first position (multiple of T) */
+        /* the tile has landed in `stage` (what this wave asked for: each lane reads its own 16 bytes back).  The wait takes the lags'
+         * accumulators as operands: nothing of their arithmetic touches memory, and without a data dependence the compiler moves the
+         * wait up to the top of the tile, in front of all of it */
+        hist_wait_loads(r);
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) {
+            const uint32_t k = wave + (uint32_t)i * NW;
+            if (k < (uint32_t)NLD) {
+                const uint32_t r = (uint32_t)RPI * k + lrow;
+                double vx = 0.0, vy = 0.0;
+                if (p_loc < n) { const lnn_d2 x = stage[k][lane]; vx = x.x * welch(p_loc + lsmp); vy = x.y * welch(p_loc + lsmp + 1u); }
+                ring_lds[slot0 + lsmp][r] = vx; ring_lds[slot0 + lsmp + 1][r] = vy;
+                if (slot0 == 0) { ring_lds[D + lsmp][r] = vx; ring_lds[D + lsmp + 1][r] = vy; }
+            }
+        }
+    };
     __syncthreads();                                          /* ring zeroed */
     issue(); commit(0);
     __syncthreads();

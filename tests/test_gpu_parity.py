@@ -931,6 +931,7 @@ def test_rice_decode_device_reads_no_further_than_its_contract(ctx):
         out = torch.full((k, nch, block), 123456, dtype=torch.int32, device="cuda")
         endbit = torch.zeros(k, dtype=torch.int64, device="cuda")
         nsk = np.ascontiguousarray(ns[:k])
+        ctx._fence()         # (the context has a stream of its own: torch's fills and copies above must be done first)
         ret = linne_amd.lib.LINNEAmd_RiceDecodeDevice(C.c_void_p(ctx.h), C.byref(shape), C.c_void_p(buf.data_ptr()), C.c_uint64(total), C.c_void_p(bitpos.data_ptr()),
                                                       nsk.ctypes.data_as(C.c_void_p), C.c_uint32(k), C.c_void_p(out.data_ptr()), C.c_void_p(endbit.data_ptr()))
         assert ret == 0
