@@ -566,7 +566,7 @@ LINNEApiResult LINNEDecoder_DecodeBlock(struct LINNEDecoder *decoder, const uint
  * blocks on the host threads straight into a staging slot, synthesise it on the GPU while the next group is being
  * entropy-decoded, then scatter the PCM into the caller's planes ---- */
 struct dgroup {
-    uint32_t nblk, ncomp; int streamed, crc_pending /* stream mode: the blocks' CRCs are checked while the GPU works (verify_groups) */; uint64_t seg_first, seg_bytes;
+    uint32_t nblk, ncomp; int streamed; uint64_t seg_first, seg_bytes;
     uint64_t *offs, *avail; uint32_t *room, *types, *ns, *prog, *cidx, *cn, *cons, *bsz /* the block's bytes by its size field (the scan) */; int *rets;
 };
 struct unpack_job {
@@ -590,13 +590,8 @@ static void unpack_blocks(void *arg, uint32_t first, uint32_t count)
             /* the block's bytes go to the slot's pinned stream buffer by the thread that checks its CRC next: the second reader
              * finds them in its cache (a pass of its own over the group cost a third of the parsing: 0.48 GB more from memory) */
             copy_to_staging(j->sstream + (g->offs[f] - j->seg_first), j->data + g->offs[f], g->bsz[f]);
-            /* the CRC waits (verify_groups: while the GPU works on the group); a block that does not parse is looked at again in the
-             * reference's order -- sync code, size, CRC, fields (linne_decoder.c:600-640) -- so that it fails with the reference's result */
-            g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], 0, g->room[f],
+            g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
                     &g->types[f], &g->ns[f], &g->cons[f], NULL, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS, &rbit);
-            if (g->rets[f] != LNN_OK)
-                g->rets[f] = lnn_parse_block_head(sh, &j->dec->layers, j->data + g->offs[f], g->avail[f], j->dec->check_crc, g->room[f],
-                        &g->types[f], &g->ns[f], &g->cons[f], NULL, j->sprm + (size_t)g->cidx[f] * C * LINNE_AMD_PARAM_WORDS, &rbit);
             j->sbitpos[g->cidx[f]] = (g->offs[f] - j->seg_first) * 8u + rbit;
             j->sbitend[g->cidx[f]] = (g->offs[f] - j->seg_first + g->cons[f]) * 8u;
             continue;
@@ -678,18 +673,6 @@ static void scatter_blocks(void *arg, uint32_t first, uint32_t count)
         }
     }
 }
-/* the CRCs of a group's COMPRESS blocks, behind their parsing (stream mode): libs/linne_decoder/src/linne_decoder.c:616-624 */
-static void crc_blocks(void *arg, uint32_t first, uint32_t count)
-{
-    struct unpack_job *j = arg;
-    struct dgroup *g = j->g;
-    uint32_t f;
-    for (f = first; f < first + count; f++) {
-        const uint8_t *b = j->data + g->offs[f];
-        if (g->cidx[f] == 0xFFFFFFFFu || g->bsz[f] < 11u) continue;           /* (RAW / SILENT blocks were checked when they were parsed) */
-        if (lnn_crc16(b + 8, (uint64_t)g->bsz[f] - 8u) != get_be16(b + 6)) g->rets[f] = LNN_DETECT_DATA_CORRUPTION;
-    }
-}
 static int dgroup_alloc(struct dgroup *g, uint32_t n)
 {
     memset(g, 0, sizeof(*g));
@@ -720,7 +703,7 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
     uint32_t group, f, produced = 0, consumed_groups = 0, progress = 0, i, ngalloc = 0, ndev = 1, window = LNN_SLOTS, nslots = LNN_SLOTS;
     const uint32_t threads = default_threads();
     uint64_t off;
-    double t_begin = now_s(), t_parse = 0, t_submit = 0, t_wait = 0, t_scatter = 0, t_crc = 0, t0;
+    double t_begin = now_s(), t_parse = 0, t_submit = 0, t_wait = 0, t_scatter = 0, t0;
     int ret = LNN_OK, scanning = 1;
     /* stream mode (the default; LINNE_AMD_DECODE_STREAM=0 turns it off): the device decodes the Rice codes
      * (LINNEAmd_SlotDecodeStreamSubmit), the host threads only scan the block headers, check the CRCs and decode the parameters.
@@ -837,7 +820,6 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
                 int dret;
                 t0 = now_s();
                 g->streamed = (uj.sstream != NULL);
-                g->crc_pending = g->streamed;
                 dret = g->streamed ? LINNEAmd_SlotDecodeStreamSubmit(sl, g->seg_bytes, g->cn, g->ncomp) : LINNEAmd_SlotDecodeSubmit(sl, g->cn, g->ncomp);
                 t_submit += now_s() - t0;
                 if (dret != LNN_OK) { report(gp->ctx[produced % ndev], "SlotDecodeSubmit", dret); ret = dret; goto done; }
@@ -846,26 +828,6 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
             continue;
         }
         scanning = 0;                       /* (armed again below once a slot is free, if the stream goes on) */
-        if (consumed_groups < produced) {
-            /* the CRCs of everything that is on its way (stream mode parsed without them): now, while the GPU works -- the host
-             * would only wait.  The first block that fails ends the stream there, as it would have when it was parsed. */
-            uint32_t k_;
-            t0 = now_s();
-            for (k_ = consumed_groups; k_ < produced && ret == LNN_OK; k_++) {
-                struct dgroup *gk = &grp[k_ % window];
-                if (!gk->crc_pending) continue;
-                gk->crc_pending = 0;
-                uj.g = gk;
-                lnn_parallel_for(gk->nblk, threads, crc_blocks, &uj);
-                for (f = 0; f < gk->nblk; f++) if (gk->rets[f] != LNN_OK) {
-                    uint32_t k2;
-                    ret = gk->rets[f]; gk->nblk = f;
-                    for (k2 = k_ + 1; k2 < produced; k2++) { grp[k2 % window].nblk = 0; grp[k2 % window].crc_pending = 0; }      /* (their slots are still waited for) */
-                    break;
-                }
-            }
-            t_crc += now_s() - t0;
-        }
         if (consumed_groups < produced) {
             struct dgroup *g = &grp[consumed_groups % window];
             struct LINNEAmdSlot *sl = gp->slot[consumed_groups % ndev][(consumed_groups / ndev) % nslots];
@@ -905,8 +867,8 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
         }
     }
     if (stream_mode && produced) g_last_decode_mode |= 1u;
-    if (trace_on()) fprintf(stderr, "liblinne_amd: DecodeWhole %u threads%s: parse %.1f ms, submit %.1f, crc %.1f, wait %.1f, scatter %.1f, total %.1f ms\n",
-            threads, stream_mode ? ", Rice codes decoded on the device" : "", t_parse * 1e3, t_submit * 1e3, t_crc * 1e3, t_wait * 1e3, t_scatter * 1e3, (now_s() - t_begin) * 1e3);
+    if (trace_on()) fprintf(stderr, "liblinne_amd: DecodeWhole %u threads%s: parse %.1f ms, submit %.1f, wait %.1f, scatter %.1f, total %.1f ms\n",
+            threads, stream_mode ? ", Rice codes decoded on the device" : "", t_parse * 1e3, t_submit * 1e3, t_wait * 1e3, t_scatter * 1e3, (now_s() - t_begin) * 1e3);
 done:
     for (f = 0; f < LNN_MAX_DEVICES; f++) for (i = 0; i < LNN_SLOTS; i++) if (gp->slot[f][i]) (void)LINNEAmd_SlotWait(gp->slot[f][i]);
     for (i = 0; i < ngalloc; i++) dgroup_free(&grp[i]);
