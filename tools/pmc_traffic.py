@@ -11,7 +11,9 @@ KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the s
         ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_fwd_loss", "k_fwd_loss<P> (last layer: forward pass + ordered loss)"),
         ("k_fir2<1, true", "k_fir2<1,true,*> (forward of layer 0, jobs with several units)"),
         ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"), ("k_quantize", "k_finalize"), ("k_fir_cascade", "k_finalize"),
-        ("k_synth_rows", "k_synth_rows<NCH> / k_synth_rows8<PB> (four / eight channel-frames per wave, the old taps on the matrix unit: the throughput form)"), ("k_deemph_lr", "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out)"),
+        ("k_synth_l0_de", "k_synth_l0_de (layer 0 + de-emphasis + MS -> LR in one launch, tiles in LDS)"),
+        ("k_synth_rows8", "k_synth_rows8<PB> / k_synth_rows<0> (a short layer: eight / four channel-frames per wave)"), ("k_synth_rows<0", "k_synth_rows8<PB> / k_synth_rows<0> (a short layer: eight / four channel-frames per wave)"),
+        ("k_synth_rows", "k_synth_rows<NCH> (a long layer: four channel-frames per wave, the old taps on the matrix unit)"), ("k_deemph_lr", "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out; LINNE_AMD_DECODE_FUSED=0)"),
         ("k_synth_big", "k_synth_big<P> (synthesis of the long layer)"), ("k_synth_small", "k_synth_small<P> (synthesis of the short layers, de-emphasis)"),
         ("k_synthesize", "k_synthesize (one wave per channel-frame, all layers)"), ("k_ms_to_lr", "k_ms_to_lr"), ("k_chain_sum", "k_chain_sum<1>"), ("k_stats", "k_stats"), ("k_rice_plan", "k_rice_plan"), ("k_rice_emit", "k_rice_emit")]
 def load(path, counter):
@@ -48,12 +50,17 @@ for kind, v in out.items():
 out["_whole_step"] = {"encode_hbm_bytes_per_channel_frame": int(tot["encode"] / (frames * channels)), "decode_hbm_bytes_per_channel_frame": int(tot["decode"] / (frames * channels)),
                       "algorithmic_bytes_per_channel_frame": 82552, "encode_over_algorithmic": round(tot["encode"] / (frames * channels) / 82552.0, 2),
                       "decode_over_algorithmic": round(tot["decode"] / (frames * channels) / 82552.0, 2)}
+# the commit the library was built from: the GPU box has no .git -- the caller passes it (tools/round_profiles.sh takes it from the
+# build container: `bash tools/round_profiles.sh r04 "$(git rev-parse --short HEAD)"`)
+commit = ""
 try:
     import subprocess
-    out["_source"] += "; tree " + subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    commit = subprocess.run(["git", "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 except Exception:
     pass
-if len(sys.argv) > 5: out["_source"] += "; " + sys.argv[5]
+note = sys.argv[5] if len(sys.argv) > 5 else ""
+out["_source"] += "; tree " + (commit or note or "UNKNOWN (no commit id was passed)")
+if commit and note: out["_source"] += "; " + note
 json.dump(out, open("profiles/pmc_latest.json", "w"), indent=1)
 for k, v in out.items():
     if not k.startswith("_"): print(k, v["launches_sampled"], v["hbm_bytes_per_channel_frame_per_launch"])
