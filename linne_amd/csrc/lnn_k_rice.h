@@ -320,6 +320,14 @@ struct RiceBR {
         sh += n;
         if (sh >= 32u) { sh -= 32u; w0 = w1; w1 = pre; pre = load(widx); widx++; }
     }
+    /* skip(n), n <= 32, for a lane whose next word is staged (widx < hi), without a branch: every lane reads its ring (one LDS read
+     * for the wave) and keeps or drops the word */
+    __device__ __forceinline__ void skip_staged(uint32_t n) {
+        const uint32_t nw = ring[widx & (RDEC_RING - 1u)];
+        sh += n;
+        const bool adv = sh >= 32u;
+        sh = adv ? sh - 32u : sh; w0 = adv ? w1 : w0; w1 = adv ? pre : w1; pre = adv ? nw : pre; widx += adv ? 1u : 0u;
+    }
     __device__ __forceinline__ uint32_t get(uint32_t n) {                  /* n <= 32 */
         const uint32_t v = n ? (peek() >> (32u - n)) : 0u;
         skip(n);
@@ -425,11 +433,22 @@ __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
                         next_part += ns;
                     }
                     if (!bad) {
+                        /* The usual sample -- a zero run of at most 24, run and binary part within the 32 bits in view, the next
+                         * word staged in the ring: ONE look at the stream and one branch-free step over it (round 4: a look and a
+                         * step for the run, another pair for the binary part, each step a divergent branch around an LDS read:
+                         * ~100 instructions a sample where the walk of a block is all that a launch's 8 ms are).  Anything else
+                         * takes the general reader. */
                         const uint32_t t = r.peek();
-                        uint32_t quot;
-                        if (t >> 7) { quot = (uint32_t)__clz((int)t); r.skip(quot + 1u); }          /* the usual case: a short run */
-                        else quot = r.zero_run(nbits_total, bad);
-                        const uint32_t low = r.get((quot == 0u) ? k1 : k2);         /* (one read for both forms: the lanes differ) */
+                        uint32_t quot = (uint32_t)__clz((int)t), low;
+                        const uint32_t kk = (quot == 0u) ? k1 : k2, used = quot + 1u + kk;
+                        if ((t >> 7) != 0u && used <= 32u && r.widx < r.hi) {
+                            low = (kk != 0u) ? ((t << (quot + 1u)) >> (32u - kk)) : 0u;      /* (quot + 1 <= 25, 1 <= 32 - kk <= 31) */
+                            r.skip_staged(used);
+                        } else {
+                            if (t >> 7) r.skip(quot + 1u);
+                            else quot = r.zero_run(nbits_total, bad);
+                            low = r.get((quot == 0u) ? k1 : k2);
+                        }
                         const uint32_t v = (quot == 0u) ? low : (low + k1pow + ((quot - 1u) << k2));
                         val = (int32_t)(v >> 1) ^ -(int32_t)(v & 1u);
                     }
