@@ -45,6 +45,7 @@
 /* ================================================================================================
  * host side of this TU: context, scratch arena, launch sequences, C-ABI
  * ============================================================================================== */
+#define LNN_RICE_STREAMS 4
 struct LINNEAmdContext {
     int device;
     hipStream_t stream; int own_stream;
@@ -60,6 +61,7 @@ struct LINNEAmdContext {
     /* frame groups of one call rotate over these streams so that the latency-bound phases of one group (short
      * layers, Levinson, ordered sums) overlap the throughput-bound phases of another */
     hipStream_t sub[LNN_MAXSUB]; hipEvent_t sub_done[LNN_MAXSUB]; hipEvent_t ev_start; int nsub, nsub_forced /* LINNE_AMD_STREAMS was given */;
+    int enc_streams_done;
     hipStream_t side; hipEvent_t side_done; int has_side;     /* block-type statistics run beside the analysis */
     hipEvent_t fork_ev, join_ev;        /* side stream: the general autocorrelation kernel for the few frames the lanes = jobs kernels do not take */
     DevClass *d_cls; double *d_sin; uint64_t sin_cap; double *d_wt; uint64_t wt_cap; uint32_t *d_clsidx; uint64_t clsidx_cap; uint32_t *d_map;   /* class index per sorted row, then the sorted row's frame (same buffer) */ uint32_t *d_nsmp; uint64_t nsmp_cap;
@@ -74,6 +76,9 @@ struct LINNEAmdContext {
     uint32_t *meta_h[LNN_META]; uint64_t meta_cap[LNN_META]; hipEvent_t meta_ev[LNN_META]; int meta_used[LNN_META]; int meta_next;
     /* copy streams of the staging slots (H2D of the next group and D2H of the previous one overlap the kernels) */
     hipStream_t copy_in, copy_out; int has_copy;
+    /* decode slots in stream mode: the Rice decoders of a stream's groups run side by side on these (a launch is a few dozen waves
+     * walking their blocks for ~8 ms), the slots take them in turn */
+    hipStream_t rice_pool[LNN_RICE_STREAMS]; int n_rice_pool, rice_next;
     uint32_t *d_plan_nsmp; uint64_t plan_nsmp_cap; double rice_steps[32]; uint32_t rice_nsteps;
     int prod_ok;                        /* set per batch by build_classes, bit l: in layer l every class has all its trials and even unit lengths (k_autocorr_prod) */
     int fir_small;                      /* LINNE_AMD_FIR_SMALL (default 1): register-window search kernel for layers of <= 16 taps */
@@ -113,11 +118,15 @@ extern "C" int lnn_preset_info(uint32_t preset, uint32_t *num_layers, uint32_t *
  * shared a queue, the H2D of group g + 1 sat behind the Rice emission of group g, which waits for the analysis of g: the
  * staging pipeline ran serially (measured: 28 ms per group instead of 23).  The runtime reads GPU_MAX_HW_QUEUES when it
  * initialises, i.e. at the first HIP call of the process; loading this library comes before that.  A value the user set is
- * left alone.  Round 4: 24, not 8 -- DecodeWhole keeps eight groups in flight, each slot with a stream of its own for its H2D and
- * its Rice decoder (a 9 ms kernel of a few dozen waves) beside the synthesis and the copy-out stream; with 8 queues a slot's stream
- * shared one with the copy-out stream and its Rice decoder started 3 ms late behind another group's D2H (timeline:
- * profiles/r04_decode_timeline.txt; DecodeWhole of the 60-minute stream 55 ms with 8 queues, 42 with 16, 37 with 24). */
-__attribute__((constructor)) static void lnn_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+ * left alone.  Round 4 tried more: DecodeWhole keeps eight groups in flight, and with a stream per slot 8 queues were too few -- a
+ * slot's stream shared one with the copy-out stream and its Rice decoder started 3 ms late behind another group's D2H
+ * (profiles/r04_decode_timeline.txt; 55 ms per 60-minute stream with 8 queues, 42 with 16, 37 with 24) -- but with 24 queues
+ * EncodeWhole lost a quarter of its rate inside a process that holds other contexts (bench.py: 142 k -> 107 k frames/s, every
+ * kernel of the analysis 6 % slower: profiles/r04_encode_whole_queues.txt).  So the count stays at 8 and the decoder asks for LESS:
+ * its context creates no encode-side streams (ctx_encode_streams) and four pooled streams carry the Rice decoders
+ * (LNN_RICE_STREAMS), so that what runs side by side in a decode -- synthesis, copy-in, copy-out, four decoders -- are seven streams
+ * created one after the other: seven different queues out of eight. */
+__attribute__((constructor)) static void lnn_more_hw_queues(void) { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 extern "C" int LINNEAmd_GetDeviceCount(void)
 {
@@ -126,24 +135,14 @@ extern "C" int LINNEAmd_GetDeviceCount(void)
     return n;
 }
 
-extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t scratch_bytes)
+/* The streams only the ENCODE side uses -- the compute sub-streams of a large call and the side stream of the block-type statistics --
+ * are created at the first encode call, not with the context: a stream takes the next of the process's few hardware queues in turn
+ * (GPU_MAX_HW_QUEUES), and a decoder's context that never encodes should not push its own streams -- the synthesis, the copy-out, the
+ * Rice decoders -- onto queues that collide (round 4: DecodeWhole's Rice decoders started milliseconds late behind another group's D2H). */
+static int ctx_encode_streams(LINNEAmdContext *ctx)
 {
-    int n = 0;
-    hipError_t e;
-#define CC_FAIL(what) do { fprintf(stderr, "liblinne_amd: ContextCreate(device=%d): %s: %s\n", device, what, hipGetErrorString(e)); } while (0)
-    if ((e = hipGetDeviceCount(&n)) != hipSuccess) { CC_FAIL("hipGetDeviceCount"); return NULL; }
-    if (n <= 0 || device < 0 || device >= n) { fprintf(stderr, "liblinne_amd: ContextCreate(device=%d): %d HIP device(s) visible\n", device, n); return NULL; }
-    if ((e = hipSetDevice(device)) != hipSuccess) { CC_FAIL("hipSetDevice"); return NULL; }
-    LINNEAmdContext *ctx = (LINNEAmdContext *)calloc(1, sizeof(*ctx));
-    if (!ctx) return NULL;
-    ctx->device = device;
-    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { CC_FAIL("hipStreamCreate"); free(ctx); return NULL; }
-    ctx->own_stream = 1;
-    if (scratch_bytes == 0) scratch_bytes = 6ull << 30;
-    if ((e = hipMalloc(&ctx->arena, scratch_bytes)) != hipSuccess) { CC_FAIL("hipMalloc(arena)"); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
-    ctx->arena_bytes = scratch_bytes;
-    if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
-    if ((e = hipMalloc((void **)&ctx->d_ucount, 4 * sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
+    if (ctx->enc_streams_done) return LNN_OK;
+    ctx->enc_streams_done = 1;
     {
         const char *env = getenv("LINNE_AMD_STREAMS");
         int ns = env ? atoi(env) : 2;                /* (two by default since round 3: see the rule at the chunk loop) */
@@ -165,6 +164,27 @@ extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t s
                 && hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming) == hipSuccess
                 && hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming) == hipSuccess;
     }
+    return LNN_OK;
+}
+
+extern "C" struct LINNEAmdContext *LINNEAmd_ContextCreate(int device, uint64_t scratch_bytes)
+{
+    int n = 0;
+    hipError_t e;
+#define CC_FAIL(what) do { fprintf(stderr, "liblinne_amd: ContextCreate(device=%d): %s: %s\n", device, what, hipGetErrorString(e)); } while (0)
+    if ((e = hipGetDeviceCount(&n)) != hipSuccess) { CC_FAIL("hipGetDeviceCount"); return NULL; }
+    if (n <= 0 || device < 0 || device >= n) { fprintf(stderr, "liblinne_amd: ContextCreate(device=%d): %d HIP device(s) visible\n", device, n); return NULL; }
+    if ((e = hipSetDevice(device)) != hipSuccess) { CC_FAIL("hipSetDevice"); return NULL; }
+    LINNEAmdContext *ctx = (LINNEAmdContext *)calloc(1, sizeof(*ctx));
+    if (!ctx) return NULL;
+    ctx->device = device;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) { CC_FAIL("hipStreamCreate"); free(ctx); return NULL; }
+    ctx->own_stream = 1;
+    if (scratch_bytes == 0) scratch_bytes = 6ull << 30;
+    if ((e = hipMalloc(&ctx->arena, scratch_bytes)) != hipSuccess) { CC_FAIL("hipMalloc(arena)"); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
+    ctx->arena_bytes = scratch_bytes;
+    if ((e = hipMalloc((void **)&ctx->d_cls, sizeof(DevClass) * LNN_MAXCLS)) != hipSuccess) { CC_FAIL("hipMalloc(classes)"); hipFree(ctx->arena); hipStreamDestroy(ctx->stream); free(ctx); return NULL; }
+    if ((e = hipMalloc((void **)&ctx->d_ucount, 4 * sizeof(uint32_t))) != hipSuccess) { CC_FAIL("hipMalloc(counter)"); }
     { const char *ex = getenv("LINNE_AMD_EXACT"); ctx->force_exact = ex ? atoi(ex) : 0; }
     { const char *sp = getenv("LINNE_AMD_SPECULATE"); ctx->fir_spec = sp ? atoi(sp) : 1; }
     { const char *lr = getenv("LINNE_AMD_LEV_RIDE"); ctx->lev_ride = lr ? atoi(lr) : 1; }
@@ -198,6 +218,7 @@ extern "C" void LINNEAmd_ContextDestroy(struct LINNEAmdContext *ctx)
     if (ctx->hstage) hipFree(ctx->hstage);
     if (ctx->af_h) hipHostFree(ctx->af_h);
     for (int i = 0; i < LNN_META; i++) { if (ctx->meta_h[i]) hipHostFree(ctx->meta_h[i]); if (ctx->meta_ev[i]) hipEventDestroy(ctx->meta_ev[i]); }
+    for (int i = 0; i < ctx->n_rice_pool; i++) { hipStreamSynchronize(ctx->rice_pool[i]); hipStreamDestroy(ctx->rice_pool[i]); }
     if (ctx->has_copy) { hipStreamSynchronize(ctx->copy_in); hipStreamSynchronize(ctx->copy_out); hipStreamDestroy(ctx->copy_in); hipStreamDestroy(ctx->copy_out); }
     hipEventDestroy(ctx->ev[0]); hipEventDestroy(ctx->ev[1]);
     for (int i = 0; i < 2 * ctx->span_cap; i++) hipEventDestroy(ctx->span_ev[i]);
@@ -651,6 +672,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     int ret = shape_info(shape, &hs);
     if (ret != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if ((ret = ctx_encode_streams(ctx)) != LNN_OK) return ret;
     read_call_knobs(ctx);
     if ((ret = build_classes(ctx, shape, &hs, h_num_samples, num_frames)) != LNN_OK) return ret;
 
@@ -1297,7 +1319,7 @@ struct LINNEAmdSlot {
     uint8_t *h_packed, *d_packed; uint64_t packed_cap; uint32_t *h_offsets, *d_offsets;
     /* decode, stream mode: the blocks' bytes instead of the residual; PCM optionally as int16 */
     uint8_t *h_stream, *d_stream; uint64_t stream_cap; uint64_t *h_bitpos, *d_bitpos, *h_endbit, *d_endbit; int16_t *h_out16, *d_out16; uint32_t *d_flag, *h_flag;
-    hipStream_t in_stream;      /* stream mode: this slot's own copy-in stream (H2D + k_rice_decode), so that the slots' Rice decoders -- a few dozen waves each -- run side by side */
+    hipStream_t in_stream;      /* stream mode: the stream of this slot's Rice decoder, one of the context's pool (not owned) */
     hipEvent_t ev_in, ev_k, ev_done; int pending;
 };
 
@@ -1315,7 +1337,7 @@ extern "C" void LINNEAmd_SlotDestroy(struct LINNEAmdSlot *s)
     if (!s) return;
     hipSetDevice(s->ctx->device);
     if (s->pending) hipEventSynchronize(s->ev_done);
-    if (s->in_stream) { hipStreamSynchronize(s->in_stream); hipStreamDestroy(s->in_stream); }
+    if (s->in_stream) hipStreamSynchronize(s->in_stream);
     if (s->h_pcm) hipHostFree(s->h_pcm);
     if (s->h_data) hipHostFree(s->h_data);
     if (s->h_prm) hipHostFree(s->h_prm);
@@ -1401,7 +1423,11 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
         /* room for the blocks' bytes: what RAW blocks take, and a little more (a COMPRESS block is chosen on an estimate and may
          * come out larger: a group that does not fit is decoded the other way, lnn_api.c) */
         s->stream_cap = ((uint64_t)max_frames * (CS * ((shape->bits_per_sample + 7u) / 8u) + CS / 8u + 1024u) + 4095u) & ~(uint64_t)4095u;
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->in_stream, hipStreamNonBlocking);
+        if (e == hipSuccess) {
+            const int k = ctx->rice_next++ % LNN_RICE_STREAMS;
+            if (k >= ctx->n_rice_pool) { e = hipStreamCreateWithFlags(&ctx->rice_pool[k], hipStreamNonBlocking); if (e == hipSuccess) ctx->n_rice_pool = k + 1; }
+            if (e == hipSuccess) s->in_stream = ctx->rice_pool[k];
+        }
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_stream, s->stream_cap + 16, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&s->d_stream, s->stream_cap + 16);
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_bitpos, (2 * sizeof(uint64_t) + sizeof(uint32_t)) * max_frames, hipHostMallocDefault);      /* positions, the blocks' ends, the frames' lengths */
@@ -1537,7 +1563,10 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
     int ret = LINNEAmd_SlotWait(s);
     if (ret != LNN_OK) return ret;
     HIPCHK(ctx, hipSetDevice(ctx->device));
-    hipStream_t cin = s->in_stream ? s->in_stream : ctx->copy_in;
+    /* the copies in on the context's copy-in stream, one group behind the other; the Rice decoder on one of the pooled streams, so that
+     * the groups' decoders run side by side (a pooled stream is shared by every fourth group: its decoder waits for the one four groups
+     * back, which has had 9 ms by then) */
+    hipStream_t cin = ctx->copy_in, rst = s->in_stream ? s->in_stream : ctx->copy_in;
     const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames;
     memset(s->h_stream + stream_bytes, 0, 16);                 /* the reader loads whole 8-byte words */
@@ -1558,11 +1587,12 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
         RiceDecodeArgs a; memset(&a, 0, sizeof(a));
         a.words = (const uint32_t *)s->d_stream; a.nbytes = stream_bytes; a.bitpos = s->d_bitpos; a.nsmp = (const uint32_t *)(s->d_bitpos + 2 * (size_t)s->max_frames); a.bitend = s->d_bitpos + s->max_frames;
         a.resid = s->d_data; a.endbit = s->d_endbit; a.F = num_frames; a.C = s->shape.num_channels; a.S = s->shape.num_samples_per_block;
-        const int sp_ = span_begin(ctx, 28, cin);
-        hipLaunchKernelGGL(k_rice_decode, dim3((num_frames + RDEC_THREADS - 1) / RDEC_THREADS), dim3(RDEC_THREADS), 0, cin, a);
-        span_end(ctx, sp_, cin);
+        if (rst != cin) { HIPCHK(ctx, hipEventRecord(s->ev_in, cin)); HIPCHK(ctx, hipStreamWaitEvent(rst, s->ev_in, 0)); }
+        const int sp_ = span_begin(ctx, 28, rst);
+        hipLaunchKernelGGL(k_rice_decode, dim3((num_frames + RDEC_THREADS - 1) / RDEC_THREADS), dim3(RDEC_THREADS), 0, rst, a);
+        span_end(ctx, sp_, rst);
     }
-    HIPCHK(ctx, hipEventRecord(s->ev_in, cin));
+    HIPCHK(ctx, hipEventRecord(s->ev_in, rst));
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, s->ev_in, 0));
     if ((ret = LINNEAmd_DecodeFramesDevice(ctx, &s->shape, s->d_data, num_samples, num_frames, s->d_prm)) != LNN_OK) return ret;
     if (s->d_out16) {
