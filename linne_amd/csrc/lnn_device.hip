@@ -1326,8 +1326,15 @@ struct LINNEAmdSlot {
 static int ctx_copy_streams(LINNEAmdContext *ctx)
 {
     if (ctx->has_copy) return LNN_OK;
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
-    HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+    /* The three kinds of work a staging pipeline overlaps must sit on different hardware queues: streams that share one run in order
+     * whatever their events allow (an H2D behind a kernel that waits for another group's decoder: DecodeWhole took 67 ms in one process
+     * and 25 in another, by which queue the copy-in stream had drawn).  Which queue of a priority level's pool a stream gets is
+     * round-robin over everything the process ever created at that level -- so the copy-in stream (and the Rice decoders' streams) are
+     * created at HIGH priority and the copy-out stream at LOW: three pools, and in each only this library's streams. */
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          /* (numerically lowest = highest priority) */
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_in, hipStreamNonBlocking, prio_hi));
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_out, hipStreamNonBlocking, prio_lo));
     ctx->has_copy = 1;
     return LNN_OK;
 }
@@ -1425,7 +1432,16 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
         s->stream_cap = ((uint64_t)max_frames * (CS * ((shape->bits_per_sample + 7u) / 8u) + CS / 8u + 1024u) + 4095u) & ~(uint64_t)4095u;
         if (e == hipSuccess) {
             const int k = ctx->rice_next++ % LNN_RICE_STREAMS;
-            if (k >= ctx->n_rice_pool) { e = hipStreamCreateWithFlags(&ctx->rice_pool[k], hipStreamNonBlocking); if (e == hipSuccess) ctx->n_rice_pool = k + 1; }
+            if (k >= ctx->n_rice_pool) {
+                /* HIGH priority: the runtime keeps a pool of hardware queues per priority level, so these streams cannot land on the
+                 * queue of the synthesis or of a copy stream whatever else the process created before (which of the normal pool's
+                 * queues a stream gets is round-robin over the process's whole history: DecodeWhole took 25 ms in one process and
+                 * 67 ms in another before this) -- and a launch of a few dozen latency-bound waves is what should go first anyway */
+                int lo = 0, hi = 0;
+                (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      /* (numerically lowest = highest priority) */
+                e = hipStreamCreateWithPriority(&ctx->rice_pool[k], hipStreamNonBlocking, hi);
+                if (e == hipSuccess) ctx->n_rice_pool = k + 1;
+            }
             if (e == hipSuccess) s->in_stream = ctx->rice_pool[k];
         }
         if (e == hipSuccess) e = hipHostMalloc((void **)&s->h_stream, s->stream_cap + 16, hipHostMallocDefault);
