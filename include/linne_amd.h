@@ -118,7 +118,10 @@ int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEA
 int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         int32_t *d_data, const uint32_t *h_num_samples, uint32_t num_frames, const int32_t *d_params);
 
-/* Same two paths on host buffers (H2D, kernels, D2H, synchronous); what EncodeBlock / DecodeBlock use. */
+/* Same two paths on host buffers (H2D, kernels, D2H, synchronous); what EncodeBlock / DecodeBlock use.  Where the parameter records
+ * are in HOST memory -- here and in the staging slots' decode submits -- the [-128, 127] contract of the coefficients is CHECKED:
+ * a record outside it is refused with LINNE_APIRESULT_INVALID_FORMAT's value (2), so that no result depends on which form of the
+ * synthesis the batch size picks. */
 int LINNEAmd_EncodeFramesHost(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         const int32_t *pcm, const uint32_t *num_samples, uint32_t num_frames,
         int32_t *residual, int32_t *params, double *stats);

@@ -1020,6 +1020,26 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
     return LNN_OK;
 }
 
+/* The throughput and latency forms of the synthesis carry a coefficient as int8 (the format's range: the coefficients are 8-bit
+ * Huffman symbols, linne_decoder.c:452-470); the lanes form would take any int32.  A parameter record with a coefficient outside
+ * [-128, 127] is no LINNE stream's: the entry points that see the records on the HOST refuse it, so that the result never depends on
+ * which form the batch size picked (include/linne_amd.h states the contract for records that are already in HBM). */
+static int params_in_range(LINNEAmdContext *ctx, const HostShape *hs, uint32_t C, const int32_t *h_params, uint32_t num_frames)
+{
+    uint32_t ncoef = 0;
+    for (uint32_t l = 0; l < hs->L; l++) ncoef += hs->P[l];
+    const uint64_t rows = (uint64_t)num_frames * C;
+    uint32_t bad = 0;
+    for (uint64_t r = 0; r < rows; r++) {
+        const int32_t *c = h_params + r * LINNE_AMD_PARAM_WORDS + LINNE_AMD_PRM_COEF;
+        uint32_t acc = 0;
+        for (uint32_t i = 0; i < ncoef; i++) acc |= (uint32_t)(c[i] + 128) & ~255u;
+        bad |= acc;
+    }
+    if (bad) { snprintf(ctx->err, sizeof(ctx->err), "a coefficient outside [-128, 127] in the parameter records (not a LINNE stream's)"); return LNN_INVALID_FORMAT; }
+    return LNN_OK;
+}
+
 extern "C" int LINNEAmd_DecodeFramesDevice(struct LINNEAmdContext *ctx, const struct LINNEAmdShape *shape,
         int32_t *d_data, const uint32_t *h_num_samples, uint32_t num_frames, const int32_t *d_params)
 {
@@ -1182,6 +1202,8 @@ extern "C" int LINNEAmd_DecodeFramesHost(struct LINNEAmdContext *ctx, const stru
     if (!ctx) return LNN_INVALID_ARGUMENT;
     if (!shape || !data || !params) return LNN_INVALID_ARGUMENT;
     if (num_frames == 0) return LNN_OK;
+    { HostShape hs_; int r_ = shape_info(shape, &hs_); if (r_ != LNN_OK) { snprintf(ctx->err, sizeof(ctx->err), "invalid shape"); return r_; }
+      if ((r_ = params_in_range(ctx, &hs_, shape->num_channels, params, num_frames)) != LNN_OK) return r_; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t CS = (uint64_t)shape->num_channels * shape->num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * (uint64_t)shape->num_channels * num_frames;
@@ -1552,6 +1574,7 @@ extern "C" int LINNEAmd_SlotDecodeSubmit(struct LINNEAmdSlot *s, const uint32_t 
     if (num_frames == 0 || num_frames > s->max_frames) { snprintf(ctx->err, sizeof(ctx->err), "SlotDecodeSubmit: %u frames in a slot of %u", num_frames, s->max_frames); return LNN_INVALID_ARGUMENT; }
     int ret = LINNEAmd_SlotWait(s);
     if (ret != LNN_OK) return ret;
+    { HostShape hs_; if ((ret = shape_info(&s->shape, &hs_)) != LNN_OK || (ret = params_in_range(ctx, &hs_, s->shape.num_channels, s->h_prm, num_frames)) != LNN_OK) return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     const uint64_t C = s->shape.num_channels, CS = C * s->shape.num_samples_per_block;
     const uint64_t nb = sizeof(int32_t) * CS * num_frames, pb = sizeof(int32_t) * LINNE_AMD_PARAM_WORDS * C * num_frames;
@@ -1578,6 +1601,7 @@ extern "C" int LINNEAmd_SlotDecodeStreamSubmit(struct LINNEAmdSlot *s, uint64_t 
     if (num_frames == 0 || num_frames > s->max_frames || stream_bytes > s->stream_cap) { snprintf(ctx->err, sizeof(ctx->err), "SlotDecodeStreamSubmit: %u frames / %llu bytes in a slot of %u / %llu", num_frames, (unsigned long long)stream_bytes, s->max_frames, (unsigned long long)s->stream_cap); return LNN_INVALID_ARGUMENT; }
     int ret = LINNEAmd_SlotWait(s);
     if (ret != LNN_OK) return ret;
+    { HostShape hs_; if ((ret = shape_info(&s->shape, &hs_)) != LNN_OK || (ret = params_in_range(ctx, &hs_, s->shape.num_channels, s->h_prm, num_frames)) != LNN_OK) return ret; }
     HIPCHK(ctx, hipSetDevice(ctx->device));
     /* the copies in on the context's copy-in stream, one group behind the other; the Rice decoder on one of the pooled streams, so that
      * the groups' decoders run side by side (a pooled stream is shared by every fourth group: its decoder waits for the one four groups

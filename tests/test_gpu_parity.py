@@ -1,6 +1,7 @@
 """GPU parity tests (-m gpu): the HIP path, called through the C-ABI, against the oracle on the same inputs.
 Bar: bit-exact (all outputs are integers; the double-precision analysis feeds an 8-bit quantiser and an argmin,
 so any deviation in operation order would show up as differing coefficients / unit counts)."""
+import os
 import numpy as np
 import pytest
 
@@ -983,3 +984,29 @@ def test_host_libm_values_on_the_gpu_box():
     SIN-window samples and Cholesky pivots bit for bit (tests/golden/libm_values.json) -- a mismatch here explains 162 differing hashes"""
     from test_abi_cpu import test_host_libm_values_are_the_build_containers
     test_host_libm_values_are_the_build_containers()
+
+
+def test_decode_refuses_a_coefficient_outside_the_formats_range(ctx):
+    """The stream's coefficients are 8-bit Huffman symbols (libs/linne_decoder/src/linne_decoder.c:452-470): [-128, 127].  The
+    throughput / latency forms of the synthesis carry them as int8, the lanes form would take any int32 -- so a parameter record with a
+    coefficient outside the range must be REFUSED where the host can see it (LINNEAmd_DecodeFramesHost), whatever the batch size
+    would have picked; the untouched batch still decodes."""
+    nch, bits, block, preset = 2, 16, 2048, 7
+    frames = music_frames(3, nch, block, bits, seed=2718)
+    shape = ctx.shape(nch, bits, block, preset, True)
+    res, prm, st = ctx.encode_frames_host(shape, frames)
+    assert np.array_equal(ctx.decode_frames_host(shape, res, prm), frames)
+    for kernel in (None, "lanes", "rows"):
+        for value in (128, -129, 70000):
+            bad = prm.copy()
+            bad[1, 1, linne_amd.PARAM_WORDS - 20] = value          # a coefficient of the last layer, second frame, second channel
+            old = os.environ.pop("LINNE_AMD_DECODE_KERNEL", None)
+            if kernel:
+                os.environ["LINNE_AMD_DECODE_KERNEL"] = kernel
+            try:
+                with pytest.raises(linne_amd.LinneAmdError, match="-> 2"):
+                    ctx.decode_frames_host(shape, res, bad)
+            finally:
+                os.environ.pop("LINNE_AMD_DECODE_KERNEL", None)
+                if old is not None:
+                    os.environ["LINNE_AMD_DECODE_KERNEL"] = old
