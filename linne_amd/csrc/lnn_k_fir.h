@@ -332,7 +332,14 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
 #pragma unroll
     for (int i = 0; i < HP + FIR_SPL; i += 2) { const lnn_d2 v = *(const lnn_d2 *)(xc - HP + i); wv[i] = v.x; wv[i + 1] = v.y; }
     const bool live = s < na;
-    const bool fast = live && (s >= (uint32_t)P) && (s + FIR_SPL - 1 < na) && ((na % (uint32_t)(FIR_SPL * P)) == 0);
+    /* A tile that lies whole inside a frame of whole 8-sample groups per finest unit (every tile of a 10 240-sample frame) takes the
+     * register form in EVERY lane, as straight-line code without a per-lane test around each trial (round 4: those tests and their
+     * exec-mask branches were a good part of the ~900 instructions a wave spent per tile on 248 multiply-adds).  The first lanes of
+     * the first tile are no exception: the history in front of sample 0 is staged as zeros, and a tap on a zero adds +-0.0 to a chain
+     * -- the reference's ramp (linne_network.c:320-327) term for term; only sample 0 itself, which the reference's loss leaves out,
+     * is masked. */
+    const bool tile_fast = ((na % (uint32_t)(FIR_SPL * P)) == 0) && (s0 + FIR_TILE <= na);          /* (uniform) */
+    const bool fast = tile_fast || (live && (s >= (uint32_t)P) && (s + FIR_SPL - 1 < na) && ((na % (uint32_t)(FIR_SPL * P)) == 0));
     const uint32_t fine_unit = fast ? s / (na >> (NT - 1)) : 0u;   /* my samples' unit under the finest split (one division for all trials: the units nest) */
     for (uint32_t rr_ = 0; rr_ < nr; rr_++) {
     const uint32_t job = job0 + rr_;
@@ -340,6 +347,35 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
     double ps[NT], fwd[FIR_SPL];
 #pragma unroll
     for (int j = 0; j < FIR_SPL; j++) fwd[j] = 0.0;
+/* the register form of one trial (t and np are constants where it is expanded: the trial loops are unrolled) */
+#define FS_REGISTER_FORM() do { \
+                const double *hb = hs[t] + (size_t)(fine_unit >> (NT - 1 - t)) * np; \
+                double h[(P >> 0)]; \
+                _Pragma("unroll") for (int k = 0; k < np; k++) h[k] = hb[k]; \
+                _Pragma("unroll") for (int j = 0; j < FIR_SPL; j++) { \
+                    double term; \
+                    if (SPEC && t == 0) {                           /* one chain for two results, as in k_fir2's dual form (search_slack) */ \
+                        double acc2 = 0.0; \
+                        _Pragma("unroll") for (int k = 0; k < np; k++) acc2 += h[k] * wv[HP - np + k + j]; \
+                        fwd[j] = wv[HP + j] + acc2; \
+                        term = fabs(fwd[j]); \
+                    } else { \
+                        double acc = wv[HP + j];                     /* fused multiply-adds: inside the certificate's interval (see k_fir2) */ \
+                        _Pragma("unroll") for (int k = 0; k < np; k++) acc = __builtin_fma(h[k], wv[HP - np + k + j], acc); \
+                        term = fabs(acc); \
+                    } \
+                    if (j == 0) term = (s == 0u) ? 0.0 : term;      /* sample 0 is not part of the loss (the reference's unit 0 starts at s = 1) */ \
+                    sum += term; \
+                } } while (0)
+    if (tile_fast) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const int np = P >> t;                                 /* a constant once the loop is unrolled */
+            double sum = 0.0;
+            if ((uint32_t)t < ntr) FS_REGISTER_FORM();
+            ps[t] = sum;
+        }
+    } else
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         constexpr int dummy = 0; (void)dummy;
@@ -347,27 +383,8 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         const uint32_t u = 1u << t, n = na / u;
         double sum = 0.0;
         if ((uint32_t)t < ntr && live) {
-            if (fast) {
-                const double *hb = hs[t] + (size_t)(fine_unit >> (NT - 1 - t)) * np;
-                double h[(P >> 0)];
-#pragma unroll
-                for (int k = 0; k < np; k++) h[k] = hb[k];
-#pragma unroll
-                for (int j = 0; j < FIR_SPL; j++) {
-                    if (SPEC && t == 0) {                           /* one chain for two results, as in k_fir2's dual form (search_slack) */
-                        double acc2 = 0.0;
-#pragma unroll
-                        for (int k = 0; k < np; k++) acc2 += h[k] * wv[HP - np + k + j];
-                        fwd[j] = wv[HP + j] + acc2;
-                        sum += fabs(fwd[j]);
-                    } else {
-                        double acc = wv[HP + j];                     /* fused multiply-adds: inside the certificate's interval (see k_fir2) */
-#pragma unroll
-                        for (int k = 0; k < np; k++) acc = __builtin_fma(h[k], wv[HP - np + k + j], acc);
-                        sum += fabs(acc);
-                    }
-                }
-            } else {
+            if (fast) FS_REGISTER_FORM();
+            else {
 #pragma unroll 1
                 for (int j = 0; j < FIR_SPL; j++) {
                     const uint32_t sj = s + j;
