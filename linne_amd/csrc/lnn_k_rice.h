@@ -418,8 +418,10 @@ __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
             for (uint32_t i = 0; i < RDEC_TILE; i++) {
                 const uint32_t s = s0 + i;
                 int32_t val = 0;
-                if (live && !bad && s < n) {
-                    if (s == next_part) {                                   /* a partition starts: its parameter */
+                const bool act = live && !bad && s < n;
+                /* a partition starts in some lane: its parameter (the lanes' partitions differ in length: a few percent of the samples) */
+                if (__any(act && s == next_part)) {
+                    if (act && s == next_part) {
                         if (first) { k2 = r.get(5); first = false; }
                         else {
                             const uint32_t nd = r.zero_run(nbits_total, bad) + 1u;
@@ -432,17 +434,27 @@ __global__ __launch_bounds__(RDEC_THREADS) void k_rice_decode(RiceDecodeArgs a)
                         k2 &= 31u; k1 = k2 + 1u; k1pow = 1u << (k1 & 31u);
                         next_part += ns;
                     }
-                    if (!bad) {
-                        /* The usual sample -- a zero run of at most 24, run and binary part within the 32 bits in view, the next
-                         * word staged in the ring: ONE look at the stream and one branch-free step over it (round 4: a look and a
-                         * step for the run, another pair for the binary part, each step a divergent branch around an LDS read:
-                         * ~100 instructions a sample where the walk of a block is all that a launch's 8 ms are).  Anything else
-                         * takes the general reader. */
-                        const uint32_t t = r.peek();
-                        uint32_t quot = (uint32_t)__clz((int)t), low;
-                        const uint32_t kk = (quot == 0u) ? k1 : k2, used = quot + 1u + kk;
-                        if ((t >> 7) != 0u && used <= 32u && r.widx < r.hi) {
-                            low = (kk != 0u) ? ((t << (quot + 1u)) >> (32u - kk)) : 0u;      /* (quot + 1 <= 25, 1 <= 32 - kk <= 31) */
+                }
+                {
+                    /* The usual sample -- a zero run of at most 24, run and binary part within the 32 bits in view, the next word
+                     * staged in the ring: ONE look at the stream and one branch-free step over it; when that holds in EVERY lane
+                     * that has a sample (it nearly always does) the wave runs it as straight-line code, a lane without a sample
+                     * stepping over 0 bits (round 4: a look and a step for the run, another pair for the binary part, each step a
+                     * divergent branch around an LDS read: ~100 instructions a sample where the walk of a block is all that a
+                     * launch's 8 ms are).  Anything else takes the general reader, lane by lane. */
+                    const bool go = act && !bad;
+                    const uint32_t t = r.peek();
+                    uint32_t quot = (uint32_t)__clz((int)t), low;
+                    const uint32_t kk = (quot == 0u) ? k1 : k2, used = quot + 1u + kk;
+                    const bool usual = (t >> 7) != 0u && used <= 32u && r.widx < r.hi;
+                    if (__all(usual || !go)) {
+                        low = (kk != 0u) ? ((t << (quot + 1u)) >> (32u - kk)) : 0u;          /* (quot + 1 <= 25, 1 <= 32 - kk <= 31) */
+                        r.skip_staged(go ? used : 0u);
+                        const uint32_t v = (quot == 0u) ? low : (low + k1pow + ((quot - 1u) << k2));
+                        val = go ? ((int32_t)(v >> 1) ^ -(int32_t)(v & 1u)) : 0;
+                    } else if (go) {
+                        if (usual) {
+                            low = (kk != 0u) ? ((t << (quot + 1u)) >> (32u - kk)) : 0u;
                             r.skip_staged(used);
                         } else {
                             if (t >> 7) r.skip(quot + 1u);
