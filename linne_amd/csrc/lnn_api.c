@@ -741,10 +741,10 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
          * on the link or in the decoder */
         const char *eg = getenv("LINNE_AMD_DECODE_GROUPS");
         const uint32_t S_ = decoder->shape.num_samples_per_block, F_ = (uint32_t)(((uint64_t)hd->num_samples + S_ - 1) / S_);
-        /* eight groups for mono / stereo; fewer for more channels: a block's channels are ONE serial code, the decoder's latency grows
-         * with them (36 ms per launch for 8 channels) and a group's launch should not outlast the host's work on the others
-         * (8-channel 24-bit 96 kHz, 10 minutes: 115 ms with two groups, 145 with eight) */
-        const uint32_t ng_auto = decoder->shape.num_channels <= 2u ? 8u : (16u / decoder->shape.num_channels < 2u ? 2u : 16u / decoder->shape.num_channels);
+        /* eight groups for mono / stereo, four for more channels: a block's channels are ONE serial code, so the decoder's latency per
+         * launch grows with them and a group's launch should not outlast the host's work on the others (8 channels, 24 bits, 96 kHz,
+         * 10 minutes: 80 ms with two groups, 67 with four, 72 with six or eight; 4 channels: 34.5 with four, 37.8 with eight) */
+        const uint32_t ng_auto = decoder->shape.num_channels <= 2u ? 8u : 4u;
         const uint32_t ng = (eg && atoi(eg) > 0) ? (uint32_t)atoi(eg) : ng_auto;
         const uint64_t cap = (1ull << 30) / ((uint64_t)decoder->shape.num_channels * S_ * sizeof(int32_t)) + 1;
         /* a group keeps the synthesis in its throughput form (from 1536 channel-frames on, lnn_device.hip) */
