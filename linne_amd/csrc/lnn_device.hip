@@ -1355,8 +1355,14 @@ static int ctx_copy_streams(LINNEAmdContext *ctx)
      * created at HIGH priority and the copy-out stream at LOW: three pools, and in each only this library's streams. */
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);          /* (numerically lowest = highest priority) */
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_in, hipStreamNonBlocking, prio_hi));
-    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->copy_out, hipStreamNonBlocking, prio_lo));
+    if (hipStreamCreateWithPriority(&ctx->copy_in, hipStreamNonBlocking, prio_hi) != hipSuccess) {        /* (a runtime without priorities: plain streams) */
+        (void)hipGetLastError();
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_in, hipStreamNonBlocking));
+    }
+    if (hipStreamCreateWithPriority(&ctx->copy_out, hipStreamNonBlocking, prio_lo) != hipSuccess) {
+        (void)hipGetLastError();
+        HIPCHK(ctx, hipStreamCreateWithFlags(&ctx->copy_out, hipStreamNonBlocking));
+    }
     ctx->has_copy = 1;
     return LNN_OK;
 }
@@ -1462,6 +1468,7 @@ extern "C" struct LINNEAmdSlot *LINNEAmd_SlotCreateEx(struct LINNEAmdContext *ct
                 int lo = 0, hi = 0;
                 (void)hipDeviceGetStreamPriorityRange(&lo, &hi);      /* (numerically lowest = highest priority) */
                 e = hipStreamCreateWithPriority(&ctx->rice_pool[k], hipStreamNonBlocking, hi);
+                if (e != hipSuccess) { (void)hipGetLastError(); e = hipStreamCreateWithFlags(&ctx->rice_pool[k], hipStreamNonBlocking); }
                 if (e == hipSuccess) ctx->n_rice_pool = k + 1;
             }
             if (e == hipSuccess) s->in_stream = ctx->rice_pool[k];
