@@ -21,7 +21,8 @@
 __device__ __forceinline__ void lds_dma16(const void *g, void *lds_wave_base)
 {
     const uint32_t base = (uint32_t)(size_t)(__attribute__((address_space(3))) void *)lds_wave_base;
-    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(base), "v"(g) : "memory", "m0");
+    uint32_t keep;                                                  /* M0 is the compiler's: handed back as it was (the s_nop: a scalar write of M0 needs a wait state before an LDS-DMA load reads it, and nothing inserts it inside an asm) */
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "s"(base), "v"(g) : "memory");
 }
 template <int N> __device__ __forceinline__ void hist_wait_loads(double (&r)[N])
 {
