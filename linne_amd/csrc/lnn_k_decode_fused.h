@@ -18,11 +18,6 @@
 #ifndef LNN_K_DECODE_FUSED_H_INCLUDED
 #define LNN_K_DECODE_FUSED_H_INCLUDED
 
-#if defined(SF_EXP) && SF_EXP == 3
-#define defined_SF_EXP3 true
-#else
-#define defined_SF_EXP3 false
-#endif
 #define SF_PROD 8                          /* producer waves (layer 0): eight channel-frames each */
 #define SF_WAVES (SF_PROD + 3)             /* + the de-emphasis wave + two waves that load and store */
 #define SF_STRIDE 65u                      /* words from a tile row to the next */
@@ -108,9 +103,6 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
 #pragma unroll 1
             do {
                 int32_t *const cell = trow + ((m >> 3) & 3u) * SF_TILE + 8u * (m & 7u);
-#if defined(SF_EXP) && SF_EXP == 2
-                m++; if ((m & 7u) == 0u) __syncthreads(); continue;
-#endif
                 const int32_t res = *cell;
                 const uint32_t acc0 = half_l + accB;
                 uint32_t acc = acc0, nb = 0;
@@ -153,7 +145,6 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
         __builtin_amdgcn_s_setprio(3);
 #pragma unroll 1
         for (uint32_t t = 0; t < ntiles + 3u; t++) {
-#if !defined(SF_EXP) || SF_EXP != 1
             if (t >= 2u && t - 2u < ntiles) {
                 int32_t *tl = trow + ((t - 2u) & 3u) * SF_TILE;
 #pragma unroll 16
@@ -164,7 +155,6 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
                     tl[s] = y;
                 }
             }
-#endif
             __syncthreads();
         }
         return;
@@ -202,7 +192,7 @@ __global__ __launch_bounds__(64 * SF_WAVES, 6) void k_synth_l0_de(DecPlan p)    
         if (ntiles) issue(0);
 #pragma unroll 1
         for (uint32_t t = 0; t < ntiles + 3u; t++) {
-            if (t >= 3u && !(defined_SF_EXP3)) {                   /* tile t - 3 leaves */
+            if (t >= 3u) {                   /* tile t - 3 leaves */
                 const uint32_t to = t - 3u, s0 = to * 64u + i4;
                 const int32_t *tb = tl0 + (to & 3u) * SF_TILE;
 #pragma unroll
