@@ -15,6 +15,7 @@
 #define LNN_MAXSUB      8
 #define LNN_META        8
 typedef double lnn_d2 __attribute__((ext_vector_type(2)));
+typedef int lnn_v4i __attribute__((ext_vector_type(4)));
 
 /* one distinct frame length of a batch (full frames, the ragged tail, ...) */
 struct DevClass {
@@ -53,6 +54,8 @@ struct Plan {
     uint32_t search_long;               /* the long layer's search comes from k_search_long where it takes the job (LINNE_AMD_SEARCH_LONG, default 1) */
     uint32_t job_off;                   /* k_fir2: the launch covers the jobs job_off .. (its blockIdx.x is relative: the search of the frames k_search_long leaves) */
     uint32_t prep_general;              /* LINNE_AMD_PREP_GENERAL=1 (tests, A/B runs): k_prep streams the channel through global memory whatever its size */
+    uint32_t prep_defer;                /* k_prep hands the channel-frames whose pre-emphasis correlations are not exact integers (loud 24-bit material) to k_prep_slow (lanes = channel-frames) instead of running their ordered chains on two lanes of its own block (LINNE_AMD_PREP_DEFER, default 1; needs S % 4 == 0) */
+    uint32_t *prep_slow_n, *prep_slow_rows;   /* their count (one word, zeroed before k_prep) and rows f * C + ch of the chunk, in the order the blocks arrived */
     uint32_t fused_last;                /* the last layer's forward pass and loss come from k_fwd_loss where it takes the job (fwd_loss_takes) */
     RowRuns runs[2];                    /* [0] rows = channel-frames (layer 0), [1] rows = jobs */
     uint32_t P[LNN_MAXL], coef_off[LNN_MAXL];

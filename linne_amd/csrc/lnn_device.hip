@@ -91,7 +91,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, prep_defer /* LINNE_AMD_PREP_DEFER (default 1): inexact pre-emphasis sums go to k_prep_slow */, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -300,6 +300,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.search_long = env_int("LINNE_AMD_SEARCH_LONG", 1);
     ctx->knob.rows16 = env_int("LINNE_AMD_ROWS16", 1);
     ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
+    ctx->knob.prep_defer = env_int("LINNE_AMD_PREP_DEFER", 1);
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
     ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", -1);
@@ -623,6 +624,7 @@ static uint64_t frame_scratch_bytes(const struct LINNEAmdShape *shape, const Hos
     b += J * LNN_MAXL * LNN_MAXP * sizeof(double);
     b += J * LNN_MAXL * sizeof(uint32_t);
     b += J * 2 * sizeof(double);
+    b += C * sizeof(uint32_t) + 512;                        /* k_prep_slow's list */
     if (af_iters)       /* the auxiliary-function pass: per channel-frame the normal matrices, reciprocals, vectors, problem lists */
         b += C * (sizeof(double) * ((uint64_t)hs->maxP * hs->maxP + S + 3 * LNN_MAXP + 3 * LNN_MAXU + 2) + sizeof(uint32_t) * (2 * LNN_MAXU + 1)) + 8192;
     if (af_iters || learning) b += C * (sizeof(uint32_t) + 2 * sizeof(double)) + 1024;        /* the winners of the search passes */
@@ -765,6 +767,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.search_long = ctx->knob.search_long ? 1u : 0u;
         p.rows16 = ctx->knob.rows16 ? 1u : 0u;
         p.prep_general = ctx->knob.prep_general ? 1u : 0u;
+        p.prep_defer = (ctx->knob.prep_defer && !ctx->knob.prep_general && (S & 3u) == 0 && CF * S * sizeof(int32_t) <= 0xFFFFFFFFull) ? 1u : 0u;      /* (k_prep_slow addresses xtmp with 32-bit byte offsets) */
         build_runs(&p.runs[0], ctx->cur_idx + f0, Fc, C); build_runs(&p.runs[1], ctx->cur_idx + f0, Fc, C * hs.R);
         p.hist = (ctx->knob.hist >= 0 ? (ctx->knob.hist != 0) : (J >= 12288u)) ? 1u : 0u;
         if (p.runs[1].mixed) p.hist = 0;                        /* more class runs than RowRuns holds: blocks may mix classes, which only the general kernels serve */
@@ -787,6 +790,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         TAKE(p.ptail, double, J * LNN_MAXT * LNN_MAXU); TAKE(p.ptail_set, uint8_t, J * LNN_MAXT * LNN_MAXU);
         TAKE(p.tloss, double, J * LNN_MAXT); p.npart = ((S + FIR_TILE - 1) / FIR_TILE) * (FIR_THREADS / 64); TAKE(p.tsum, double, J * LNN_MAXT * p.npart); TAKE(p.txmax, double, J * p.npart); TAKE(p.thsum, double, J * LNN_MAXT); TAKE(p.uncertain, uint8_t, J); TAKE(p.lparams, double, J * LNN_MAXL * LNN_MAXP);
         TAKE(p.lunits, uint32_t, J * LNN_MAXL); TAKE(p.jloss, double, J); TAKE(p.jtail, double, J);
+        TAKE(p.prep_slow_n, uint32_t, 64); TAKE(p.prep_slow_rows, uint32_t, CF);
         uint32_t *af_best = NULL; double *af_loss = NULL, *af_reg = NULL;
         TrainArgs tr; memset(&tr, 0, sizeof(tr));
         if (ctx->af_iters || ctx->learning) { TAKE(af_best, uint32_t, CF); TAKE(af_loss, double, CF); TAKE(af_reg, double, CF); }
@@ -803,7 +807,13 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
 #undef TAKE
         if ((uint64_t)(a - abase) > part_bytes) { snprintf(ctx->err, sizeof(ctx->err), "internal: arena overflow"); return LNN_NG; }
         const uint32_t sblocks = (S + 255) / 256;
-        { const int sp_ = span_begin(ctx, 1, st); hipLaunchKernelGGL(k_prep, dim3(Fc, C), dim3(PREP_THREADS), 0, st, p); span_end(ctx, sp_, st); }
+        if (p.prep_defer) HIPCHK(ctx, hipMemsetAsync(p.prep_slow_n, 0, sizeof(uint32_t), st));
+        {   /* k_prep, and behind it k_prep_slow for the channel-frames it listed (none for 16-bit material: its blocks leave at once) */
+            const int sp_ = span_begin(ctx, 1, st);
+            hipLaunchKernelGGL(k_prep, dim3(Fc, C), dim3(PREP_THREADS), 0, st, p);
+            if (p.prep_defer) hipLaunchKernelGGL(k_prep_slow, dim3((uint32_t)((CF + 63) / 64)), dim3(256), 0, st, p);
+            span_end(ctx, sp_, st);
+        }
         /* -a N: the auxiliary-function iterations on the coefficients k_select kept for layer l (lnn_k_af.h); synchronous: every
          * Cholesky pivot goes through the host's pow() */
         auto run_af = [&](const Plan &q, uint64_t Jq, uint32_t l, uint32_t cur, uint32_t iters) -> int {

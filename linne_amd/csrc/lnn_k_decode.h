@@ -391,7 +391,6 @@ __global__ __launch_bounds__(64) void k_synth_big(DecPlan p, uint32_t layer)
  *                     modulo 2^32 (the reference's wrap-around int32 arithmetic is associative, the planes recombine by shifts).
  * Coefficients are 8-bit by format (the stream codes them with a 256-symbol Huffman code; k_synth_small / k_synth_big rely on the
  * same range).  Frames too long for the LDS image stay with k_synthesize. */
-typedef int lnn_v4i __attribute__((ext_vector_type(4)));
 #define SP_RING 256u
 #define SP_RINGP 272u                   /* bytes from a digit plane to the next: the four planes' 16-byte reads of a window (one lane each) hit different banks */
 struct SpShared { uint32_t prog[LNN_MAXL + 1]; uint32_t pad[4]; int8_t ring[LNN_MAXL][4][SP_RINGP]; };

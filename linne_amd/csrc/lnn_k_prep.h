@@ -274,10 +274,27 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
         coefs[stage] = sh_coef;
         return sh_exact != 0;
     };
+    /* a channel whose sums are not exact integers (loud 24-bit material) needs the reference's ordered chains: 2 x 10 239 dependent
+     * adds.  With p.prep_defer it leaves this block as it came (after copy / zero padding / LR -> MS) into xtmp and goes onto
+     * k_prep_slow's list, where a lane runs a channel-frame's chains -- here they would occupy two lanes of the block while 254 wait
+     * (77 us per stage and block, eight blocks per CU: 9.6 ms for the 45 000 channel-frames of the 8-channel stress case) */
+    auto defer = [&]() {
+        int32_t *raw = p.xtmp + ((size_t)f * C + ch) * S;
+#pragma unroll
+        for (uint32_t r = 0; r < PREP2_MAXROUNDS; r++) {
+            if (r >= rounds) continue;
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < PREP2_RUN; j++) tile[PREP2_RUN * tid + j] = x[r][j + 2];
+            __syncthreads();
+            for (uint32_t i = tid; i < PREP2_ROUND; i += PREP_THREADS) { const uint32_t s = r * PREP2_ROUND + i; if (s < S) raw[s] = tile[i]; }
+        }
+        if (tid == 0) p.prep_slow_rows[atomicAdd(p.prep_slow_n, 1u)] = f * C + ch;
+    };
     /* stage 0 works on x, stage 1 on y[s] = x[s] - mulshr5(x[s ? s - 1 : 0], coef0) for s < n (0 beyond), recomputed where needed */
     const int32_t x_first = input_at(0);
     auto xv = [&](uint32_t r, uint32_t j) -> int32_t { return x[r][j + 2]; };
-    if (!stage_coef(xv, 0u)) { __syncthreads(); prep_general(p, sh[0], sh_coef, sh_prod); return; }
+    if (!stage_coef(xv, 0u)) { if (p.prep_defer) { defer(); return; } __syncthreads(); prep_general(p, sh[0], sh_coef, sh_prod); return; }
     const int32_t cf0 = coefs[0];
     auto yat = [&](uint32_t r, int32_t j) -> int32_t {          /* j = -1 .. 10 */
         const int64_t s = (int64_t)r * PREP2_ROUND + (int64_t)PREP2_RUN * tid + j;
@@ -288,7 +305,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
     auto yv = [&](uint32_t r, uint32_t j) -> int32_t { return yat(r, (int32_t)j); };
     firsts[0] = x_first;
     const int32_t y_first = (n > 0) ? (int32_t)((uint32_t)x_first - (uint32_t)mulshr5(x_first, cf0)) : 0;
-    if (!stage_coef(yv, 1u)) { __syncthreads(); prep_general(p, sh[0], sh_coef, sh_prod); return; }
+    if (!stage_coef(yv, 1u)) { if (p.prep_defer) { defer(); return; } __syncthreads(); prep_general(p, sh[0], sh_coef, sh_prod); return; }
     const int32_t cf1 = coefs[1];
     firsts[1] = y_first;
     if (tid == 0) {
@@ -311,6 +328,158 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
         for (uint32_t i = tid; i < PREP2_ROUND; i += PREP_THREADS) { const uint32_t s = r * PREP2_ROUND + i; if (s < S) out[s] = tile[i]; }
     }
 }
+
+/* k_prep_slow: the pre-emphasis of the channel-frames k_prep could not finish with integer sums (its list: Plan.prep_slow_rows),
+ * lanes = channel-frames.  linne_utility.c:158-193: corr0 = sum x[i]^2 and corr1 = sum x[i] x[i+1], i < n - 1, are double chains in
+ * sample order -- 10 239 dependent adds each, per stage.  A block takes 64 listed rows and walks them in tiles of 64 samples
+ * (coalesced 16-byte loads from xtmp, transposed through LDS, two buffers, one barrier per tile):
+ *   waves 0, 3   load tile t + 1 / request tile t + 2, half the rows each;
+ *   wave 1   corr0's chain of its 64 rows over tile t; wave 2: corr1's (a step: LDS read, conversion, multiply, add -- the products
+ *            and their order are the reference's; what lies at or behind n - 1 is not added);
+ *   pass A   the chains of stage 0 on x -> coefficient 0; pass B: of stage 1 on y[s] = x[s] - mulshr5(x[s ? s - 1 : 0], c0), formed
+ *            on the fly -> coefficient 1; pass C (all waves, 16 bytes per lane): z[s] = y[s] - mulshr5(y[s ? s - 1 : 0], c1) from
+ *            x[s - 2 .. s] into xint -- what prep_general leaves there, by the same integer arithmetic (linne_utility.c:196-212).
+ * Blocks beyond the list's end leave at once (16-bit material: all of them). */
+#define PS_WAVES 4
+__global__ __launch_bounds__(64 * PS_WAVES, 3) void k_prep_slow(Plan p)      /* (three blocks per CU: the 45 000 channel-frames of the 8-channel stress case are 704 blocks) */
+{
+    __shared__ __attribute__((aligned(16))) int32_t tile[2][64][68];      /* [tile mod 2][row][sample], rows 68 words apart: 16-byte accesses both ways -- the loader's (16 lanes of a row: 64 banks) and the chains' (lane = row: 16 lanes x 4 words hit banks 4 lane + j, all different) */
+    __shared__ double xch[64];                                    /* corr1 on its way to the wave that holds corr0 */
+    __shared__ int32_t cfs[2][64];                                /* the rows' coefficients */
+    __shared__ uint32_t rowid[64], nlen[64];
+    const uint32_t cnt = *p.prep_slow_n, base = blockIdx.x * 64u;
+    if (base >= cnt) return;
+    const uint32_t lane = threadIdx.x & 63u, S = p.S, C = p.C;
+    const uint32_t role = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t nv = (cnt - base < 64u) ? cnt - base : 64u;
+    const uint32_t row = p.prep_slow_rows[base + (lane < nv ? lane : nv - 1u)];      /* f * C + ch of the chunk */
+    const uint32_t f = row / C, ch = row - f * C;
+    const uint32_t n = p.cls[p.cls_of_frame[f]].n;
+    if (role == 0u) { rowid[lane] = row; nlen[lane] = n; }
+    uint32_t nmax = n, nmin = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_xor((int)nmax, o), b = (uint32_t)__shfl_xor((int)nmin, o);
+        nmax = a > nmax ? a : nmax; nmin = b < nmin ? b : nmin;
+    }
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax); nmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmin);
+    const uint32_t ntiles = (nmax + 63u) / 64u;
+    __syncthreads();
+    /* the loaders (waves 0 and 3, half the rows each): instruction k of loader h takes rows 4 (8 h + k) + (lane >> 4), samples
+     * 4 (lane & 15) .. + 3 of the tile */
+    const bool loader = (role == 0u || role == 3u);
+    const uint32_t rq = lane >> 4, i4 = 4u * (lane & 15u), r0l = (role == 3u) ? 32u : 0u;
+    uint32_t roff[8];                                             /* 32-bit BYTE offsets from xtmp (one uniform base + an offset register per load: eight 64-bit pointers were spilled, and a reload in front of each load made it wait for the one before); the host sets prep_defer only for chunks whose xtmp is below 4 GB */
+    const char *const xb = (const char *)p.xtmp;
+    lnn_v4i pre[8];
+    if (loader) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) roff[k] = rowid[r0l + 4 * k + rq] * S * 4u;
+    }
+    auto issue = [&](uint32_t t) {
+        const uint32_t s0 = t * 64u + i4;
+#pragma unroll
+        for (int k = 0; k < 8; k++) pre[k] = (s0 < S) ? *(const lnn_v4i *)(xb + (roff[k] + 4u * s0)) : lnn_v4i{ 0, 0, 0, 0 };      /* (S is a multiple of 4) */
+    };
+    auto commit = [&](uint32_t t) {
+#pragma unroll
+        for (int k = 0; k < 8; k++) *(lnn_v4i *)&tile[t & 1u][r0l + 4 * k + rq][i4] = pre[k];
+    };
+    int32_t first0 = 0, first1 = 0;                               /* the stages' first input samples (the decoder's initial state) */
+    int32_t c0 = 0;
+#pragma unroll 1
+    for (uint32_t pass = 0; pass < 2u; pass++) {
+        if (loader && ntiles) { issue(0); commit(0); if (ntiles > 1u) issue(1); }
+        __syncthreads();
+        double acc = 0.0, prevd = 0.0;                            /* (index -1: a zero whose products add +0.0) */
+        int32_t xprev = 0;
+#pragma unroll 1
+        for (uint32_t t = 0; t < ntiles; t++) {
+            if (loader) {
+                if (t + 1u < ntiles) { commit(t + 1u); if (t + 2u < ntiles) issue(t + 2u); }
+            } else {
+                const int32_t *tl = tile[t & 1u][lane];
+                if (t == 0u) { xprev = tl[0]; if (pass) first1 = (int32_t)((uint32_t)xprev - (uint32_t)mulshr5(xprev, c0)); else first0 = xprev; }
+                const bool whole = 64u * t + 64u <= nmin;          /* every row has all of the tile: no step asks where its row ends */
+                /* step g: the products of index g - 1 = (value before) x (value before | this value), added while g < n */
+#define PS_STEP(SQ_, GUARD_, PASS_, V_, S_) { \
+                    const int32_t v = (V_); \
+                    int32_t in_ = v; \
+                    if (PASS_) { in_ = (int32_t)((uint32_t)v - (uint32_t)mulshr5(xprev, c0)); if ((GUARD_) && 64u * t + (S_) >= n) in_ = 0; xprev = v; } \
+                    const double vd = (double)in_; \
+                    const double prod = (SQ_) ? prevd * prevd : prevd * vd; \
+                    if (!(GUARD_) || 64u * t + (S_) < n) acc += prod; \
+                    prevd = vd; }
+                /* a whole tile: the row's 64 samples first (a read waited for inside the chain costs the wave its latency per step), then 64
+                 * steps of straight-line code, eight at a time (the conversions do not depend on the chain: left alone the scheduler forms
+                 * all 64 first, in 128 registers) */
+#define PS_CHAIN(SQ_, PASS_) { lnn_v4i vv[16]; \
+                _Pragma("unroll") for (int k = 0; k < 16; k++) vv[k] = *(const lnn_v4i *)(tl + 4 * k); \
+                __builtin_amdgcn_sched_barrier(0); \
+                _Pragma("unroll") for (uint32_t s = 0; s < 64u; s++) { PS_STEP(SQ_, false, PASS_, vv[s >> 2][s & 3u], s) if ((s & 7u) == 7u) __builtin_amdgcn_sched_barrier(0); } }
+                /* a tile in which a row ends (a ragged last frame's, once per pass): step by step */
+#define PS_TAIL(SQ_, PASS_) { _Pragma("unroll 1") for (uint32_t s = 0; s < 64u; s++) PS_STEP(SQ_, true, PASS_, tl[s], s) }
+#define PS_CHAIN2(SQ_, PASS_) { if (whole) PS_CHAIN(SQ_, PASS_) else PS_TAIL(SQ_, PASS_) }
+                if (role == 1u) { if (pass) PS_CHAIN2(true, true) else PS_CHAIN2(true, false) }
+                else            { if (pass) PS_CHAIN2(false, true) else PS_CHAIN2(false, false) }
+#undef PS_CHAIN2
+#undef PS_TAIL
+#undef PS_CHAIN
+#undef PS_STEP
+            }
+            __syncthreads();
+        }
+        /* the stage's coefficient (linne_utility.c:176-190), in the lanes of wave 1 */
+        if (role == 2u) xch[lane] = acc;
+        __syncthreads();
+        if (role == 1u) {
+            const double corr0 = acc;
+            double corr1 = xch[lane];
+            int32_t coef;
+            corr1 /= corr0;
+            if ((corr0 < 1e-6) || (corr1 < 0.0)) coef = 0;
+            else { coef = (int32_t)round_away(corr1 * 32.0); if (coef >= 16) coef = 15; }
+            cfs[pass][lane] = coef;
+        }
+        __syncthreads();
+        c0 = cfs[0][lane];
+    }
+    if (role == 1u && lane < nv) {
+        int32_t *rec = p.prm + ((size_t)p.frame_map[f] * C + ch) * LINNE_AMD_PARAM_WORDS;
+        rec[LINNE_AMD_PRM_PREV + 0] = first0; rec[LINNE_AMD_PRM_PCOEF + 0] = cfs[0][lane];
+        rec[LINNE_AMD_PRM_PREV + 1] = first1; rec[LINNE_AMD_PRM_PCOEF + 1] = cfs[1][lane];
+    }
+    /* pass C: both stages' filters, four samples per lane */
+#pragma unroll 1
+    for (uint32_t r = 0; r < nv; r++) {
+        const uint32_t nr = nlen[r];
+        const int32_t a0 = cfs[0][r], a1 = cfs[1][r];
+        const int32_t *xin = p.xtmp + (size_t)rowid[r] * S;
+        int32_t *out = p.xint + (size_t)rowid[r] * S;
+        for (uint32_t g0 = 4u * threadIdx.x; g0 < S; g0 += 4u * 64u * PS_WAVES) {
+            const lnn_v4i v = *(const lnn_v4i *)(xin + g0);
+            int32_t xm1 = 0, xm2 = 0;
+            if (g0) { xm1 = xin[g0 - 1u]; xm2 = xin[g0 - 2u]; }
+            /* y[g] = x[g] - mulshr5(x[g ? g - 1 : 0], a0) for g < n, 0 beyond; z likewise from y */
+            int32_t yprev = g0 ? (int32_t)((uint32_t)xm1 - (uint32_t)mulshr5(xm2, a0)) : 0;      /* y[g0 - 1] (g0 >= 4: its own predecessor is x[g0 - 2]) */
+            if (g0 && g0 - 1u >= nr) yprev = 0;
+            int32_t xp = xm1;
+            lnn_v4i z;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const uint32_t g = g0 + (uint32_t)e;
+                const int32_t xg = v[e];
+                int32_t y = (int32_t)((uint32_t)xg - (uint32_t)mulshr5(g ? xp : xg, a0));
+                if (g >= nr) y = 0;
+                int32_t zz = (int32_t)((uint32_t)y - (uint32_t)mulshr5(g ? yprev : y, a1));
+                if (g >= nr) zz = 0;
+                z[e] = zz; xp = xg; yprev = y;
+            }
+            *(lnn_v4i *)(out + g0) = z;
+        }
+    }
+}
+#undef PS_WAVES
 
 /* block-type statistics (linne_encoder.c:494-503 -> lpc.c:810-848): SIN-window autocorrelation of the RAW channel at
  * order P0 = layer-0 size, then Levinson-Durbin.  One block per (frame, channel): all threads window a chunk of samples

@@ -1,4 +1,4 @@
-"""small driver for profiling: encode (and optionally decode) a batch of synthetic stereo frames once or twice"""
+"""small driver for profiling: encode (and optionally decode) a batch of synthetic frames (stereo 16-bit unless --channels / --bits say otherwise) once or twice"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,12 +12,14 @@ ap.add_argument("--decode", action="store_true")
 ap.add_argument("--preset", type=int, default=7)
 ap.add_argument("--no-timing", action="store_true")
 ap.add_argument("--tail", type=int, default=0, help="length of a ragged last frame (0: all frames full)")
+ap.add_argument("--channels", type=int, default=2)
+ap.add_argument("--bits", type=int, default=16)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-track = synth_track(a.frames * 10240 - ((10240 - a.tail) if a.tail else 0), 2, 16, 1, dev)
+track = synth_track(a.frames * 10240 - ((10240 - a.tail) if a.tail else 0), a.channels, a.bits, 1, dev)
 frames, nsm = frames_from_track(track, 10240)
 ctx = linne_amd.Context(0, scratch_bytes=12 << 30)
-shape = ctx.shape(2, 16, 10240, a.preset, True)
+shape = ctx.shape(a.channels, a.bits, 10240, a.preset, True)
 ctx.enable_timing(not a.no_timing)
 for r in range(a.reps):
     t0 = time.perf_counter()
