@@ -729,10 +729,10 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         const int sp_ = span_begin(ctx, 13, ss);
         /* batches: lanes = channel-frames (k_stats_rows); a few channel-frames: a block each (k_stats finishes one block sooner).  LINNE_AMD_STATS_ROWS forces either */
         const bool rows_form = ctx->knob.stats_rows >= 0 ? (ctx->knob.stats_rows != 0) : ((uint64_t)num_frames * C >= 1024u);
-        if (rows_form && pcm16 <= 1u && (S & 3u) == 0 && (hs.P[0] == 2u || hs.P[0] == 4u)) {
+        if (rows_form && (S & 3u) == 0 && (hs.P[0] == 2u || hs.P[0] == 4u)) {
             const dim3 g((num_frames * C + 63u) / 64u);
-            if (hs.P[0] == 4u) { if (pcm16) hipLaunchKernelGGL((k_stats_rows<5, true>), g, dim3(320), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<5, false>), g, dim3(320), 0, ss, ps); }
-            else               { if (pcm16) hipLaunchKernelGGL((k_stats_rows<3, true>), g, dim3(192), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<3, false>), g, dim3(192), 0, ss, ps); }
+            if (hs.P[0] == 4u) { if (pcm16 == 1u) hipLaunchKernelGGL((k_stats_rows<5, 1>), g, dim3(320), 0, ss, ps); else if (pcm16 == 2u) hipLaunchKernelGGL((k_stats_rows<5, 2>), g, dim3(320), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<5, 0>), g, dim3(320), 0, ss, ps); }
+            else               { if (pcm16 == 1u) hipLaunchKernelGGL((k_stats_rows<3, 1>), g, dim3(192), 0, ss, ps); else if (pcm16 == 2u) hipLaunchKernelGGL((k_stats_rows<3, 2>), g, dim3(192), 0, ss, ps); else hipLaunchKernelGGL((k_stats_rows<3, 0>), g, dim3(192), 0, ss, ps); }
         }
         else hipLaunchKernelGGL(k_stats, dim3(num_frames, C), dim3(STAT_THREADS), 0, ss, ps);
         span_end(ctx, sp_, ss); }

@@ -585,7 +585,7 @@ __device__ __forceinline__ double stats_rows_chain(const double (*xt)[STATR_T][6
     return r;
 }
 
-template <int NW, bool P16>          /* NW = P0 + 1 waves (3 or 5); P16: the PCM is staged as int16.  The host launches it only for S % 4 == 0 */
+template <int NW, int FMT>           /* NW = P0 + 1 waves (3 or 5); FMT: how the PCM is staged -- 0 int32, 1 int16, 2 packed little-endian 3-byte samples.  The host launches it only for S % 4 == 0 (a piece of four samples is then 16 / 8 / 12 bytes at a 4-byte boundary) */
 __global__ __launch_bounds__(64 * NW, 2) void k_stats_rows(Plan p)
 {
     constexpr uint32_t NPIECE = 64u * (STATR_T / 4u), NTH = 64u * NW, NP = (NPIECE + NTH - 1u) / NTH;     /* loader pieces (a row's 4 consecutive samples) per thread and tile */
@@ -622,7 +622,12 @@ __global__ __launch_bounds__(64 * NW, 2) void k_stats_rows(Plan p)
 #pragma unroll
         for (uint32_t q = 0; q < NP; q++) {
             const uint32_t s = ti * STATR_T + plsm[q], sc = (s + 3u < S) ? s : 0u;          /* (S % 4 == 0: a piece is inside the row or behind its end) */
-            if (P16) { const short4 v = *(const short4 *)((const int16_t *)p.pcm + pbase[q] + sc); raw[q] = make_int4(v.x, v.y, v.z, v.w); }
+            if (FMT == 1) { const short4 v = *(const short4 *)((const int16_t *)p.pcm + pbase[q] + sc); raw[q] = make_int4(v.x, v.y, v.z, v.w); }
+            else if (FMT == 2) {                            /* twelve bytes = four samples, least significant byte first */
+                const uint32_t *w = (const uint32_t *)((const uint8_t *)p.pcm + 3u * (pbase[q] + sc));
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+                raw[q] = make_int4((int32_t)(w0 << 8) >> 8, (int32_t)(((w0 >> 24) | (w1 << 8)) << 8) >> 8, (int32_t)(((w1 >> 16) | (w2 << 16)) << 8) >> 8, (int32_t)w2 >> 8);
+            }
             else raw[q] = *(const int4 *)(p.pcm + pbase[q] + sc);
             const uint32_t last = pn[q] ? pn[q] - 1u : 0u;
 #pragma unroll

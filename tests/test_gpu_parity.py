@@ -979,6 +979,11 @@ def test_prep_and_statistics_forms_agree(ctx, product, oracle, monkeypatch, stat
                         music(2, 3 * block + 555, 16, seed=32)], axis=1)
     for preset in (7, 0):
         assert product.encode_whole(x, 16, 44100, block, preset, True) == oracle.encode_whole(x, 16, 44100, block, preset, True)
+    # 24-bit material travels to the GPU as packed 3-byte samples: both statistics kernels (and k_prep) unpack it themselves
+    x24 = np.concatenate([music(2, 4 * block + 300, 24, seed=44), np.zeros((2, block), dtype=np.int32), music(2, 2 * block + 17, 24, seed=45) * 5], axis=1)
+    x24 = np.clip(x24, -(1 << 23), (1 << 23) - 1).astype(np.int32)
+    for preset in (7, 1):
+        assert product.encode_whole(x24, 24, 96000, block, preset, True) == oracle.encode_whole(x24, 24, 96000, block, preset, True)
 
 
 @pytest.mark.parametrize("prep_defer", ["1", "0"])
