@@ -333,7 +333,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
  * lanes = channel-frames.  linne_utility.c:158-193: corr0 = sum x[i]^2 and corr1 = sum x[i] x[i+1], i < n - 1, are double chains in
  * sample order -- 10 239 dependent adds each, per stage.  A block takes 64 listed rows and walks them in tiles of 64 samples
  * (coalesced 16-byte loads from xtmp, transposed through LDS, two buffers, one barrier per tile):
- *   waves 0, 3   load tile t + 1 / request tile t + 2, half the rows each;
+ *   waves 0, 3   load tile t + 1 / request tile t + 5 (four tiles in flight in registers), half the rows each;
  *   wave 1   corr0's chain of its 64 rows over tile t; wave 2: corr1's (a step: LDS read, conversion, multiply, add -- the products
  *            and their order are the reference's; what lies at or behind n - 1 is not added);
  *   pass A   the chains of stage 0 on x -> coefficient 0; pass B: of stage 1 on y[s] = x[s] - mulshr5(x[s ? s - 1 : 0], c0), formed
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(PREP_THREADS) void k_prep(Plan p)
  *            x[s - 2 .. s] into xint -- what prep_general leaves there, by the same integer arithmetic (linne_utility.c:196-212).
  * Blocks beyond the list's end leave at once (16-bit material: all of them). */
 #define PS_WAVES 4
-__global__ __launch_bounds__(64 * PS_WAVES, 3) void k_prep_slow(Plan p)      /* (three blocks per CU: the 45 000 channel-frames of the 8-channel stress case are 704 blocks) */
+__global__ __launch_bounds__(64 * PS_WAVES, 2) void k_prep_slow(Plan p)      /* (two blocks per CU: up to 512 blocks = 32 768 listed rows run at once; a chunk of the 8-channel stress case lists 22 500) */
 {
     __shared__ __attribute__((aligned(16))) int32_t tile[2][64][68];      /* [tile mod 2][row][sample], rows 68 words apart: 16-byte accesses both ways -- the loader's (16 lanes of a row: 64 banks) and the chains' (lane = row: 16 lanes x 4 words hit banks 4 lane + j, all different) */
     __shared__ double xch[64];                                    /* corr1 on its way to the wave that holds corr0 */
@@ -371,33 +371,58 @@ __global__ __launch_bounds__(64 * PS_WAVES, 3) void k_prep_slow(Plan p)      /* 
     const uint32_t rq = lane >> 4, i4 = 4u * (lane & 15u), r0l = (role == 3u) ? 32u : 0u;
     uint32_t roff[8];                                             /* 32-bit BYTE offsets from xtmp (one uniform base + an offset register per load: eight 64-bit pointers were spilled, and a reload in front of each load made it wait for the one before); the host sets prep_defer only for chunks whose xtmp is below 4 GB */
     const char *const xb = (const char *)p.xtmp;
-    lnn_v4i pre[8];
+    /* FOUR tiles on their way in registers: a tile is 1-2 us of chain work, and beside the previous group's Rice kernels and copies
+     * (whole streams) a load takes several -- with one tile in flight the launch took 3.2-3.8 ms there instead of 0.7 */
+    lnn_v4i pre[4][8];
     if (loader) {
 #pragma unroll
         for (int k = 0; k < 8; k++) roff[k] = rowid[r0l + 4 * k + rq] * S * 4u;
     }
-    auto issue = [&](uint32_t t) {
-        const uint32_t s0 = t * 64u + i4;
+    auto issue = [&](uint32_t t, lnn_v4i (&pr)[8]) {
+        const uint32_t s0 = t * 64u + i4, sb = 4u * ((s0 < S) ? s0 : 0u);      /* (S is a multiple of 4.  What a tile holds behind S >= n is never added: any readable address will do, and no load sits behind a branch) */
 #pragma unroll
-        for (int k = 0; k < 8; k++) pre[k] = (s0 < S) ? *(const lnn_v4i *)(xb + (roff[k] + 4u * s0)) : lnn_v4i{ 0, 0, 0, 0 };      /* (S is a multiple of 4) */
+        for (int k = 0; k < 8; k++) pr[k] = *(const lnn_v4i *)(xb + (roff[k] + sb));
     };
-    auto commit = [&](uint32_t t) {
+    auto commit = [&](uint32_t t, const lnn_v4i (&pr)[8]) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) *(lnn_v4i *)&tile[t & 1u][r0l + 4 * k + rq][i4] = pre[k];
+        for (int k = 0; k < 8; k++) *(lnn_v4i *)&tile[t & 1u][r0l + 4 * k + rq][i4] = pr[k];
     };
+    /* the chains are the launch's critical path -- a dependent add per step -- and the launch often runs beside the previous group's
+     * Rice kernels (whole streams) or the other half's analysis: their steps go first */
+    if (loader) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
     int32_t first0 = 0, first1 = 0;                               /* the stages' first input samples (the decoder's initial state) */
     int32_t c0 = 0;
 #pragma unroll 1
     for (uint32_t pass = 0; pass < 2u; pass++) {
-        if (loader && ntiles) { issue(0); commit(0); if (ntiles > 1u) issue(1); }
-        __syncthreads();
         double acc = 0.0, prevd = 0.0;                            /* (index -1: a zero whose products add +0.0) */
         int32_t xprev = 0;
+        if (loader) {
+            /* the loaders' own walk over the tiles (the same barriers as the chains'): iteration t writes tile t + 1 into LDS and
+             * requests tile t + 5 into the registers that held it; unrolled over the four register stages */
+            uint32_t z = 0;
+            asm volatile("" : "+s"(z));                            /* (a zero the compiler cannot see through: the first tiles' 40 addresses are the same in both passes, and it kept them -- 80 registers, spilled -- instead of adding an offset to a base) */
+            if (ntiles) { issue(z, pre[0]); commit(0, pre[0]); }
+            if (ntiles > 1u) issue(z + 1u, pre[1]);
+            if (ntiles > 2u) issue(z + 2u, pre[2]);
+            if (ntiles > 3u) issue(z + 3u, pre[3]);
+            if (ntiles > 4u) issue(z + 4u, pre[0]);
+            __syncthreads();
+#pragma unroll 1
+            for (uint32_t t4 = 0; t4 < ntiles; t4 += 4u) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t t = t4 + (uint32_t)u;
+                    if (t < ntiles) {
+                        if (t + 1u < ntiles) { commit(t + 1u, pre[(u + 1) % 4]); if (t + 5u < ntiles) issue(t + 5u, pre[(u + 1) % 4]); }
+                        __syncthreads();
+                    }
+                }
+            }
+        } else {
+        __syncthreads();
 #pragma unroll 1
         for (uint32_t t = 0; t < ntiles; t++) {
-            if (loader) {
-                if (t + 1u < ntiles) { commit(t + 1u); if (t + 2u < ntiles) issue(t + 2u); }
-            } else {
+            {
                 const int32_t *tl = tile[t & 1u][lane];
                 if (t == 0u) { xprev = tl[0]; if (pass) first1 = (int32_t)((uint32_t)xprev - (uint32_t)mulshr5(xprev, c0)); else first0 = xprev; }
                 const bool whole = 64u * t + 64u <= nmin;          /* every row has all of the tile: no step asks where its row ends */
@@ -428,6 +453,7 @@ __global__ __launch_bounds__(64 * PS_WAVES, 3) void k_prep_slow(Plan p)      /* 
 #undef PS_STEP
             }
             __syncthreads();
+        }
         }
         /* the stage's coefficient (linne_utility.c:176-190), in the lanes of wave 1 */
         if (role == 2u) xch[lane] = acc;
