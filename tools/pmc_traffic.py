@@ -10,7 +10,7 @@ KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the s
         ("k_fir_small<4, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"), ("k_fir_small<2, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"),
         ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_fwd_loss", "k_fwd_loss<P> (last layer: forward pass + ordered loss)"),
         ("k_fir2<1, true", "k_fir2<1,true,*> (forward of layer 0, jobs with several units)"),
-        ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"), ("k_quantize", "k_finalize"), ("k_fir_cascade", "k_finalize"),
+        ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep_slow", "k_prep_slow (the ordered pre-emphasis chains of loud 24-bit material; 16-bit: its blocks leave at once)"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"), ("k_quantize", "k_finalize"), ("k_fir_cascade", "k_finalize"),
         ("k_synth_l0_de", "k_synth_l0_de (layer 0 + de-emphasis + MS -> LR in one launch, tiles in LDS)"),
         ("k_synth_rows8", "k_synth_rows8<PB> / k_synth_rows<0> (a short layer: eight / four channel-frames per wave)"), ("k_synth_rows<0", "k_synth_rows8<PB> / k_synth_rows<0> (a short layer: eight / four channel-frames per wave)"),
         ("k_synth_rows", "k_synth_rows<NCH> (a long layer: four channel-frames per wave, the old taps on the matrix unit)"), ("k_deemph_lr", "k_deemph_lr (de-emphasis behind layer 0, MS -> LR on the way out; LINNE_AMD_DECODE_FUSED=0)"),
