@@ -711,8 +711,8 @@ LINNEApiResult LINNEDecoder_DecodeWhole(struct LINNEDecoder *decoder, const uint
      * something no encoder writes, the whole call starts over with the host's Rice decoder (stream_mode = 0, and the host path's
      * group size and slots), which restates the reference's; PCM beyond the 16-bit range only makes that group come back as int32.  60-minute stream, one GPU, 16 host threads: 62 ms against 94 with the
      * host's Rice decoder (profiles/r02_decode_stream.txt). */
-    int stream_mode;
-    { const char *e_ = getenv("LINNE_AMD_DECODE_STREAM"); stream_mode = (e_ ? atoi(e_) != 0 : 1); }
+    int stream_mode, stream_auto;
+    { const char *e_ = getenv("LINNE_AMD_DECODE_STREAM"); stream_mode = (e_ ? atoi(e_) != 0 : 1); stream_auto = (e_ == NULL); }
     if (decoder == NULL || data == NULL || buffer == NULL) return LINNE_APIRESULT_INVALID_ARGUMENT;
     if ((r = LINNEDecoder_DecodeHeader(data, data_size, &h)) != LINNE_APIRESULT_OK) return r;
     if ((r = LINNEDecoder_SetHeader(decoder, &h)) != LINNE_APIRESULT_OK) return r;
@@ -731,6 +731,21 @@ setup:      /* (again after the device's Rice decoder refused something: the hos
         if (gp->ndev == 0) { gp->ndev = lnn_parse_device_list(getenv("LINNE_AMD_DEVICES"), gp->device, LNN_MAX_DEVICES); if (gp->ndev == 0) { const char *e = getenv("LINNE_AMD_DEVICE"); gp->device[0] = e ? atoi(e) : 0; gp->ndev = 1; } }
         ndev = gp->ndev; window = ndev * LNN_SLOTS; nslots = LNN_SLOTS;
         group = default_group((F + ndev - 1) / ndev, &decoder->shape, &decoder->layers, 0); if (group > F) group = F ? F : 1;
+        /* Short streams: the device's Rice decoder walks a block's channels one after the other, 0.29 us per sample -- 6 ms for a
+         * stereo block of 10 240 samples, 24-28 ms for eight channels, whether the launch holds one block or thirty thousand -- while the
+         * host threads decode 150 samples per microsecond each.  Measured on stereo 44.1 kHz with 16 threads (tools/e2e.py,
+         * LINNE_AMD_DECODE_STREAM=1 / 0): 6 s 7.0 / 1.2 ms, 30 s 7.6 / 2.2, 3 min 9.8 / 7.7, 6 min 11.2 / 13.1, 10 min 12.5 / 20.6:
+         * they cross near 4.3 minutes.  Unless the environment says which, the call takes the way this estimate makes shorter */
+        if (stream_mode && stream_auto) {
+            const double smp = (double)S * (double)hd->num_channels, all = smp * (double)F;
+            const double t_host = 1.0 + all * ((uint64_t)F * hd->num_channels >= 1024u ? 5.4e-6 : 6.7e-6) / (double)threads;      /* ms; (three groups from 1024 channel-frames on, below: their decoding overlaps the GPU's work) */
+            const double t_stream = 1.0 + 0.29e-3 * smp + 1.05e-7 * all;
+            if (t_host < t_stream) stream_mode = 0;
+            stream_auto = 0;
+        }
+        /* the host's way with a stream that would be ONE group: three, so that the threads decode the second's codes while the GPU
+         * reconstructs the first (3 minutes of stereo: 7.9 -> 6.1 ms; LINNE_AMD_GROUP says otherwise) */
+        if (!stream_mode && !getenv("LINNE_AMD_GROUP") && group >= F && (uint64_t)F * hd->num_channels >= 1024u) group = (F + 2u) / 3u;
     }
     if (stream_mode) {
         /* The device's Rice decoder is serial per block: a launch takes ~9 ms for 300 blocks as for 30 000 -- a LATENCY, not a cost:

@@ -742,6 +742,24 @@ def _blocks(stream):
         off += size
 
 
+def test_decode_whole_picks_the_rice_decoder_by_the_streams_length(product, monkeypatch):
+    """Unless LINNE_AMD_DECODE_STREAM says which, a short stream's Rice codes are decoded by the host threads (the device's decoder is
+    serial per block: a latency of 0.29 us per sample of a block, however few blocks) and a long stream's by the device; the PCM is
+    the encoder's input either way.  Sixteen host threads, as on the GPU box: 100 stereo blocks of 1024 samples -- the host; 4000 --
+    the device; 600 blocks of 4096 samples -- the host, in three groups (decoding overlaps the GPU's work from 1024 channel-frames on)"""
+    monkeypatch.delenv("LINNE_AMD_DECODE_STREAM", raising=False)
+    monkeypatch.delenv("LINNE_AMD_GROUP", raising=False)
+    monkeypatch.setenv("LINNE_AMD_THREADS", "16")
+    piece = music(2, 200 * 1024, 16, seed=91)
+    for block, frames, tail, want in [(1024, 100, 17, 0), (1024, 4000, 300, 1), (4096, 600, 1000, 0)]:
+        total = frames * block + tail
+        x = np.ascontiguousarray(np.tile(piece, (1, total // piece.shape[1] + 1))[:, :total])
+        stream = product.encode_whole(x, 16, 44100, block, 5, True)
+        ret, dec = product.decode_whole(stream)
+        assert ret == 0 and np.array_equal(dec, x), f"{frames} blocks of {block}"
+        assert (product.last_decode_whole_mode() & 1) == want, f"{frames} blocks of {block}: mode {product.last_decode_whole_mode()}"
+
+
 @pytest.mark.parametrize("nch,bits,block,preset,total,group", [(2, 16, 4096, 7, 11 * 4096 + 1500, "3"), (1, 16, 2048, 4, 9 * 2048 + 777, "2"), (3, 24, 2048, 5, 6 * 2048 + 99, "4"),
                                                                (8, 8, 1024, 2, 5 * 1024 + 1000, "2"), (2, 16, 1023, 7, 5 * 1023 + 400, "5"), (2, 16, 10240, 7, 40 * 10240 + 9280, None)])
 def test_decode_whole_with_rice_decoding_on_the_device(product, monkeypatch, nch, bits, block, preset, total, group):
