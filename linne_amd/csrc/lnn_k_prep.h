@@ -356,13 +356,10 @@ __global__ __launch_bounds__(64 * PS_WAVES, 2) void k_prep_slow(Plan p)      /* 
     const uint32_t f = row / C, ch = row - f * C;
     const uint32_t n = p.cls[p.cls_of_frame[f]].n;
     if (role == 0u) { rowid[lane] = row; nlen[lane] = n; }
-    uint32_t nmax = n, nmin = n;
+    uint32_t nmax = n;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t a = (uint32_t)__shfl_xor((int)nmax, o), b = (uint32_t)__shfl_xor((int)nmin, o);
-        nmax = a > nmax ? a : nmax; nmin = b < nmin ? b : nmin;
-    }
-    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax); nmin = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmin);
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t a = (uint32_t)__shfl_xor((int)nmax, o); nmax = a > nmax ? a : nmax; }
+    nmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)nmax);
     const uint32_t ntiles = (nmax + 63u) / 64u;
     __syncthreads();
     /* the loaders (waves 0 and 3, half the rows each): instruction k of loader h takes rows 4 (8 h + k) + (lane >> 4), samples
@@ -425,7 +422,11 @@ __global__ __launch_bounds__(64 * PS_WAVES, 2) void k_prep_slow(Plan p)      /* 
             {
                 const int32_t *tl = tile[t & 1u][lane];
                 if (t == 0u) { xprev = tl[0]; if (pass) first1 = (int32_t)((uint32_t)xprev - (uint32_t)mulshr5(xprev, c0)); else first0 = xprev; }
-                const bool whole = 64u * t + 64u <= nmin;          /* every row has all of the tile: no step asks where its row ends */
+                /* no row ends inside this tile: the rows that have all of it run the plain steps, and so do the rows that ended before it --
+                 * behind a row's end xtmp holds zeros, and from one sample behind it on they make the stage's input and its products +0.0,
+                 * which leave a chain's bits alone.  The one tile a row's end n falls into (n / 64; the tile that STARTS at n when n is a
+                 * multiple of 64: its first step would add the product of index n - 1) asks every step */
+                const bool whole = !__any((n >> 6) == t);
                 /* step g: the products of index g - 1 = (value before) x (value before | this value), added while g < n */
 #define PS_STEP(SQ_, GUARD_, PASS_, V_, S_) { \
                     const int32_t v = (V_); \

@@ -1008,8 +1008,9 @@ def test_prep_and_statistics_forms_agree(ctx, product, oracle, monkeypatch, stat
 def test_loud_and_quiet_frames_in_one_call(ctx, oracle, monkeypatch, prep_defer):
     """k_prep_slow's list: 71 stereo frames of 24-bit material in one call, every other one loud -- the pre-emphasis sums of both its
     channels leave the exact-integer range (ordered chains); of the quiet ones only the side channel's do: about a hundred listed rows
-    between rows k_prep finishes itself = two blocks of the kernel, the second partly filled; frames of five lengths, one of them three
-    samples long, one a single sample (no product at all); silence among the loud ones.  The oracle's parameters (pre-emphasis
+    between rows k_prep finishes itself = two blocks of the kernel, the second partly filled; frames of ten lengths in one block of rows
+    (ends inside a tile, on a tile's edge, one sample off it), one of them three samples long, one a single sample (no product at
+    all); silence among the loud ones.  The oracle's parameters (pre-emphasis
     coefficients and first samples among them) and residual, frame by frame"""
     monkeypatch.setenv("LINNE_AMD_PREP_DEFER", prep_defer)
     nch, bits, block, preset, F = 2, 24, 4096, 5, 71
@@ -1017,7 +1018,7 @@ def test_loud_and_quiet_frames_in_one_call(ctx, oracle, monkeypatch, prep_defer)
     loud = np.zeros(F, dtype=bool); loud[::2] = True
     frames[loud] = np.clip(frames[loud].astype(np.int64) * 6, -(1 << (bits - 1)), (1 << (bits - 1)) - 1).astype(np.int32)
     frames[4] = 0
-    ns = np.full(F, block, dtype=np.uint32); ns[10] = 3; ns[12] = 1; ns[14] = 1001; ns[-1] = 2047
+    ns = np.full(F, block, dtype=np.uint32); ns[10] = 3; ns[12] = 1; ns[14] = 1001; ns[16] = 2048; ns[18] = 64; ns[20] = 65; ns[22] = 63; ns[24] = 4095; ns[-1] = 2047
     for f in range(F): frames[f, :, ns[f]:] = 0
     shape = ctx.shape(nch, bits, block, preset, True)
     res, prm, st = ctx.encode_frames_host(shape, frames, ns)
