@@ -60,7 +60,7 @@ KERNEL_KINDS = {13: "k_stats", 14: "k_autocorr_lane", 1: "k_prep", 3: "k_autocor
                 25: "k_search_long<P> (search of the long layer over the shared window + fused one-unit forward)",
                 18: "k_fir_small<P,false,*> (search of the last, short layer)", 15: "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)",
                 6: "k_fir2<0> (exact fallback)", 7: "k_select", 8: "k_fir2<1,false,true> (forward, jobs with several units)",
-                19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_fwd_loss<P> (last layer: forward pass + ordered loss)", 21: "k_autocorr_hist<P,0> (long layer, one-unit trial)", 22: "k_autocorr_hist<P,1> (long layer, two-unit trial)", 23: "k_autocorr_sub<P> (long layer, trials of order <= 32)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
+                19: "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)", 20: "k_last_layer<P> / k_fwd_loss<P> (last layer: exact search + forward pass + ordered loss in one launch / forward pass + loss)", 21: "k_autocorr_hist<P,0> (long layer, one-unit trial)", 22: "k_autocorr_hist<P,1> (long layer, two-unit trial)", 23: "k_autocorr_sub<P> (long layer, trials of order <= 32)", 16: "k_fir2<1,true,*> (forward of layer 0, jobs with several units)",
                 9: "k_chain_sum<1>", 10: "k_finalize",      # (k_quantize + k_fir_cascade since round 3; the name keys profiles/pmc_latest.json)
                 11: "k_synthesize (one wave per channel-frame, all layers)", 12: "k_ms_to_lr",
                 30: "k_synth_big<P> (synthesis of the long layer)", 31: "k_synth_small<P> (synthesis of the short layers, de-emphasis)",

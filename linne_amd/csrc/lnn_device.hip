@@ -34,6 +34,7 @@
 #include "lnn_k_fir.h"
 #include "lnn_k_search.h"
 #include "lnn_k_fwdloss.h"
+#include "lnn_k_lastlayer.h"
 #include "lnn_k_af.h"
 #include "lnn_k_train.h"
 #include "lnn_k_decode.h"
@@ -91,7 +92,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, prep_defer /* LINNE_AMD_PREP_DEFER (default 1): inexact pre-emphasis sums go to k_prep_slow */, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, prep_defer /* LINNE_AMD_PREP_DEFER (default 1): inexact pre-emphasis sums go to k_prep_slow */, last_layer /* LINNE_AMD_LAST_LAYER (default 1): the last layer's search, forward pass and loss in one launch (k_last_layer) where it takes the chunk */, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -301,6 +302,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.rows16 = env_int("LINNE_AMD_ROWS16", 1);
     ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
     ctx->knob.prep_defer = env_int("LINNE_AMD_PREP_DEFER", 1);
+    ctx->knob.last_layer = env_int("LINNE_AMD_LAST_LAYER", 1);
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
     ctx->knob.rows8 = env_int("LINNE_AMD_DECODE_ROWS8", -1);
@@ -764,6 +766,13 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         bool fuse_all = fuse_cfg;
         for (uint32_t f = f0; f < f0 + Fc && fuse_all; f++) if ((ctx->sig_cls[ctx->cur_idx[f]].na % (4u * Plast)) != 0) fuse_all = false;
         p.fused_last = fuse_cfg ? 1u : 0u;
+        /* k_last_layer (search + forward pass + loss of the last layer in one launch) takes a chunk whole or not at all: every frame
+         * k_fwd_loss's and with every trial (LINNE_AMD_EXACT keeps the certified search's exact fallback in use: that knob compares the two) */
+        bool last_layer_all = fuse_all && ctx->knob.last_layer && !ctx->force_exact && !ctx->af_iters && !ctx->learning && J > 256u;
+        if (last_layer_all) {
+            uint32_t nt = 0; for (uint32_t u = 1; u <= Plast && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
+            for (uint32_t f = f0; f < f0 + Fc && last_layer_all; f++) if (ctx->sig_cls[ctx->cur_idx[f]].ntrials[hs.L - 1] != nt) last_layer_all = false;
+        }
         p.search_long = ctx->knob.search_long ? 1u : 0u;
         p.rows16 = ctx->knob.rows16 ? 1u : 0u;
         p.prep_general = ctx->knob.prep_general ? 1u : 0u;
@@ -899,6 +908,20 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
               }
               }
               span_end(ctx, sp_, st); }
+            /* the last layer of a chunk k_last_layer takes: search, selection, forward pass and loss from one pass over the input */
+            const bool ll = last_layer_all && l + 1 == hs.L && fcfg && fall && !final_pass && spec_ok;
+            if (ll) {
+                { const int sp_ = span_begin(ctx, 20, st);
+                  const dim3 g(((uint32_t)Jq + 63) / 64), b(64);
+                  switch (hs.P[l]) {
+                  case 2: hipLaunchKernelGGL(k_last_layer<2>, g, b, 0, st, q, l, cur); break;
+                  case 4: hipLaunchKernelGGL(k_last_layer<4>, g, b, 0, st, q, l, cur); break;
+                  case 8: hipLaunchKernelGGL(k_last_layer<8>, g, b, 0, st, q, l, cur); break;
+                  default: hipLaunchKernelGGL(k_last_layer<16>, g, b, 0, st, q, l, cur); break;
+                  }
+                  span_end(ctx, sp_, st); }
+                { const int sp_ = span_begin(ctx, 7, st); hipLaunchKernelGGL(k_select, dim3(((uint32_t)Jq + 63) / 64), dim3(64), 0, st, q, l, 2u); span_end(ctx, sp_, st); }
+            } else {
             {   /* unit-count search.  Short layers: the register-window kernel.  The long layer: k_search_long for the frames it takes
                  * (search_long_takes), k_fir2<2> for the others (it returns at once for the jobs taken there) */
                 bool long_any = false, long_all = true;
@@ -953,6 +976,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
                 }
                 span_end(ctx, sp_, st);
             }
+            }       /* (not k_last_layer's) */
             if (af_iters && (ret = run_af(q, Jq, l, cur, af_iters)) != LNN_OK) return ret;
             if (final_pass && l + 1 == hs.L) { cur ^= 1u; continue; }       /* the final pass needs no output of the last layer: only its parameters */
             if (!(l + 1 == hs.L && fall)) { const int sp_ = span_begin(ctx, (l == 0) ? 16 : (fir_spec ? 8 : 19), st); launch_fir<1>(st, q, l, cur, (uint32_t)Jq, (S + FIR_TILE - 1) / FIR_TILE, fir_spec != 0); span_end(ctx, sp_, st); }

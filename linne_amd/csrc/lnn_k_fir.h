@@ -552,7 +552,7 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
 {
     const uint32_t job = blockIdx.x * blockDim.x + threadIdx.x;
     if (job >= p.J) return;
-    if (exact && !p.uncertain[job]) return;
+    if (exact == 1u && !p.uncertain[job]) return;              /* (exact = 2: every job's ordered means are in tloss -- k_last_layer) */
     const DevClass &c = job_class(p, job);
     double min_loss = (double)FLT_MAX;
     uint32_t best = 0;
@@ -614,6 +614,7 @@ __global__ void k_select(Plan p, uint32_t layer, uint32_t exact)
         if (!ok) atomicAdd(p.ucount, 1u);
     }
     const uint32_t P = p.P[layer];
+    if (exact == 2u) p.jloss[job] = p.tsum[((size_t)job * LNN_MAXT + best) * p.npart];      /* the winner's forward loss, as k_last_layer left it */
     p.lunits[(size_t)job * LNN_MAXL + layer] = c.trial_u[layer][best];
     const double *h = p.tcoef + ((size_t)job * LNN_MAXT + best) * LNN_MAXP;
     double *dst = p.lparams + ((size_t)job * LNN_MAXL + layer) * LNN_MAXP;

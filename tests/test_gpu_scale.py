@@ -79,7 +79,7 @@ def run_batch(c, frames, ns, check_decode=True, preset=PRESET, nch=NCH, bits=BIT
     pcm = torch.from_numpy(frames).cuda()
     res, prm, st = c.encode_frames(shape, pcm, ns)
     c.synchronize()
-    c.launches = {k: c.last_launches(k) for k in (1, 3, 20, 21, 22, 23)}        # (the decode call below resets the spans)
+    c.launches = {k: c.last_launches(k) for k in (1, 3, 18, 20, 21, 22, 23)}        # (the decode call below resets the spans)
     out = (res.cpu().numpy(), prm.cpu().numpy(), st.cpu().numpy())
     if check_decode:
         dec = c.decode_frames(shape, res, prm, ns)
@@ -268,6 +268,51 @@ def test_exact_search_everywhere_equals_the_certified_search(ctx_env, big):
         assert c.last_fallback_count() == F * NCH * 4 * 3
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
     assert margin > 0.0
+
+
+def test_last_layer_in_one_launch_equals_the_three_kernel_form(ctx_env, oracle, big):
+    """A chunk of 24 576 jobs or more whose frames all have every trial: k_last_layer makes the last layer's exact ordered search means,
+    the strict-< argmin and the winner's forward loss in ONE pass over the input (lanes = jobs), where LINNE_AMD_LAST_LAYER=0 runs the
+    certified search (k_fir_small), the selection with its fallback and k_fwd_loss.  Same parameters, residual and statistics (the loss
+    of the best pass among them) on every frame of the batch, tail included; a sample of them against the oracle"""
+    with ctx_env({}, scratch_bytes=8 << 30) as c:
+        c.enable_timing(True)
+        a = run_batch(c, big["frames"], big["ns"], check_decode=False)
+        assert c.launches[20] >= 1 and c.launches[18] == 0, f"k_last_layer did not take the chunk: {c.launches}"
+        assert c.last_fallback_count() == 0
+    with ctx_env({"LINNE_AMD_LAST_LAYER": "0"}, scratch_bytes=8 << 30) as c:
+        c.enable_timing(True)
+        b = run_batch(c, big["frames"], big["ns"], check_decode=False)
+        assert c.launches[18] >= 1, c.launches
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    idx = sample_indices(NBIG, seed=7)
+    compare_sample(oracle_taps(oracle, big["frames"], big["ns"], idx, big["cache"]), big["ns"], a[0], a[1], a[2], "k_last_layer")
+
+
+def test_last_layer_in_one_launch_with_eight_taps(ctx_env, oracle):
+    """k_last_layer<8> (presets 2-4: layers 4 / 64 / 8): 3 328 stereo frames of 1024 samples = 26 624 jobs in one chunk, every frame
+    with all four trials; against LINNE_AMD_LAST_LAYER=0 on every frame and against the oracle on a sample"""
+    nch, bits, block, preset, F = 2, 16, 1024, 4, 3328
+    base = np.stack([music(nch, block, bits, seed=700 + k) for k in range(64)])
+    frames = np.ascontiguousarray(np.tile(base, ((F + 63) // 64, 1, 1))[:F])
+    frames[1::2] = frames[1::2] // 3                           # (two loudness classes, so that the unit counts vary)
+    ns = np.full(F, block, dtype=np.uint32)
+    out = []
+    for env in ({}, {"LINNE_AMD_LAST_LAYER": "0"}):
+        with ctx_env(env, scratch_bytes=4 << 30) as c:
+            shape = c.shape(nch, bits, block, preset, True)
+            c.enable_timing(True)
+            out.append(c.encode_frames_host(shape, frames, ns))
+            assert c.last_launches(1) == 1, "expected one chunk"
+            assert (c.last_launches(18) == 0) == (not env), f"kind 18 launches: {c.last_launches(18)}"
+    for a, b, what in zip(out[0], out[1], ("residual", "parameters", "statistics")):
+        assert np.array_equal(a, b), what
+    enc = oracle.encoder(nch, bits, 44100, block, preset, True)
+    for f in list(range(0, 24)) + list(range(F - 8, F)):
+        tap, ores = enc.hotpath(frames[f])
+        _check_taps(tap, out[0][1][f], out[0][2][f], preset, nch, f"frame {f}")
+        assert np.array_equal(ores, out[0][0][f]), f"frame {f}"
+    enc.close()
 
 
 @pytest.mark.parametrize("devices,group", [([0, 0], 0), ([0, 0, 0], 37), ([0], 100)])

@@ -8,7 +8,7 @@ KIND = [("k_search_long", "k_search_long<P> (search of the long layer over the s
         ("k_fir2<2, false, true>", "k_fir2<2,false,true> (search of the long layer + fused one-unit forward; frames k_search_long does not take)"),
         ("k_fir_small<16, false", "k_fir_small<P,false,*> (search of the last, short layer)"), ("k_fir_small<8, false", "k_fir_small<P,false,*> (search of the last, short layer)"),
         ("k_fir_small<4, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"), ("k_fir_small<2, true", "k_fir_small<P,true,*> (search of layer 0 + fused one-unit forward)"),
-        ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_fwd_loss", "k_fwd_loss<P> (last layer: forward pass + ordered loss)"),
+        ("k_fir2<1, false, true>", "k_fir2<1,false,true> (forward, jobs with several units)"), ("k_fir2<1, false, false>", "k_fir2<1,false,false> (forward of the last layer, frames k_fwd_loss does not take)"), ("k_last_layer", "k_last_layer<P> / k_fwd_loss<P> (last layer: exact search + forward pass + ordered loss in one launch / forward pass + loss)"), ("k_fwd_loss", "k_last_layer<P> / k_fwd_loss<P> (last layer: exact search + forward pass + ordered loss in one launch / forward pass + loss)"),
         ("k_fir2<1, true", "k_fir2<1,true,*> (forward of layer 0, jobs with several units)"),
         ("k_autocorr_hist<128, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<64, 0>", "k_autocorr_hist<P,0> (long layer, one-unit trial)"), ("k_autocorr_hist<128, 1>", "k_autocorr_hist<P,1> (long layer, two-unit trial)"), ("k_autocorr_sub", "k_autocorr_sub<P> (long layer, trials of order <= 32)"), ("k_autocorr2", "k_autocorr2"), ("k_autocorr_lane", "k_autocorr_lane"), ("k_levinson", "k_levinson_lds"), ("k_prep_slow", "k_prep_slow (the ordered pre-emphasis chains of loud 24-bit material; 16-bit: its blocks leave at once)"), ("k_prep", "k_prep"), ("k_finalize", "k_finalize"), ("k_quantize", "k_finalize"), ("k_fir_cascade", "k_finalize"),
         ("k_synth_l0_de", "k_synth_l0_de (layer 0 + de-emphasis + MS -> LR in one launch, tiles in LDS)"),
