@@ -768,7 +768,10 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         p.fused_last = fuse_cfg ? 1u : 0u;
         /* k_last_layer (search + forward pass + loss of the last layer in one launch) takes a chunk whole or not at all: every frame
          * k_fwd_loss's and with every trial (LINNE_AMD_EXACT keeps the certified search's exact fallback in use: that knob compares the two) */
-        bool last_layer_all = fuse_all && ctx->knob.last_layer && !ctx->force_exact && !ctx->af_iters && !ctx->learning && J > 256u;
+        /* (from 49 152 jobs on, or when LINNE_AMD_LAST_LAYER=2 says always: with lanes = jobs and a wave per 64 of them a chunk of J jobs is
+         * J / 64 waves on 1024 SIMDs, and a lone wave walks its frames in 4.1 ms however few they are -- the 31 008 jobs of a group of
+         * EncodeWhole took 4.1 ms here and 1.8 in the three kernels: 108 -> 110.5 ms per 60-minute stream) */
+        bool last_layer_all = fuse_all && ctx->knob.last_layer && !ctx->force_exact && !ctx->af_iters && !ctx->learning && (J >= 49152u || (ctx->knob.last_layer == 2 && J > 256u));
         if (last_layer_all) {
             uint32_t nt = 0; for (uint32_t u = 1; u <= Plast && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
             for (uint32_t f = f0; f < f0 + Fc && last_layer_all; f++) if (ctx->sig_cls[ctx->cur_idx[f]].ntrials[hs.L - 1] != nt) last_layer_all = false;

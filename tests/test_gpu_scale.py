@@ -271,11 +271,11 @@ def test_exact_search_everywhere_equals_the_certified_search(ctx_env, big):
 
 
 def test_last_layer_in_one_launch_equals_the_three_kernel_form(ctx_env, oracle, big):
-    """A chunk of 24 576 jobs or more whose frames all have every trial: k_last_layer makes the last layer's exact ordered search means,
+    """A chunk of 49 152 jobs or more (LINNE_AMD_LAST_LAYER=2: 24 576) whose frames all have every trial: k_last_layer makes the last layer's exact ordered search means,
     the strict-< argmin and the winner's forward loss in ONE pass over the input (lanes = jobs), where LINNE_AMD_LAST_LAYER=0 runs the
     certified search (k_fir_small), the selection with its fallback and k_fwd_loss.  Same parameters, residual and statistics (the loss
     of the best pass among them) on every frame of the batch, tail included; a sample of them against the oracle"""
-    with ctx_env({}, scratch_bytes=8 << 30) as c:
+    with ctx_env({"LINNE_AMD_LAST_LAYER": "2"}, scratch_bytes=8 << 30) as c:        # (2: from 24 576 jobs on; the default waits for 49 152)
         c.enable_timing(True)
         a = run_batch(c, big["frames"], big["ns"], check_decode=False)
         assert c.launches[20] >= 1 and c.launches[18] == 0, f"k_last_layer did not take the chunk: {c.launches}"
@@ -298,13 +298,13 @@ def test_last_layer_in_one_launch_with_eight_taps(ctx_env, oracle):
     frames[1::2] = frames[1::2] // 3                           # (two loudness classes, so that the unit counts vary)
     ns = np.full(F, block, dtype=np.uint32)
     out = []
-    for env in ({}, {"LINNE_AMD_LAST_LAYER": "0"}):
+    for env in ({"LINNE_AMD_LAST_LAYER": "2"}, {"LINNE_AMD_LAST_LAYER": "0"}):
         with ctx_env(env, scratch_bytes=4 << 30) as c:
             shape = c.shape(nch, bits, block, preset, True)
             c.enable_timing(True)
             out.append(c.encode_frames_host(shape, frames, ns))
             assert c.last_launches(1) == 1, "expected one chunk"
-            assert (c.last_launches(18) == 0) == (not env), f"kind 18 launches: {c.last_launches(18)}"
+            assert (c.last_launches(18) == 0) == (env["LINNE_AMD_LAST_LAYER"] == "2"), f"kind 18 launches: {c.last_launches(18)}"
     for a, b, what in zip(out[0], out[1], ("residual", "parameters", "statistics")):
         assert np.array_equal(a, b), what
     enc = oracle.encoder(nch, bits, 44100, block, preset, True)
