@@ -771,7 +771,7 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
         /* (from 49 152 jobs on, or when LINNE_AMD_LAST_LAYER=2 says always: with lanes = jobs and a wave per 64 of them a chunk of J jobs is
          * J / 64 waves on 1024 SIMDs, and a lone wave walks its frames in 4.1 ms however few they are -- the 31 008 jobs of a group of
          * EncodeWhole took 4.1 ms here and 1.8 in the three kernels: 108 -> 110.5 ms per 60-minute stream) */
-        bool last_layer_all = fuse_all && ctx->knob.last_layer && !ctx->force_exact && !ctx->af_iters && !ctx->learning && (J >= 49152u || (ctx->knob.last_layer == 2 && J > 256u));
+        bool last_layer_all = fuse_all && ctx->knob.last_layer && !ctx->force_exact && !ctx->af_iters && !ctx->learning && (J >= (use_sub ? 49152u : 81920u) || (ctx->knob.last_layer == 2 && J > 256u));      /* (a chunk alone on the GPU has nothing beside its lone waves: it pays from ~78 k jobs on -- 124 k x 4.1 / 6.6) */
         if (last_layer_all) {
             uint32_t nt = 0; for (uint32_t u = 1; u <= Plast && u <= (uint32_t)LNN_MAXU; u <<= 1) nt++;
             for (uint32_t f = f0; f < f0 + Fc && last_layer_all; f++) if (ctx->sig_cls[ctx->cur_idx[f]].ntrials[hs.L - 1] != nt) last_layer_all = false;
