@@ -316,6 +316,9 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
         const uint32_t i = tid + (uint32_t)q * FIR_THREADS;
         hreg[q] = (i < nr * NT * P) ? p.tcoef[((size_t)(job0 + i / (NT * P)) * LNN_MAXT + (i % (NT * P)) / P) * LNN_MAXP + i % P] : 0.0;
     }
+    if (!L0 && s0 >= (uint32_t)HP && s0 + FIR_TILE <= na) {         /* an interior tile of doubles: 16-byte streaming loads (S, s0, HP are even) -- the last layer's search 4.31 -> 3.72 ms against 8-byte ones */
+        for (uint32_t i = 2 * tid; i < HP + FIR_TILE; i += 2 * FIR_THREADS) *(lnn_d2 *)(xs + i) = __builtin_nontemporal_load((const lnn_d2 *)(x + (s0 - HP + i)));
+    } else
     for (uint32_t i = tid; i < HP + FIR_TILE; i += FIR_THREADS) {
         const int64_t g = (int64_t)s0 - HP + i;
         xs[i] = (g >= 0 && g < (int64_t)na) ? (L0 ? ((double)xi[g] * p.scale) : x[g]) : 0.0;
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(FIR_THREADS, 4) void k_fir_small(Plan p, uint32_t l
 #pragma unroll
         for (int i = 0; i < FIR_SPL / 2; i++) {
             const uint32_t e = 2 * ln + 128 * i, g = wbase + e;
-            if (g + 1 < na) *(lnn_d2 *)(dst + g) = *(const lnn_d2 *)(ob + e);
+            if (g + 1 < na) __builtin_nontemporal_store(*(const lnn_d2 *)(ob + e), (lnn_d2 *)(dst + g));      /* (streaming: layer 0's kernel is its 330 KB of output per channel-frame -- 3.70 -> 3.13 ms; the same hint on k_search_long's output, on the decode kernels' stores and on the lanes = jobs kernels' loads changed nothing) */
             else if (g < na) dst[g] = ob[e];
         }
     }
