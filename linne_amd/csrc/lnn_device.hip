@@ -92,7 +92,7 @@ struct LINNEAmdContext {
     void *hstage; uint64_t hstage_cap;  /* device staging of the host-buffer forms (EncodeFramesHost / DecodeFramesHost: block-at-a-time calls), kept between calls */
     /* debug / test knobs that select a kernel form per CALL (read_call_knobs: once at the top of an encode / decode call, never
      * inside the chunk loop; production never sets them and gets the batch-size rules) */
-    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, prep_defer /* LINNE_AMD_PREP_DEFER (default 1): inexact pre-emphasis sums go to k_prep_slow */, last_layer /* LINNE_AMD_LAST_LAYER (default 1): the last layer's search, forward pass and loss in one launch (k_last_layer) where it takes the chunk */, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
+    struct { int sort, l0_products, wide, search_long, rows16, prep_general, stats_rows /* -1 = by batch size */, hist /* -1 = by batch size */, decode_kernel /* 0 = by batch size, 1 = wave, 2 = lanes, 3 = pipe, 4 = rows */, rows8, streams /* LINNE_AMD_STREAMS of this call, 0 = not given */, nostats, fwd_loss_mw /* LINNE_AMD_FWD_LOSS_MW (default 1): chunks below 65 536 jobs take the five-wave form of k_fwd_loss */, prep_defer /* LINNE_AMD_PREP_DEFER (default 1): inexact pre-emphasis sums go to k_prep_slow */, last_layer /* LINNE_AMD_LAST_LAYER (default 1): the last layer's search, forward pass and loss in one launch (k_last_layer) where it takes the chunk */, decode_fused /* LINNE_AMD_DECODE_FUSED (default 1): layer 0 + de-emphasis + MS -> LR in one launch */; uint32_t dbg_maxtr; } knob;
 };
 
 #define HIPCHK(ctx, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); return LNN_NG; } } while (0)
@@ -302,6 +302,7 @@ static void read_call_knobs(LINNEAmdContext *ctx)
     ctx->knob.rows16 = env_int("LINNE_AMD_ROWS16", 1);
     ctx->knob.prep_general = env_int("LINNE_AMD_PREP_GENERAL", 0);
     ctx->knob.prep_defer = env_int("LINNE_AMD_PREP_DEFER", 1);
+    ctx->knob.fwd_loss_mw = env_int("LINNE_AMD_FWD_LOSS_MW", 1);
     ctx->knob.last_layer = env_int("LINNE_AMD_LAST_LAYER", 1);
     ctx->knob.stats_rows = env_int("LINNE_AMD_STATS_ROWS", -1);
     { const char *e = getenv("LINNE_AMD_HIST"); ctx->knob.hist = e ? (atoi(e) != 0) : -1; }
@@ -970,8 +971,15 @@ extern "C" int LINNEAmd_EncodeFramesDevice(struct LINNEAmdContext *ctx, const st
              * kernel and write nothing else */
             if (l + 1 == hs.L && fcfg && !final_pass) {
                 const int sp_ = span_begin(ctx, 20, st);
-                const dim3 g(((uint32_t)Jq + 63) / 64), b(64);
-                switch (hs.P[l]) {
+                const dim3 g(((uint32_t)Jq + 63) / 64), b(64), b5(320);
+                /* fewer than 1024 waves of 64 jobs: each would be alone on its SIMD (1.4 ms per launch however few) -- five waves per 64 jobs then (k_fwd_loss_mw) */
+                if (Jq < 65536u && ctx->knob.fwd_loss_mw) switch (hs.P[l]) {
+                case 2: hipLaunchKernelGGL(k_fwd_loss_mw<2>, g, b5, 0, st, q, l, cur); break;
+                case 4: hipLaunchKernelGGL(k_fwd_loss_mw<4>, g, b5, 0, st, q, l, cur); break;
+                case 8: hipLaunchKernelGGL(k_fwd_loss_mw<8>, g, b5, 0, st, q, l, cur); break;
+                default: hipLaunchKernelGGL(k_fwd_loss_mw<16>, g, b5, 0, st, q, l, cur); break;
+                }
+                else switch (hs.P[l]) {
                 case 2: hipLaunchKernelGGL(k_fwd_loss<2>, g, b, 0, st, q, l, cur); break;
                 case 4: hipLaunchKernelGGL(k_fwd_loss<4>, g, b, 0, st, q, l, cur); break;
                 case 8: hipLaunchKernelGGL(k_fwd_loss<8>, g, b, 0, st, q, l, cur); break;
