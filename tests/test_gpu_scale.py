@@ -289,6 +289,22 @@ def test_last_layer_in_one_launch_equals_the_three_kernel_form(ctx_env, oracle, 
     compare_sample(oracle_taps(oracle, big["frames"], big["ns"], idx, big["cache"]), big["ns"], a[0], a[1], a[2], "k_last_layer")
 
 
+def test_fwd_loss_forms_agree(ctx_env, big):
+    """the last layer's forward pass and loss for a chunk of 25 600 jobs: five waves per 64 jobs (k_fwd_loss_mw: four filter 16 samples
+    of a super-tile each, the fifth adds the magnitudes in sample order -- the default below 65 536 jobs) and one wave per 64 jobs
+    (LINNE_AMD_FWD_LOSS_MW=0) give the same statistics -- the best pass and its loss among them --, parameters and residual"""
+    with ctx_env({}, scratch_bytes=8 << 30) as c:
+        c.enable_timing(True)
+        a = run_batch(c, big["frames"], big["ns"], check_decode=False)
+        assert c.launches[20] >= 1 and c.launches[18] >= 1, c.launches      # (k_fwd_loss's kind ran, behind the certified search: not k_last_layer)
+    with ctx_env({"LINNE_AMD_FWD_LOSS_MW": "0"}, scratch_bytes=8 << 30) as c:
+        b = run_batch(c, big["frames"], big["ns"], check_decode=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    if "one_chunk" in big:
+        o = big["one_chunk"]
+        assert np.array_equal(a[0], o[0]) and np.array_equal(a[1], o[1]) and np.array_equal(a[2], o[2], equal_nan=True)
+
+
 def test_last_layer_in_one_launch_with_eight_taps(ctx_env, oracle):
     """k_last_layer<8> (presets 2-4: layers 4 / 64 / 8): 3 328 stereo frames of 1024 samples = 26 624 jobs in one chunk, every frame
     with all four trials; against LINNE_AMD_LAST_LAYER=0 on every frame and against the oracle on a sample"""
